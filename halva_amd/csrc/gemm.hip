@@ -1,0 +1,286 @@
+// bf16 GEMM on v_mfma_f32_32x32x16_bf16 for the small dense contractions of the vision side of the DPA step:
+// the mm_projector MLP (fwd: bias + GELU epilogue; bwd: NN and TN forms) and CLIP's patch-embed (im2col + GEMM).
+//   C[M,N] = epi( opA(A) @ opB(B)^T + bias ),   opA(A) = A[M,K] or A given as [K,M];  opB(B) = B[N,K] or [K,N]
+// Workgroup = 4 waves as 2x2, tile 128x128x64, each wave 64x64 (2x2 MFMA tiles); operands are register-staged
+// into double-buffered swizzled LDS tiles; transposed operands are read with ds_read_b64_tr_b16.
+#include "common.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ int off64(int row, int ch) {    // [rows][64] bf16 tile, 128-byte rows
+    return row * 128 + ((ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))) << 4);
+}
+__device__ __forceinline__ int off128(int row, int ch) {   // [rows][128] bf16 tile, 256-byte rows
+    return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+}
+
+// One 128(rows of the output dim) x 64(k) operand tile.  TRANS=false: source is [dim][K] (k contiguous) and the LDS
+// image is [128][64]; TRANS=true: source is [K][dim] and the LDS image is [64][128], read transposed.
+template <bool TRANS>
+struct Operand {
+    u32x4 r[4];
+    __device__ __forceinline__ void load(const bf16_t* src, int64_t ld, int dim0, int dim_lim, int k0, int K) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cid = threadIdx.x + 256 * i;
+            bool ok;
+            const bf16_t* ptr;
+            if (!TRANS) {
+                const int row = cid >> 3, ch = cid & 7;
+                ok = (dim0 + row < dim_lim) && (k0 + ch * 8 < K);
+                ptr = src + (int64_t)(dim0 + row) * ld + k0 + ch * 8;
+            } else {
+                const int row = cid >> 4, ch = cid & 15;
+                ok = (k0 + row < K) && (dim0 + ch * 8 < dim_lim);
+                ptr = src + (int64_t)(k0 + row) * ld + dim0 + ch * 8;
+            }
+            r[i] = ok ? *reinterpret_cast<const u32x4*>(ptr) : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    __device__ __forceinline__ void store(char* tile) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cid = threadIdx.x + 256 * i;
+            const int off = TRANS ? off128(cid >> 4, cid & 15) : off64(cid >> 3, cid & 7);
+            *reinterpret_cast<u32x4*>(tile + off) = r[i];
+        }
+    }
+    // fragment for rows [row0, row0+32) of the output dim, k-step ks (16 deep): lane (r, h) holds k = 16*ks + 8*h + j
+    static __device__ __forceinline__ s16x8 frag(const char* tile, int row0, int ks, int lane) {
+        if (!TRANS) {
+            return *reinterpret_cast<const s16x8*>(tile + off64(row0 + (lane & 31), 2 * ks + (lane >> 5)));
+        } else {
+            s16x8 out;
+            const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, h = g >> 1;
+            const int c = row0 + 16 * (g & 1) + 4 * pp;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int kr = 16 * ks + 8 * h + 4 * jj + q;   // natural k order: element j = 4*jj + e <-> k = 8*h + j
+                const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(tile + off128(kr, c >> 3) + (c & 7) * 2));
+                out[4 * jj + 0] = t[0];
+                out[4 * jj + 1] = t[1];
+                out[4 * jj + 2] = t[2];
+                out[4 * jj + 3] = t[3];
+            }
+            return out;
+        }
+    }
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+struct GemmParams {
+    const bf16_t* A;
+    const bf16_t* B;
+    const bf16_t* bias;
+    void* C;
+    void* pre;      // optional pre-activation output (same dtype/shape as C)
+    int64_t lda, ldb, ldc;
+    int M, N, K;
+    int epilogue, out_f32, accumulate;
+};
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+    constexpr int TILE = 128 * 64 * 2;   // bytes of one operand tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* a_lds = smem;               // [2][TILE]
+    char* b_lds = smem + 2 * TILE;    // [2][TILE]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    Operand<TA> sa;
+    Operand<TB> sb;
+    const int nk = (p.K + 63) / 64;
+    sa.load(p.A, p.lda, m0, p.M, 0, p.K);
+    sb.load(p.B, p.ldb, n0, p.N, 0, p.K);
+    sa.store(a_lds);
+    sb.store(b_lds);
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+        const char* at = a_lds + (it & 1) * TILE;
+        const char* bt = b_lds + (it & 1) * TILE;
+        if (it + 1 < nk) {
+            sa.load(p.A, p.lda, m0, p.M, (it + 1) * 64, p.K);
+            sb.load(p.B, p.ldb, n0, p.N, (it + 1) * 64, p.K);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s16x8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = Operand<TA>::frag(at, 64 * wm + 32 * i, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = Operand<TB>::frag(bt, 64 * wn + 32 * j, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                                       __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+        }
+        if (it + 1 < nk) {
+            sa.store(a_lds + ((it + 1) & 1) * TILE);
+            sb.store(b_lds + ((it + 1) & 1) * TILE);
+        }
+        __syncthreads();
+    }
+    // epilogue: accumulator column (lane & 31) = n, rows = m
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + 64 * wn + 32 * j + (lane & 31);
+        if (n >= p.N) continue;
+        const float bv = p.bias ? bf16_to_f32(p.bias[n]) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                const int64_t idx = (int64_t)m * p.ldc + n;
+                if (p.pre) {
+                    if (p.out_f32) ((float*)p.pre)[idx] = v; else ((bf16_t*)p.pre)[idx] = f32_to_bf16(v);
+                }
+                if (p.epilogue == 1) v = gelu_erf(p.out_f32 ? v : bf16_round(v));
+                if (p.out_f32) {
+                    float* c = (float*)p.C + idx;
+                    *c = p.accumulate ? *c + v : v;
+                } else {
+                    bf16_t* c = (bf16_t*)p.C + idx;
+                    *c = f32_to_bf16(p.accumulate ? bf16_to_f32(*c) + v : v);
+                }
+            }
+        }
+    }
+}
+
+// images [n, 3, hw, hw] bf16 -> col [n * (hw/p)^2, Kp] bf16, k = (c, ky, kx), zero padded to Kp
+__global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ img, bf16_t* __restrict__ col, int n, int hw,
+                                                     int p, int Kp, int64_t total) {
+    const int np1 = hw / p, K = 3 * p * p;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i % Kp);
+        const int64_t row = i / Kp;
+        bf16_t v = 0;
+        if (k < K) {
+            const int px = (int)(row % np1), py = (int)((row / np1) % np1);
+            const int64_t b = row / ((int64_t)np1 * np1);
+            const int c = k / (p * p), ky = (k / p) % p, kx = k % p;
+            v = img[((b * 3 + c) * hw + (py * p + ky)) * hw + px * p + kx];
+        }
+        col[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ hpre,
+                                                       bf16_t* __restrict__ dh, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const float x = bf16_to_f32(hpre[i]);
+        const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+        const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+        dh[i] = f32_to_bf16(bf16_to_f32(dy[i]) * (cdf + x * pdf));
+    }
+}
+
+// out[n] += sum_m x[m][n]; grid (ceil(N/256), splits); each block sums a slab of rows, one atomic per column
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int64_t M, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int64_t per = (M + gridDim.y - 1) / gridDim.y;
+    const int64_t lo = blockIdx.y * per, hi = lo + per < M ? lo + per : M;
+    float s = 0.f;
+    for (int64_t m = lo; m < hi; ++m) s += bf16_to_f32(x[m * N + n]);
+    atomicAdd(out + n, s);
+}
+
+template <bool TA, bool TB>
+int launch_gemm(const GemmParams& p, hipStream_t st) {
+    const dim3 grid((p.N + 127) / 128, (p.M + 127) / 128), block(256);
+    const size_t lds = 4 * 128 * 64 * 2;
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gemm_kernel<TA, TB>), grid, block, lds, st, p);
+    HALVA_CHECK_LAUNCH("gemm_bf16");
+    return HALVA_OK;
+}
+
+}  // namespace
+
+extern "C" int halva_gemm_bf16(const void* A, const void* B, const void* bias, void* C, void* pre_act, int M, int N, int K,
+                               int trans_a, int trans_b, int epilogue, halva_dtype out_dtype, int accumulate, void* stream) {
+    HALVA_CHECK_ARG(A && B && C, "gemm_bf16: null pointer");
+    HALVA_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_bf16: bad sizes %d %d %d", M, N, K);
+    HALVA_CHECK_ARG(epilogue == 0 || epilogue == 1, "gemm_bf16: unknown epilogue %d", epilogue);
+    // 16-byte row chunks: the contiguous dimension of every operand must be a multiple of 8 elements
+    HALVA_CHECK_ARG((trans_a ? M : K) % 8 == 0, "gemm_bf16: contiguous dim of A must be a multiple of 8");
+    HALVA_CHECK_ARG((trans_b ? N : K) % 8 == 0, "gemm_bf16: contiguous dim of B must be a multiple of 8");
+    HALVA_CHECK_ARG(!(trans_a && !trans_b), "gemm_bf16: (trans_a, !trans_b) is not used on this path");
+    GemmParams p{};
+    p.A = (const bf16_t*)A;
+    p.B = (const bf16_t*)B;
+    p.bias = (const bf16_t*)bias;
+    p.C = C;
+    p.pre = pre_act;
+    p.lda = trans_a ? M : K;
+    p.ldb = trans_b ? N : K;
+    p.ldc = N;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    p.epilogue = epilogue;
+    p.out_f32 = out_dtype == HALVA_F32;
+    p.accumulate = accumulate;
+    if (!trans_a && !trans_b) return launch_gemm<false, false>(p, (hipStream_t)stream);
+    if (!trans_a && trans_b) return launch_gemm<false, true>(p, (hipStream_t)stream);
+    return launch_gemm<true, true>(p, (hipStream_t)stream);
+}
+
+extern "C" int halva_clip_patch_embed(const void* images, const void* weight_kp, void* col_ws, void* out, int n, int hw, int p,
+                                      int d, int Kp, void* stream) {
+    HALVA_CHECK_ARG(images && weight_kp && col_ws && out, "clip_patch_embed: null pointer");
+    HALVA_CHECK_ARG(n > 0 && p > 0 && hw % p == 0, "clip_patch_embed: bad image/patch size");
+    HALVA_CHECK_ARG(Kp % 8 == 0 && Kp >= 3 * p * p, "clip_patch_embed: Kp=%d must be a multiple of 8 and >= 3*p*p", Kp);
+    const int np = (hw / p) * (hw / p);
+    const int64_t total = (int64_t)n * np * Kp;
+    int64_t grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)images,
+                       (bf16_t*)col_ws, n, hw, p, Kp, total);
+    HALVA_CHECK_LAUNCH("im2col");
+    return halva_gemm_bf16(col_ws, weight_kp, nullptr, out, nullptr, n * np, d, Kp, 0, 0, 0, HALVA_BF16, 0, stream);
+}
+
+extern "C" int halva_gelu_bwd(const void* dy, const void* h, void* dh, int64_t M, int N, void* stream) {
+    HALVA_CHECK_ARG(dy && h && dh, "gelu_bwd: null pointer");
+    const int64_t total = M * N;
+    if (total <= 0) return HALVA_OK;
+    int64_t grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                       (const bf16_t*)h, (bf16_t*)dh, total);
+    HALVA_CHECK_LAUNCH("gelu_bwd");
+    return HALVA_OK;
+}
+
+extern "C" int halva_colsum(const void* x, float* out, int64_t M, int N, void* stream) {
+    HALVA_CHECK_ARG(x && out, "colsum: null pointer");
+    if (M <= 0 || N <= 0) return HALVA_OK;
+    int splits = (int)((M + 127) / 128);
+    if (splits > 64) splits = 64;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, splits), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, M,
+                       N);
+    HALVA_CHECK_LAUNCH("colsum");
+    return HALVA_OK;
+}

@@ -1,0 +1,276 @@
+// HBM-bound row kernels of the Llama decoder on gfx950: RMSNorm fwd/bwd, RoPE (in place on packed qkv),
+// SwiGLU fwd/bwd and the splice row gather.  All bf16 I/O with 16-byte (8 x bf16) accesses per lane,
+// one 64-lane wave per row for the reductions (shuffle only, no LDS, no barrier).
+#include "common.h"
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kMaxChunks = 16;   // 16 chunks x 64 lanes x 8 elements = rows up to d = 8192 stay in registers
+
+__device__ __forceinline__ void unpack8(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = bf16_lo(v[i]);
+        f[2 * i + 1] = bf16_hi(v[i]);
+    }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RMSNorm (modelling_llama.py:65-70): t = bf16(x * rsqrt(mean(x^2) + eps)); y = bf16(w * t)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ w,
+                                                          u32x4* __restrict__ y, float* __restrict__ rstd, int64_t rows,
+                                                          int nchunk, float eps, float inv_d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const u32x4* xr = x + row * nchunk;
+    u32x4 buf[kMaxChunks];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxChunks; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            buf[i] = xr[c];
+            float f[8];
+            unpack8(buf[i], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+        }
+    }
+    ss = wave_sum(ss);
+    const float r = rsqrtf(ss * inv_d + eps);
+    if (lane == 0) rstd[row] = r;
+    u32x4* yr = y + row * nchunk;
+#pragma unroll
+    for (int i = 0; i < kMaxChunks; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            float f[8], g[8];
+            unpack8(buf[i], f);
+            unpack8(w[c], g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = g[j] * bf16_round(f[j] * r);
+            yr[c] = pack8(f);
+        }
+    }
+}
+
+// dx = r * (g - n * mean(g * n)),  g = dy * w,  n = x * r
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ x,
+                                                          const u32x4* __restrict__ w, const float* __restrict__ rstd,
+                                                          u32x4* __restrict__ dx, int64_t rows, int nchunk, float inv_d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const u32x4* xr = x + row * nchunk;
+    const u32x4* dyr = dy + row * nchunk;
+    const float r = rstd[row];
+    u32x4 bx[kMaxChunks], bg[kMaxChunks];   // bg holds g = dy * w packed back as two-halves? keep dy, recompute g
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxChunks; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            bx[i] = xr[c];
+            bg[i] = dyr[c];
+            float fx[8], fd[8], fw[8];
+            unpack8(bx[i], fx);
+            unpack8(bg[i], fd);
+            unpack8(w[c], fw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dot += fd[j] * fw[j] * fx[j] * r;
+        }
+    }
+    dot = wave_sum(dot) * inv_d;
+    u32x4* dxr = dx + row * nchunk;
+#pragma unroll
+    for (int i = 0; i < kMaxChunks; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            float fx[8], fd[8], fw[8];
+            unpack8(bx[i], fx);
+            unpack8(bg[i], fd);
+            unpack8(w[c], fw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fx[j] = r * (fd[j] * fw[j] - fx[j] * r * dot);
+            dxr[c] = pack8(fx);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RoPE in place on q and k of packed qkv [rows, 3, H, D]
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_qk_kernel(u32x4* __restrict__ qkv, const u32x4* __restrict__ cosb,
+                                                      const u32x4* __restrict__ sinb, const int32_t* __restrict__ pos,
+                                                      int64_t rows, int T, int H, int chunks_half, float sgn, int64_t total) {
+    // one thread = 8 elements of the first half of one head + the matching 8 of the second half
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks_half);
+        int64_t t = i / chunks_half;
+        const int h = (int)(t % H);
+        t /= H;
+        const int part = (int)(t & 1);   // 0 = q, 1 = k
+        const int64_t row = t >> 1;
+        const int p = pos ? pos[row] : (int)(row % T);
+        const int64_t base = ((row * 3 + part) * H + h) * (2 * chunks_half) + c;
+        float x1[8], x2[8], cs[8], sn[8];
+        unpack8(qkv[base], x1);
+        unpack8(qkv[base + chunks_half], x2);
+        unpack8(cosb[(int64_t)p * chunks_half + c], cs);
+        unpack8(sinb[(int64_t)p * chunks_half + c], sn);
+        float y1[8], y2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float s = sn[j] * sgn;
+            y1[j] = x1[j] * cs[j] - x2[j] * s;
+            y2[j] = x2[j] * cs[j] + x1[j] * s;
+        }
+        qkv[base] = pack8(y1);
+        qkv[base + chunks_half] = pack8(y2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SwiGLU on packed gate|up rows
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const u32x4* __restrict__ gu, u32x4* __restrict__ out,
+                                                         int chunksF, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / chunksF;
+        const int c = (int)(i - row * chunksF);
+        float g[8], u[8];
+        unpack8(gu[row * 2 * chunksF + c], g);
+        unpack8(gu[row * 2 * chunksF + chunksF + c], u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = bf16_round(g[j] / (1.f + __expf(-g[j]))) * u[j];
+        out[i] = pack8(g);
+    }
+}
+
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const u32x4* __restrict__ dout, const u32x4* __restrict__ gu,
+                                                         u32x4* __restrict__ dgu, int chunksF, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / chunksF;
+        const int c = (int)(i - row * chunksF);
+        float g[8], u[8], d[8], dg[8], du[8];
+        unpack8(gu[row * 2 * chunksF + c], g);
+        unpack8(gu[row * 2 * chunksF + chunksF + c], u);
+        unpack8(dout[i], d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float sg = 1.f / (1.f + __expf(-g[j]));
+            du[j] = d[j] * g[j] * sg;
+            dg[j] = d[j] * u[j] * sg * (1.f + g[j] * (1.f - sg));
+        }
+        dgu[row * 2 * chunksF + c] = pack8(dg);
+        dgu[row * 2 * chunksF + chunksF + c] = pack8(du);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// splice: one wave per output row; src >= 0 token embedding, src <= -2 image feature row, src == -1 zero pad
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void splice_rows_kernel(const u32x4* __restrict__ embed, const u32x4* __restrict__ feats,
+                                                          const int32_t* __restrict__ src, u32x4* __restrict__ out,
+                                                          int64_t rows, int nchunk) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int s = src[row];
+    const u32x4* from = s >= 0 ? embed + (int64_t)s * nchunk : (s <= -2 ? feats + (int64_t)(-s - 2) * nchunk : nullptr);
+    u32x4* to = out + row * nchunk;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    for (int c = lane; c < nchunk; c += 64) to[c] = from ? from[c] : zero;
+}
+
+inline int grid_for(int64_t total, int block) {
+    int64_t g = (total + block - 1) / block;
+    const int64_t cap = 256 * 8 * 4;   // grid-stride beyond ~32 blocks per CU
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int halva_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int d, float eps,
+                                 void* stream) {
+    HALVA_CHECK_ARG(x && w && y && rstd, "rmsnorm_fwd: null pointer");
+    HALVA_CHECK_ARG(d > 0 && d % 8 == 0 && d <= 8 * 64 * kMaxChunks, "rmsnorm_fwd: d=%d must be a multiple of 8 and <= %d", d,
+                    8 * 64 * kMaxChunks);
+    if (rows <= 0) return HALVA_OK;
+    const int blocks = (int)((rows + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, (const u32x4*)w,
+                       (u32x4*)y, rstd, rows, d / 8, eps, 1.f / d);
+    HALVA_CHECK_LAUNCH("rmsnorm_fwd");
+    return HALVA_OK;
+}
+
+extern "C" int halva_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, int64_t rows,
+                                 int d, void* stream) {
+    HALVA_CHECK_ARG(dy && x && w && rstd && dx, "rmsnorm_bwd: null pointer");
+    HALVA_CHECK_ARG(d > 0 && d % 8 == 0 && d <= 8 * 64 * kMaxChunks, "rmsnorm_bwd: d=%d must be a multiple of 8 and <= %d", d,
+                    8 * 64 * kMaxChunks);
+    if (rows <= 0) return HALVA_OK;
+    const int blocks = (int)((rows + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)dy, (const u32x4*)x,
+                       (const u32x4*)w, rstd, (u32x4*)dx, rows, d / 8, 1.f / d);
+    HALVA_CHECK_LAUNCH("rmsnorm_bwd");
+    return HALVA_OK;
+}
+
+extern "C" int halva_rope_qk(void* qkv, const void* cos, const void* sin, const int32_t* pos, int64_t rows, int T, int H,
+                             int D, int max_pos, int inverse, void* stream) {
+    HALVA_CHECK_ARG(qkv && cos && sin, "rope_qk: null pointer");
+    HALVA_CHECK_ARG(D > 0 && D % 16 == 0, "rope_qk: head_dim=%d must be a multiple of 16", D);
+    HALVA_CHECK_ARG(T > 0 && H > 0, "rope_qk: bad T/H");
+    HALVA_CHECK_ARG(pos || T <= max_pos, "rope_qk: T=%d exceeds the cos/sin table (%d rows)", T, max_pos);
+    if (rows <= 0) return HALVA_OK;
+    const int ch = D / 16;
+    const int64_t total = rows * 2 * H * ch;
+    hipLaunchKernelGGL(rope_qk_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (u32x4*)qkv,
+                       (const u32x4*)cos, (const u32x4*)sin, pos, rows, T, H, ch, inverse ? -1.f : 1.f, total);
+    HALVA_CHECK_LAUNCH("rope_qk");
+    return HALVA_OK;
+}
+
+extern "C" int halva_swiglu_fwd(const void* gu, void* out, int64_t rows, int F, void* stream) {
+    HALVA_CHECK_ARG(gu && out, "swiglu_fwd: null pointer");
+    HALVA_CHECK_ARG(F > 0 && F % 8 == 0, "swiglu_fwd: F=%d must be a multiple of 8", F);
+    if (rows <= 0) return HALVA_OK;
+    const int64_t total = rows * (F / 8);
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)gu,
+                       (u32x4*)out, F / 8, total);
+    HALVA_CHECK_LAUNCH("swiglu_fwd");
+    return HALVA_OK;
+}
+
+extern "C" int halva_swiglu_bwd(const void* dout, const void* gu, void* dgu, int64_t rows, int F, void* stream) {
+    HALVA_CHECK_ARG(dout && gu && dgu, "swiglu_bwd: null pointer");
+    HALVA_CHECK_ARG(F > 0 && F % 8 == 0, "swiglu_bwd: F=%d must be a multiple of 8", F);
+    if (rows <= 0) return HALVA_OK;
+    const int64_t total = rows * (F / 8);
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)dout,
+                       (const u32x4*)gu, (u32x4*)dgu, F / 8, total);
+    HALVA_CHECK_LAUNCH("swiglu_bwd");
+    return HALVA_OK;
+}
+
+extern "C" int halva_splice_rows(const void* embed, const void* feats, const int32_t* src, void* out, int64_t rows, int d,
+                                 void* stream) {
+    HALVA_CHECK_ARG(embed && src && out, "splice_rows: null pointer");
+    HALVA_CHECK_ARG(d > 0 && d % 8 == 0, "splice_rows: d=%d must be a multiple of 8", d);
+    if (rows <= 0) return HALVA_OK;
+    const int blocks = (int)((rows + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(splice_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)embed,
+                       (const u32x4*)feats, src, (u32x4*)out, rows, d / 8);
+    HALVA_CHECK_LAUNCH("splice_rows");
+    return HALVA_OK;
+}

@@ -1,0 +1,738 @@
+// Fused self-attention for gfx950 (CDNA4): forward, dQ and dK/dV kernels on v_mfma_f32_32x32x16_bf16.
+//
+// Replaces flash_attn_varlen_qkvpacked_func + unpad_input/pad_input of the reference
+// (llava/train/llama_flash_attn_monkey_patch.py:71-91) for Llama (causal, head_dim 128) and HF CLIPAttention's
+// softmax(QK^T)V for the frozen vision tower (non-causal, head_dim 64, forward only).
+//
+// Structure (all three kernels): a workgroup is 4 waves (256 threads); each wave owns a 32-row strip of the
+// "stationary" operand in registers (Q rows in fwd/dQ, K/V rows in dK/dV) and the workgroup streams 64-row
+// (fwd, dQ) or 32-row (dK/dV) tiles of the other operand through LDS, double buffered, register staged
+// (global loads for tile i+1 are issued before the MFMAs of tile i and written to LDS after them).
+//
+//   fwd    S^T = K Q^T (key on the accumulator rows, query on the lane) so the softmax row statistics are
+//          lane-local: 32 in-register max/add + one cross-half shuffle; P^T is cast to bf16 in registers and is
+//          already the B operand of O^T += V^T P^T; V^T comes from the row-major LDS tile via ds_read_b64_tr_b16.
+//   dQ     same skeleton: S^T, dP^T = V dO^T, dZ^T = P^T (dP^T - delta), dQ^T += K^T dZ^T (K^T by tr reads).
+//   dK/dV  S = Q K^T and dP = dO V^T with the KEY on the lane (K/V fragments stay in registers); P and dZ
+//          accumulators are directly the B operands of dV^T += dO^T P and dK^T += Q^T dZ (Q^T/dO^T by tr reads).
+// LDS tiles use one XOR swizzle that is conflict-free for both ds_read_b128 row reads and transposed reads.
+// No atomics: dQ has its own kernel, so results are bitwise reproducible.
+#include "common.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+struct SdpaParams {
+    const bf16_t* q;      // [S, T, ...] row stride ld_qkv, head offset hd * D
+    const bf16_t* k;
+    const bf16_t* v;
+    bf16_t* o;            // fwd: out; bwd: unused
+    const bf16_t* o_in;   // bwd: forward output
+    const bf16_t* d_o;    // bwd: grad of out, row stride ld_o
+    bf16_t* dq;           // bwd outputs, row stride ld_qkv (packed like q/k/v)
+    bf16_t* dk;
+    bf16_t* dv;
+    float* lse;           // [S, H, T]
+    float* delta;         // [S, H, T]
+    const int32_t* seq_start;
+    const int32_t* seq_len;
+    int64_t ld_qkv;       // elements between consecutive tokens in q/k/v
+    int64_t ld_o;         // elements between consecutive tokens in out / dout
+    int T, H;
+    float scale;          // softmax scale
+};
+
+// byte offset of 16-byte chunk `ch` of row `row` in a [rows][D] bf16 LDS tile
+template <int D>
+__device__ __forceinline__ int tile_off(int row, int ch) {
+    if (D == 128)
+        return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+    else
+        return row * 128 + ((ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))) << 4);
+}
+
+__device__ __forceinline__ f32x16 mfma32(const s16x8& a, const s16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// A/B fragment of a row-major tile: lane (r = lane & 31, h = lane >> 5) gets row (row0 + r), elements 16*ks + 8*h .. +7
+template <int D>
+__device__ __forceinline__ s16x8 frag_rows(const char* tile, int row0, int ks, int lane) {
+    const int r = row0 + (lane & 31);
+    return *reinterpret_cast<const s16x8*>(tile + tile_off<D>(r, 2 * ks + (lane >> 5)));
+}
+
+// Transposed fragment for a product that sums over the tile's ROW index with an accumulator tile as the other
+// operand.  Lane (c = lane & 31, h = lane >> 5) gets column (col0 + c) of rows
+//   row0 + 8*jj + 4*h + e,  jj = 0,1, e = 0..3   (element j = 4*jj + e)
+// which is exactly the row order of registers 8*s'..8*s'+7 of a 32x32 accumulator (row0 = 16*s' + tile base).
+template <int D, bool SLOW>
+__device__ __forceinline__ s16x8 frag_cols(const char* tile, int row0, int col0, int lane) {
+    s16x8 out;
+    if (SLOW) {
+        const int c = col0 + (lane & 31), h = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = row0 + 8 * (j >> 2) + 4 * h + (j & 3);
+            out[j] = *reinterpret_cast<const short*>(tile + tile_off<D>(r, c >> 3) + (c & 7) * 2);
+        }
+    } else {
+        // ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block; lane 4q+p supplies the address of
+        // row q, columns 4p..4p+3 and receives column (lane & 15), rows 0..3.
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, h = g >> 1;
+        const int c = col0 + 16 * (g & 1) + 4 * pp;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int r = row0 + 8 * jj + 4 * h + q;
+            const int off = tile_off<D>(r, c >> 3) + (c & 7) * 2;
+            const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + off));
+            out[4 * jj + 0] = t[0];
+            out[4 * jj + 1] = t[1];
+            out[4 * jj + 2] = t[2];
+            out[4 * jj + 3] = t[3];
+        }
+    }
+    return out;
+}
+
+// registers 8*s..8*s+7 of a 32x32 f32 accumulator -> bf16 fragment usable as the B (or A) operand
+__device__ __forceinline__ s16x8 acc_to_frag(const f32x16& x, int s) {
+    s16x8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = (short)f32_to_bf16(x[8 * s + j]);
+    return out;
+}
+
+// row index (0..31) inside a 32x32 accumulator tile of register `reg` on a lane of half h
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// ---------------------------------------------------------------------------------------------------
+// cooperative tile staging: ROWS x D bf16, 256 threads, register staged
+// ---------------------------------------------------------------------------------------------------
+template <int D, int ROWS>
+struct Stage {
+    static constexpr int NCH = D / 8;
+    static constexpr int PER_THREAD = ROWS * NCH / 256;
+    static_assert(ROWS * NCH % 256 == 0, "tile must split evenly over 256 threads");
+    u32x4 r[PER_THREAD];
+
+    // rows [row_local0, row_local0 + ROWS) of a sequence; rows with local index outside [0, limit) read as zeros
+    __device__ __forceinline__ void load(const bf16_t* base, int64_t ld, int64_t grow0, int local0, int limit) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int cid = threadIdx.x + 256 * i;
+            const int row = cid / NCH, ch = cid % NCH;
+            const int loc = local0 + row;
+            if (loc >= 0 && loc < limit)
+                r[i] = *reinterpret_cast<const u32x4*>(base + (grow0 + row) * ld + ch * 8);
+            else
+                r[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    __device__ __forceinline__ void store(char* tile) const {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int cid = threadIdx.x + 256 * i;
+            const int row = cid / NCH, ch = cid % NCH;
+            *reinterpret_cast<u32x4*>(tile + tile_off<D>(row, ch)) = r[i];
+        }
+    }
+};
+
+// Write a [D x 32] transposed accumulator (lane = row of the output, registers = columns d) as bf16 rows:
+// out_row[d] for d = 32*dt + 8*g + 4*h + (0..3) -> 8-byte stores.
+template <int D>
+__device__ __forceinline__ void store_rows_T(bf16_t* row_ptr, const f32x16 (&acc)[D / 32], float mul, bool valid, int lane) {
+    if (!valid) return;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x2 w;
+            w[0] = pack_bf16x2(acc[dt][4 * g + 0] * mul, acc[dt][4 * g + 1] * mul);
+            w[1] = pack_bf16x2(acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
+            *reinterpret_cast<u32x2*>(row_ptr + 32 * dt + 8 * g + 4 * h) = w;
+        }
+    }
+}
+template <int D>
+__device__ __forceinline__ void store_rows_zero(bf16_t* row_ptr, int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<u32x2*>(row_ptr + 32 * dt + 8 * g + 4 * h) = u32x2{0u, 0u};
+}
+
+// ===================================================================================================
+// forward
+// ===================================================================================================
+template <int D, bool CAUSAL, bool SLOW_TR>
+__global__ __launch_bounds__(256, 2) void sdpa_fwd_kernel(const SdpaParams p) {
+    constexpr int BN = 64, KS = D / 16, DT = D / 32;
+    constexpr int TILE_BYTES = BN * D * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* k_lds = smem;                    // [2][BN][D]
+    char* v_lds = smem + 2 * TILE_BYTES;   // [2][BN][D]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const int s = blockIdx.z, hd = blockIdx.y;
+    const int qb = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;   // heavy (late) blocks first
+    const int start = p.seq_start ? p.seq_start[s] : 0;
+    const int len = p.seq_len ? p.seq_len[s] : p.T;
+    const int g0 = qb * 128;                         // first padded-row index of this block
+    const int64_t seq_row0 = (int64_t)s * p.T;
+    const int gq = g0 + 32 * wave + (lane & 31);     // this lane's query row (padded index)
+    const int ql = gq - start;                       // local (un-padded) query index
+    const bool q_in_T = gq < p.T;
+    const bool q_valid = q_in_T && ql >= 0 && ql < len;
+
+    // key range this block needs (local indices)
+    int kv_end = len;
+    if (CAUSAL) kv_end = min(len, g0 + 128 - start);
+    const int ntiles = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
+
+    const bf16_t* qp = p.q + hd * D;
+    const bf16_t* kp = p.k + hd * D;
+    const bf16_t* vp = p.v + hd * D;
+    bf16_t* orow = p.o + (seq_row0 + gq) * p.ld_o + hd * D;
+
+    if (ntiles == 0) {   // every row of the block is padding
+        if (q_in_T) {
+            store_rows_zero<D>(orow, lane);
+            if (h == 0 && p.lse) p.lse[((int64_t)s * p.H + hd) * p.T + gq] = 0.f;
+        }
+        return;
+    }
+
+    // Q fragments (B operand of S^T = K Q^T): lane (q, h) holds Q[q][16*ks + 8*h .. +7]
+    s16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (q_valid)
+            qf[ks] = *reinterpret_cast<const s16x8*>(qp + (seq_row0 + gq) * p.ld_qkv + 16 * ks + 8 * h);
+        else
+            qf[ks] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = p.scale * kLog2e;
+
+    // wave-level causal bounds (local indices)
+    const int wq_min = g0 + 32 * wave - start, wq_max = wq_min + 31;
+
+    Stage<D, BN> kst, vst;
+    const int64_t krow0 = seq_row0 + start;
+    kst.load(kp, p.ld_qkv, krow0, 0, len);
+    vst.load(vp, p.ld_qkv, krow0, 0, len);
+    kst.store(k_lds);
+    vst.store(v_lds);
+    __syncthreads();
+
+    for (int it = 0; it < ntiles; ++it) {
+        const int kv0 = it * BN;
+        const char* kt = k_lds + (it & 1) * TILE_BYTES;
+        const char* vt = v_lds + (it & 1) * TILE_BYTES;
+        if (it + 1 < ntiles) {
+            kst.load(kp, p.ld_qkv, krow0 + kv0 + BN, kv0 + BN, len);
+            vst.load(vp, p.ld_qkv, krow0 + kv0 + BN, kv0 + BN, len);
+        }
+        const bool active = !CAUSAL || kv0 <= wq_max;
+        if (active) {
+            // ---- S^T[key][q] for the 64 keys of the tile
+            f32x16 st[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) st[t] = mfma32(frag_rows<D>(kt, 32 * t, ks, lane), qf[ks], st[t]);
+            }
+            // ---- online softmax over the key axis (registers), log2 domain
+            const bool need_mask = (kv0 + BN > len) || (CAUSAL && kv0 + BN - 1 > wq_min);
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float x = st[t][r] * sc;
+                    if (need_mask) {
+                        const int kl = kv0 + 32 * t + acc_row(r, h);
+                        if (kl >= len || (CAUSAL && kl > ql)) x = -INFINITY;
+                    }
+                    st[t][r] = x;
+                    tmax = fmaxf(tmax, x);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax);
+            const float m_sub = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_sub);
+            float psum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(st[t][r] - m_sub);
+                    st[t][r] = e;
+                    psum += e;
+                }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            // ---- O^T[d][q] += V^T[d][key] P^T[key][q]
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const s16x8 pb = acc_to_frag(st[ks >> 1], ks & 1);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    oacc[dt] = mfma32(frag_cols<D, SLOW_TR>(vt, 16 * ks, 32 * dt, lane), pb, oacc[dt]);
+            }
+        }
+        if (it + 1 < ntiles) {
+            kst.store(k_lds + ((it + 1) & 1) * TILE_BYTES);
+            vst.store(v_lds + ((it + 1) & 1) * TILE_BYTES);
+        }
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = (q_valid && l_tot > 0.f) ? 1.f / l_tot : 0.f;
+    if (q_in_T) {
+        store_rows_T<D>(orow, oacc, inv, true, lane);
+        if (h == 0 && p.lse)
+            p.lse[((int64_t)s * p.H + hd) * p.T + gq] = q_valid ? (m_run + log2f(l_tot)) * kLn2 : 0.f;
+    }
+}
+
+// ===================================================================================================
+// backward, part 0: delta[s, h, t] = sum_d dO * O
+// ===================================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void sdpa_delta_kernel(const SdpaParams p, int64_t total) {
+    // one 16-lane group per (token, head): D/8 chunks of 8 elements
+    constexpr int LPR = D / 8;   // lanes per row (16 for D=128, 8 for D=64)
+    const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+    const int c = threadIdx.x % LPR;
+    float acc = 0.f;
+    int64_t tok = 0;
+    int hd = 0;
+    if (gid < total) {
+        tok = gid / p.H;
+        hd = (int)(gid % p.H);
+        const u32x4 a = *reinterpret_cast<const u32x4*>(p.o_in + tok * p.ld_o + hd * D + c * 8);
+        const u32x4 b = *reinterpret_cast<const u32x4*>(p.d_o + tok * p.ld_o + hd * D + c * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc += bf16_lo(a[i]) * bf16_lo(b[i]) + bf16_hi(a[i]) * bf16_hi(b[i]);
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (gid < total && c == 0) {
+        const int64_t s = tok / p.T, t = tok % p.T;
+        p.delta[(s * p.H + hd) * p.T + t] = acc;
+    }
+}
+
+// ===================================================================================================
+// backward, part 1: dQ  (same skeleton as the forward)
+// ===================================================================================================
+template <int D, bool CAUSAL, bool SLOW_TR>
+__global__ __launch_bounds__(256, 1) void sdpa_bwd_dq_kernel(const SdpaParams p) {
+    constexpr int BN = 64, KS = D / 16, DT = D / 32;
+    constexpr int TILE_BYTES = BN * D * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* k_lds = smem;
+    char* v_lds = smem + 2 * TILE_BYTES;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const int s = blockIdx.z, hd = blockIdx.y;
+    const int qb = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    const int start = p.seq_start ? p.seq_start[s] : 0;
+    const int len = p.seq_len ? p.seq_len[s] : p.T;
+    const int g0 = qb * 128;
+    const int64_t seq_row0 = (int64_t)s * p.T;
+    const int gq = g0 + 32 * wave + (lane & 31);
+    const int ql = gq - start;
+    const bool q_in_T = gq < p.T;
+    const bool q_valid = q_in_T && ql >= 0 && ql < len;
+
+    int kv_end = len;
+    if (CAUSAL) kv_end = min(len, g0 + 128 - start);
+    const int ntiles = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
+
+    const bf16_t* qp = p.q + hd * D;
+    const bf16_t* kp = p.k + hd * D;
+    const bf16_t* vp = p.v + hd * D;
+    bf16_t* dqrow = p.dq + (seq_row0 + gq) * p.ld_qkv + hd * D;
+    if (ntiles == 0) {
+        if (q_in_T) store_rows_zero<D>(dqrow, lane);
+        return;
+    }
+
+    s16x8 qf[KS], dof[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (q_valid) {
+            qf[ks] = *reinterpret_cast<const s16x8*>(qp + (seq_row0 + gq) * p.ld_qkv + 16 * ks + 8 * h);
+            dof[ks] = *reinterpret_cast<const s16x8*>(p.d_o + (seq_row0 + gq) * p.ld_o + hd * D + 16 * ks + 8 * h);
+        } else {
+            qf[ks] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            dof[ks] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    const int64_t stat = ((int64_t)s * p.H + hd) * p.T + gq;
+    const float lse2 = q_valid ? p.lse[stat] * kLog2e : 0.f;
+    const float dlt = q_valid ? p.delta[stat] : 0.f;
+    const float sc = p.scale * kLog2e;
+
+    f32x16 dqacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.f;
+
+    const int wq_min = g0 + 32 * wave - start, wq_max = wq_min + 31;
+    Stage<D, BN> kst, vst;
+    const int64_t krow0 = seq_row0 + start;
+    kst.load(kp, p.ld_qkv, krow0, 0, len);
+    vst.load(vp, p.ld_qkv, krow0, 0, len);
+    kst.store(k_lds);
+    vst.store(v_lds);
+    __syncthreads();
+
+    for (int it = 0; it < ntiles; ++it) {
+        const int kv0 = it * BN;
+        const char* kt = k_lds + (it & 1) * TILE_BYTES;
+        const char* vt = v_lds + (it & 1) * TILE_BYTES;
+        if (it + 1 < ntiles) {
+            kst.load(kp, p.ld_qkv, krow0 + kv0 + BN, kv0 + BN, len);
+            vst.load(vp, p.ld_qkv, krow0 + kv0 + BN, kv0 + BN, len);
+        }
+        const bool active = !CAUSAL || kv0 <= wq_max;
+        if (active) {
+            f32x16 st[2], dp[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    st[t][r] = 0.f;
+                    dp[t][r] = 0.f;
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    st[t] = mfma32(frag_rows<D>(kt, 32 * t, ks, lane), qf[ks], st[t]);
+                    dp[t] = mfma32(frag_rows<D>(vt, 32 * t, ks, lane), dof[ks], dp[t]);
+                }
+            }
+            const bool need_mask = (kv0 + BN > len) || (CAUSAL && kv0 + BN - 1 > wq_min);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float pr = __builtin_amdgcn_exp2f(st[t][r] * sc - lse2);
+                    if (need_mask) {
+                        const int kl = kv0 + 32 * t + acc_row(r, h);
+                        if (kl >= len || (CAUSAL && kl > ql)) pr = 0.f;
+                    }
+                    if (!q_valid) pr = 0.f;
+                    st[t][r] = pr * (dp[t][r] - dlt);   // dZ^T
+                }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const s16x8 zb = acc_to_frag(st[ks >> 1], ks & 1);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    dqacc[dt] = mfma32(frag_cols<D, SLOW_TR>(kt, 16 * ks, 32 * dt, lane), zb, dqacc[dt]);
+            }
+        }
+        if (it + 1 < ntiles) {
+            kst.store(k_lds + ((it + 1) & 1) * TILE_BYTES);
+            vst.store(v_lds + ((it + 1) & 1) * TILE_BYTES);
+        }
+        __syncthreads();
+    }
+    if (q_in_T) store_rows_T<D>(dqrow, dqacc, q_valid ? p.scale : 0.f, true, lane);
+}
+
+// ===================================================================================================
+// backward, part 2: dK, dV.  A workgroup owns 128 keys (32 per wave, K/V fragments in registers) and streams
+// 32-row tiles of Q and dO (one dual-use LDS image each) from the diagonal to the end of the sequence.
+// ===================================================================================================
+template <int D, bool CAUSAL, bool SLOW_TR>
+__global__ __launch_bounds__(256, 1) void sdpa_bwd_dkv_kernel(const SdpaParams p) {
+    constexpr int BQ = 32, KS = D / 16, DT = D / 32;
+    constexpr int TILE_BYTES = BQ * D * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* q_lds = smem;                       // [2][BQ][D]
+    char* do_lds = smem + 2 * TILE_BYTES;     // [2][BQ][D]
+    float* lse_lds = reinterpret_cast<float*>(smem + 4 * TILE_BYTES);   // [2][BQ]
+    float* dlt_lds = lse_lds + 2 * BQ;                                  // [2][BQ]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const int s = blockIdx.z, hd = blockIdx.y;
+    const int kb = blockIdx.x;
+    const int start = p.seq_start ? p.seq_start[s] : 0;
+    const int len = p.seq_len ? p.seq_len[s] : p.T;
+    const int64_t seq_row0 = (int64_t)s * p.T;
+    const int gk = kb * 128 + 32 * wave + (lane & 31);   // this lane's key row (padded index)
+    const int kl = gk - start;
+    const bool k_in_T = gk < p.T;
+    const bool k_valid = k_in_T && kl >= 0 && kl < len;
+    bf16_t* dkrow = p.dk + (seq_row0 + gk) * p.ld_qkv + hd * D;
+    bf16_t* dvrow = p.dv + (seq_row0 + gk) * p.ld_qkv + hd * D;
+
+    // query range (local indices) this key block needs
+    const int kblk_min = kb * 128 - start;                 // local index of the block's first key row
+    int q_begin = 0;
+    if (CAUSAL) q_begin = max(0, kblk_min) / BQ * BQ;
+    const bool block_has_keys = (kblk_min < len) && (kblk_min + 128 > 0);
+    const int ntiles = (block_has_keys && len > q_begin) ? (len - q_begin + BQ - 1) / BQ : 0;
+    if (ntiles == 0) {
+        if (k_in_T) {
+            store_rows_zero<D>(dkrow, lane);
+            store_rows_zero<D>(dvrow, lane);
+        }
+        return;
+    }
+
+    const bf16_t* qp = p.q + hd * D;
+    const bf16_t* dop = p.d_o + hd * D;
+    s16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (k_valid) {
+            kf[ks] = *reinterpret_cast<const s16x8*>(p.k + (seq_row0 + gk) * p.ld_qkv + hd * D + 16 * ks + 8 * h);
+            vf[ks] = *reinterpret_cast<const s16x8*>(p.v + (seq_row0 + gk) * p.ld_qkv + hd * D + 16 * ks + 8 * h);
+        } else {
+            kf[ks] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            vf[ks] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    f32x16 dkacc[DT], dvacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dkacc[dt][r] = 0.f;
+            dvacc[dt][r] = 0.f;
+        }
+    const float sc = p.scale * kLog2e;
+    const int wk_min = kblk_min + 32 * wave;   // smallest local key index of this wave
+
+    Stage<D, BQ> qst, dst;
+    const int64_t qrow0 = seq_row0 + start;
+    const float* lse_g = p.lse + ((int64_t)s * p.H + hd) * p.T + start;
+    const float* dlt_g = p.delta + ((int64_t)s * p.H + hd) * p.T + start;
+    float st_lse = 0.f, st_dlt = 0.f;
+    auto load_stats = [&](int q0) {
+        if (threadIdx.x < BQ) {
+            const int ql = q0 + threadIdx.x;
+            st_lse = ql < len ? lse_g[ql] * kLog2e : 0.f;
+            st_dlt = ql < len ? dlt_g[ql] : 0.f;
+        }
+    };
+    auto store_stats = [&](int buf) {
+        if (threadIdx.x < BQ) {
+            lse_lds[buf * BQ + threadIdx.x] = st_lse;
+            dlt_lds[buf * BQ + threadIdx.x] = st_dlt;
+        }
+    };
+    qst.load(qp, p.ld_qkv, qrow0 + q_begin, q_begin, len);
+    dst.load(dop, p.ld_o, qrow0 + q_begin, q_begin, len);
+    load_stats(q_begin);
+    qst.store(q_lds);
+    dst.store(do_lds);
+    store_stats(0);
+    __syncthreads();
+
+    for (int it = 0; it < ntiles; ++it) {
+        const int q0 = q_begin + it * BQ;
+        const char* qt = q_lds + (it & 1) * TILE_BYTES;
+        const char* dot = do_lds + (it & 1) * TILE_BYTES;
+        const float* lse_t = lse_lds + (it & 1) * BQ;
+        const float* dlt_t = dlt_lds + (it & 1) * BQ;
+        if (it + 1 < ntiles) {
+            qst.load(qp, p.ld_qkv, qrow0 + q0 + BQ, q0 + BQ, len);
+            dst.load(dop, p.ld_o, qrow0 + q0 + BQ, q0 + BQ, len);
+            load_stats(q0 + BQ);
+        }
+        const bool active = !CAUSAL || (q0 + BQ - 1 >= wk_min);
+        if (active) {
+            // S[q][key] and dP[q][key]: key on the lane, q on the accumulator rows
+            f32x16 sa, dpa;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sa[r] = 0.f;
+                dpa[r] = 0.f;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                sa = mfma32(frag_rows<D>(qt, 0, ks, lane), kf[ks], sa);
+                dpa = mfma32(frag_rows<D>(dot, 0, ks, lane), vf[ks], dpa);
+            }
+            const bool need_mask = (q0 + BQ > len) || (CAUSAL && q0 < wk_min + 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qr = acc_row(r, h);
+                float pr = __builtin_amdgcn_exp2f(sa[r] * sc - lse_t[qr]);
+                if (need_mask) {
+                    const int ql = q0 + qr;
+                    if (ql >= len || (CAUSAL && kl > ql)) pr = 0.f;
+                }
+                if (!k_valid) pr = 0.f;
+                sa[r] = pr;                              // P
+                dpa[r] = pr * (dpa[r] - dlt_t[qr]);      // dZ
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const s16x8 pb = acc_to_frag(sa, ks);
+                const s16x8 zb = acc_to_frag(dpa, ks);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    dvacc[dt] = mfma32(frag_cols<D, SLOW_TR>(dot, 16 * ks, 32 * dt, lane), pb, dvacc[dt]);
+                    dkacc[dt] = mfma32(frag_cols<D, SLOW_TR>(qt, 16 * ks, 32 * dt, lane), zb, dkacc[dt]);
+                }
+            }
+        }
+        if (it + 1 < ntiles) {
+            qst.store(q_lds + ((it + 1) & 1) * TILE_BYTES);
+            dst.store(do_lds + ((it + 1) & 1) * TILE_BYTES);
+            store_stats((it + 1) & 1);
+        }
+        __syncthreads();
+    }
+    if (k_in_T) {
+        store_rows_T<D>(dkrow, dkacc, k_valid ? p.scale : 0.f, true, lane);
+        store_rows_T<D>(dvrow, dvacc, k_valid ? 1.f : 0.f, true, lane);
+    }
+}
+
+bool slow_tr_requested() {
+    const char* e = getenv("HALVA_SDPA_SLOW_TR");
+    return e && e[0] == '1';
+}
+
+template <int D, bool CAUSAL>
+int launch_fwd(const SdpaParams& p, int S, hipStream_t st) {
+    const dim3 grid((p.T + 127) / 128, p.H, S), block(256);
+    const size_t lds = 4 * 64 * D * 2;
+    if (slow_tr_requested()) {
+        (void)hipFuncSetAttribute((const void*)sdpa_fwd_kernel<D, CAUSAL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((sdpa_fwd_kernel<D, CAUSAL, true>), grid, block, lds, st, p);
+    } else {
+        (void)hipFuncSetAttribute((const void*)sdpa_fwd_kernel<D, CAUSAL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((sdpa_fwd_kernel<D, CAUSAL, false>), grid, block, lds, st, p);
+    }
+    HALVA_CHECK_LAUNCH("sdpa_fwd");
+    return HALVA_OK;
+}
+
+template <int D, bool CAUSAL>
+int launch_bwd(const SdpaParams& p, int S, hipStream_t st) {
+    {
+        const int64_t total = (int64_t)S * p.T * p.H;
+        const int64_t threads = total * (D / 8);
+        hipLaunchKernelGGL((sdpa_delta_kernel<D>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, total);
+        HALVA_CHECK_LAUNCH("sdpa_delta");
+    }
+    const dim3 grid((p.T + 127) / 128, p.H, S), block(256);
+    const size_t lds_dq = 4 * 64 * D * 2;
+    const size_t lds_dkv = 4 * 32 * D * 2 + 4 * 32 * sizeof(float);
+    if (slow_tr_requested()) {
+        (void)hipFuncSetAttribute((const void*)sdpa_bwd_dq_kernel<D, CAUSAL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
+        hipLaunchKernelGGL((sdpa_bwd_dq_kernel<D, CAUSAL, true>), grid, block, lds_dq, st, p);
+        hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<D, CAUSAL, true>), grid, block, lds_dkv, st, p);
+    } else {
+        (void)hipFuncSetAttribute((const void*)sdpa_bwd_dq_kernel<D, CAUSAL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
+        hipLaunchKernelGGL((sdpa_bwd_dq_kernel<D, CAUSAL, false>), grid, block, lds_dq, st, p);
+        hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<D, CAUSAL, false>), grid, block, lds_dkv, st, p);
+    }
+    HALVA_CHECK_LAUNCH("sdpa_bwd");
+    return HALVA_OK;
+}
+
+}  // namespace
+
+extern "C" int halva_sdpa_causal_fwd(const void* qkv, void* out, float* lse, const int32_t* seq_start, const int32_t* seq_len,
+                                     int S, int T, int H, int D, float scale, void* stream) {
+    HALVA_CHECK_ARG(qkv && out && lse, "sdpa_causal_fwd: null pointer");
+    HALVA_CHECK_ARG(D == 128 || D == 64, "sdpa_causal_fwd: head_dim %d not supported (64 or 128)", D);
+    HALVA_CHECK_ARG(S > 0 && T > 0 && H > 0, "sdpa_causal_fwd: bad sizes");
+    SdpaParams p{};
+    const bf16_t* base = (const bf16_t*)qkv;
+    p.q = base;
+    p.k = base + (int64_t)H * D;
+    p.v = base + 2 * (int64_t)H * D;
+    p.o = (bf16_t*)out;
+    p.lse = lse;
+    p.seq_start = seq_start;
+    p.seq_len = seq_len;
+    p.ld_qkv = 3 * (int64_t)H * D;
+    p.ld_o = (int64_t)H * D;
+    p.T = T;
+    p.H = H;
+    p.scale = scale > 0.f ? scale : 1.f / sqrtf((float)D);
+    return D == 128 ? launch_fwd<128, true>(p, S, (hipStream_t)stream) : launch_fwd<64, true>(p, S, (hipStream_t)stream);
+}
+
+extern "C" int halva_sdpa_causal_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                                     float* delta_ws, float* dq_ws, const int32_t* seq_start, const int32_t* seq_len, int S,
+                                     int T, int H, int D, float scale, void* stream) {
+    (void)dq_ws;   // reserved for an atomics-based dQ variant; the shipped dQ kernel needs no scratch
+    HALVA_CHECK_ARG(qkv && out && dout && lse && dqkv && delta_ws, "sdpa_causal_bwd: null pointer");
+    HALVA_CHECK_ARG(D == 128 || D == 64, "sdpa_causal_bwd: head_dim %d not supported (64 or 128)", D);
+    HALVA_CHECK_ARG(S > 0 && T > 0 && H > 0, "sdpa_causal_bwd: bad sizes");
+    SdpaParams p{};
+    const bf16_t* base = (const bf16_t*)qkv;
+    p.q = base;
+    p.k = base + (int64_t)H * D;
+    p.v = base + 2 * (int64_t)H * D;
+    p.o_in = (const bf16_t*)out;
+    p.d_o = (const bf16_t*)dout;
+    bf16_t* dbase = (bf16_t*)dqkv;
+    p.dq = dbase;
+    p.dk = dbase + (int64_t)H * D;
+    p.dv = dbase + 2 * (int64_t)H * D;
+    p.lse = const_cast<float*>(lse);
+    p.delta = delta_ws;
+    p.seq_start = seq_start;
+    p.seq_len = seq_len;
+    p.ld_qkv = 3 * (int64_t)H * D;
+    p.ld_o = (int64_t)H * D;
+    p.T = T;
+    p.H = H;
+    p.scale = scale > 0.f ? scale : 1.f / sqrtf((float)D);
+    return D == 128 ? launch_bwd<128, true>(p, S, (hipStream_t)stream) : launch_bwd<64, true>(p, S, (hipStream_t)stream);
+}
+
+extern "C" int halva_sdpa_full_fwd(const void* qkv, void* out, int N, int S, int H, int D, float scale, void* stream) {
+    HALVA_CHECK_ARG(qkv && out, "sdpa_full_fwd: null pointer");
+    HALVA_CHECK_ARG(D == 128 || D == 64, "sdpa_full_fwd: head_dim %d not supported (64 or 128)", D);
+    HALVA_CHECK_ARG(N > 0 && S > 0 && H > 0, "sdpa_full_fwd: bad sizes");
+    SdpaParams p{};
+    const bf16_t* base = (const bf16_t*)qkv;
+    p.q = base;
+    p.k = base + (int64_t)H * D;
+    p.v = base + 2 * (int64_t)H * D;
+    p.o = (bf16_t*)out;
+    p.lse = nullptr;
+    p.ld_qkv = 3 * (int64_t)H * D;
+    p.ld_o = (int64_t)H * D;
+    p.T = S;
+    p.H = H;
+    p.scale = scale > 0.f ? scale : 1.f / sqrtf((float)D);
+    return D == 128 ? launch_fwd<128, false>(p, N, (hipStream_t)stream) : launch_fwd<64, false>(p, N, (hipStream_t)stream);
+}

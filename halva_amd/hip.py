@@ -1,0 +1,89 @@
+"""ctypes binding of libhalva_hip.so (include/halva_hip.h) - the only way the product reaches the GPU kernels.
+
+There is NO fallback: if the shared library is missing or an entry point fails, this module raises.
+PyTorch supplies device memory and the HIP stream only (raw pointers cross the boundary).
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("HALVA_HIP_LIB", os.path.join(_HERE, "libhalva_hip.so"))
+ABI_VERSION = 1
+BF16, F32 = 0, 1
+
+_P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+
+# name -> argtypes (all return int), mirroring include/halva_hip.h
+SIGNATURES = {
+    "halva_rmsnorm_fwd": [_P, _P, _P, _P, _L, _I, _F, _P],
+    "halva_rmsnorm_bwd": [_P, _P, _P, _P, _P, _L, _I, _P],
+    "halva_rope_qk": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
+    "halva_swiglu_fwd": [_P, _P, _L, _I, _P],
+    "halva_swiglu_bwd": [_P, _P, _P, _L, _I, _P],
+    "halva_sdpa_causal_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "halva_sdpa_causal_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "halva_sdpa_full_fwd": [_P, _P, _I, _I, _I, _I, _F, _P],
+    "halva_gemm_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "halva_clip_patch_embed": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "halva_gelu_bwd": [_P, _P, _P, _L, _I, _P],
+    "halva_colsum": [_P, _P, _L, _I, _P],
+    "halva_splice_rows": [_P, _P, _P, _P, _L, _I, _P],
+    "halva_token_logp_fwd": [_P, _I, _L, _P, _P, _P, _L, _I, _P],
+    "halva_token_logp_bwd": [_P, _I, _L, _P, _P, _P, _P, _L, _I, _P],
+    "halva_kl_rows": [_P, _P, _I, _L, _P, _P, _P, _F, _L, _I, _P],
+    "halva_phrase_sum_fwd": [_P, _P, _P, _P, _I, _P, _I, _I, _P],
+    "halva_phrase_sum_bwd": [_P, _P, _P, _P, _I, _P, _I, _I, _P],
+    "halva_probe_layouts": [_P, _I, _P],
+}
+
+_lib = None
+
+
+class HalvaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library; raises HalvaHipError if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HalvaHipError(
+            "libhalva_hip.so not found at %s - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C halva_amd/csrc`). There is no CPU fallback for the DPA hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.halva_last_error.restype = c_char_p
+    lib.halva_last_error.argtypes = []
+    lib.halva_abi_version.restype = c_int
+    lib.halva_abi_version.argtypes = []
+    if lib.halva_abi_version() != ABI_VERSION:
+        raise HalvaHipError("libhalva_hip.so ABI %d != expected %d" % (lib.halva_abi_version(), ABI_VERSION))
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = c_int
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise HalvaHipError("%s failed (%d): %s" % (name, rc, lib.halva_last_error().decode()))
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a CUDA/HIP tensor (None -> NULL).  CPU tensors are rejected: the kernels are GPU-only."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HalvaHipError("halva_amd kernels need device tensors; got a %s tensor (no CPU fallback)" % t.device)
+    return t.data_ptr()

@@ -1,0 +1,321 @@
+"""torch.autograd wrappers over the C-ABI kernels (halva_amd/hip.py).  Device tensors only; bf16 activations.
+
+Each Function names the reference call it stands in for; numerics follow the vendored transformers-4.31 spec
+(reference llava/model/language_model/modelling_llama.py) - see include/halva_hip.h for the per-kernel contract.
+"""
+import math
+
+import torch
+
+from . import hip
+from .hip import BF16, F32, call, ptr, stream_ptr
+
+_DT = {torch.bfloat16: BF16, torch.float32: F32}
+
+
+def _chk(t, dtype=None, name="tensor"):
+    if not t.is_cuda:
+        raise hip.HalvaHipError("%s must live on the GPU (got %s); the DPA path has no CPU fallback" % (name, t.device))
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+class _RMSNorm(torch.autograd.Function):
+    """LlamaRMSNorm.forward (modelling_llama.py:65-70).  Weight is frozen on the DPA path -> dx only."""
+
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        _chk(x, torch.bfloat16, "x"), _chk(w, torch.bfloat16, "w")
+        d = x.shape[-1]
+        rows = x.numel() // d
+        y = torch.empty_like(x)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        call("halva_rmsnorm_fwd", ptr(x), ptr(w), ptr(y), ptr(rstd), rows, d, float(eps), stream_ptr())
+        ctx.save_for_backward(x, w, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, rstd = ctx.saved_tensors
+        dy = _chk(dy.contiguous(), torch.bfloat16, "dy")
+        dx = torch.empty_like(x)
+        d = x.shape[-1]
+        call("halva_rmsnorm_bwd", ptr(dy), ptr(x), ptr(w), ptr(rstd), ptr(dx), x.numel() // d, d, stream_ptr())
+        return dx, None, None
+
+
+def rmsnorm(x, w, eps):
+    return _RMSNorm.apply(x, w, eps)
+
+
+# ------------------------------------------------------------------------------------------------
+def rope_tables(head_dim, max_pos, base=10000.0, device="cuda"):
+    """cos/sin tables [max_pos, D/2] in bf16 (modelling_llama.py:79-106: computed in fp32, cast to the compute dtype)."""
+    inv = 1.0 / (base ** (torch.arange(0, head_dim, 2, dtype=torch.float32, device=device) / head_dim))
+    freqs = torch.outer(torch.arange(max_pos, dtype=torch.float32, device=device), inv)
+    return freqs.cos().to(torch.bfloat16).contiguous(), freqs.sin().to(torch.bfloat16).contiguous()
+
+
+def _rope_inplace(qkv, cos, sin, T, H, D, inverse):
+    rows = qkv.numel() // (3 * H * D)
+    call("halva_rope_qk", ptr(qkv), ptr(cos), ptr(sin), None, rows, T, H, D, cos.shape[0], int(inverse), stream_ptr())
+
+
+class _Attention(torch.autograd.Function):
+    """RoPE + causal varlen attention on a packed qkv buffer: apply_rotary_pos_emb (modelling_llama.py:154-169) +
+    flash_attn_varlen_qkvpacked_func(causal=True) + pad_input (llama_flash_attn_monkey_patch.py:51-91).
+
+    qkv: [S, T, 3*H*D] bf16 (fresh GEMM output; rotated IN PLACE).  Returns [S, T, H*D]."""
+
+    @staticmethod
+    def forward(ctx, qkv, cos, sin, seq_start, seq_len, H, D):
+        _chk(qkv, torch.bfloat16, "qkv")
+        S, T = qkv.shape[0], qkv.shape[1]
+        _rope_inplace(qkv, cos, sin, T, H, D, False)
+        out = torch.empty(S, T, H * D, dtype=torch.bfloat16, device=qkv.device)
+        lse = torch.empty(S, H, T, dtype=torch.float32, device=qkv.device)
+        call("halva_sdpa_causal_fwd", ptr(qkv), ptr(out), ptr(lse), ptr(seq_start), ptr(seq_len), S, T, H, D, 0.0,
+             stream_ptr())
+        ctx.mark_dirty(qkv)
+        ctx.save_for_backward(qkv, out, lse, cos, sin, seq_start, seq_len)
+        ctx.dims = (S, T, H, D)
+        return out, qkv
+
+    @staticmethod
+    def backward(ctx, dout, _dqkv_unused):
+        qkv, out, lse, cos, sin, seq_start, seq_len = ctx.saved_tensors
+        S, T, H, D = ctx.dims
+        dout = _chk(dout.contiguous(), torch.bfloat16, "dout")
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty(S, H, T, dtype=torch.float32, device=qkv.device)
+        call("halva_sdpa_causal_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), None, ptr(seq_start),
+             ptr(seq_len), S, T, H, D, 0.0, stream_ptr())
+        _rope_inplace(dqkv, cos, sin, T, H, D, True)
+        return dqkv, None, None, None, None, None, None
+
+
+def attention(qkv, cos, sin, seq_start, seq_len, H, D):
+    out, _ = _Attention.apply(qkv, cos, sin, seq_start, seq_len, H, D)
+    return out
+
+
+def sdpa_full(qkv, H, D):
+    """Non-causal attention of the frozen CLIP tower (forward only).  qkv [N, S, 3*H*D] -> [N, S, H*D]."""
+    _chk(qkv, torch.bfloat16, "qkv")
+    N, S = qkv.shape[0], qkv.shape[1]
+    out = torch.empty(N, S, H * D, dtype=torch.bfloat16, device=qkv.device)
+    call("halva_sdpa_full_fwd", ptr(qkv), ptr(out), N, S, H, D, 0.0, stream_ptr())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+class _SwiGLU(torch.autograd.Function):
+    """act_fn(gate) * up (modelling_llama.py:197) on a fused [rows, 2F] gate|up buffer."""
+
+    @staticmethod
+    def forward(ctx, gu):
+        _chk(gu, torch.bfloat16, "gu")
+        F2 = gu.shape[-1]
+        rows = gu.numel() // F2
+        out = torch.empty(*gu.shape[:-1], F2 // 2, dtype=torch.bfloat16, device=gu.device)
+        call("halva_swiglu_fwd", ptr(gu), ptr(out), rows, F2 // 2, stream_ptr())
+        ctx.save_for_backward(gu)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (gu,) = ctx.saved_tensors
+        dout = _chk(dout.contiguous(), torch.bfloat16, "dout")
+        dgu = torch.empty_like(gu)
+        F2 = gu.shape[-1]
+        call("halva_swiglu_bwd", ptr(dout), ptr(gu), ptr(dgu), gu.numel() // F2, F2 // 2, stream_ptr())
+        return dgu
+
+
+def swiglu(gu):
+    return _SwiGLU.apply(gu)
+
+
+# ------------------------------------------------------------------------------------------------
+class _SpliceRows(torch.autograd.Function):
+    """The text/image splice of prepare_inputs_labels_for_multimodal[_signed] (llava_arch.py:285-374) as one row
+    gather driven by a host-computed index plan.  Gradient flows to the image features (mm_projector) only."""
+
+    @staticmethod
+    def forward(ctx, embed, feats, src, S, T):
+        _chk(embed, torch.bfloat16, "embed_tokens"), _chk(feats, torch.bfloat16, "image_features")
+        _chk(src, torch.int32, "src")
+        d = embed.shape[1]
+        out = torch.empty(S, T, d, dtype=torch.bfloat16, device=embed.device)
+        call("halva_splice_rows", ptr(embed), ptr(feats), ptr(src), ptr(out), S * T, d, stream_ptr())
+        ctx.save_for_backward(src)
+        ctx.feat_shape = feats.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (src,) = ctx.saved_tensors
+        d = dout.shape[-1]
+        rows = (src <= -2).nonzero().flatten()
+        dfeat = torch.zeros(ctx.feat_shape, dtype=torch.float32, device=dout.device).view(-1, d)
+        if rows.numel():
+            dfeat.index_add_(0, (-src[rows].long() - 2), dout.reshape(-1, d)[rows].float())
+        return None, dfeat.to(torch.bfloat16).view(ctx.feat_shape), None, None, None
+
+
+def splice_rows(embed, feats, src, S, T):
+    return _SpliceRows.apply(embed, feats.contiguous(), src, S, T)
+
+
+# ------------------------------------------------------------------------------------------------
+def gemm(A, B, bias=None, trans_a=False, trans_b=False, epilogue=0, out=None, out_dtype=torch.bfloat16, pre_act=None,
+         accumulate=False):
+    """C = epi(opA(A) @ opB(B)^T + bias) on the MFMA GEMM kernel.  Shapes: A [M,K] ([K,M] if trans_a), B [N,K] ([K,N])."""
+    _chk(A, torch.bfloat16, "A"), _chk(B, torch.bfloat16, "B")
+    M, K = (A.shape[1], A.shape[0]) if trans_a else (A.shape[0], A.shape[1])
+    N = B.shape[1] if trans_b else B.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype, device=A.device)
+    call("halva_gemm_bf16", ptr(A), ptr(B), ptr(bias), ptr(out), ptr(pre_act), M, N, K, int(trans_a), int(trans_b),
+         int(epilogue), _DT[out.dtype], int(accumulate), stream_ptr())
+    return out
+
+
+class _ProjectorMLP(torch.autograd.Function):
+    """mlp2x_gelu projector (multimodal_projector/builder.py:39-46): Linear -> GELU -> Linear with the bias/GELU
+    epilogue fused into the first GEMM.  The input (CLIP features) carries no gradient (clip_encoder.py:37)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x2 = _chk(x.reshape(-1, x.shape[-1]).contiguous(), torch.bfloat16, "x")
+        h_pre = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.bfloat16, device=x.device)
+        g = gemm(x2, w1, b1, epilogue=1, pre_act=h_pre)
+        y = gemm(g, w2, b2)
+        ctx.save_for_backward(x2, w1, w2, h_pre, g)
+        return y.view(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, h_pre, g = ctx.saved_tensors
+        dy2 = _chk(dy.reshape(-1, dy.shape[-1]).contiguous(), torch.bfloat16, "dy")
+        M = dy2.shape[0]
+        st = stream_ptr()
+        dw2 = gemm(dy2, g, trans_a=True, trans_b=True, out_dtype=torch.float32)          # dW2[n,k] = sum_m dy[m,n] g[m,k]
+        db2 = torch.zeros(w2.shape[0], dtype=torch.float32, device=dy.device)
+        call("halva_colsum", ptr(dy2), ptr(db2), M, w2.shape[0], st)
+        dg = gemm(dy2, w2, trans_b=True)                                                  # dg[m,k] = sum_n dy[m,n] W2[n,k]
+        dh = torch.empty_like(dg)
+        call("halva_gelu_bwd", ptr(dg), ptr(h_pre), ptr(dh), M, dg.shape[1], st)
+        dw1 = gemm(dh, x2, trans_a=True, trans_b=True, out_dtype=torch.float32)
+        db1 = torch.zeros(w1.shape[0], dtype=torch.float32, device=dy.device)
+        call("halva_colsum", ptr(dh), ptr(db1), M, w1.shape[0], st)
+        return None, dw1.to(w1.dtype), db1.to(w1.dtype), dw2.to(w2.dtype), db2.to(w2.dtype)
+
+
+def projector_mlp(x, w1, b1, w2, b2):
+    return _ProjectorMLP.apply(x, w1, b1, w2, b2)
+
+
+def clip_patch_embed(images, weight_kp, patch, d):
+    """Conv2d(3, d, k=p, s=p, bias=False) of HF CLIPVisionEmbeddings as im2col + MFMA GEMM.  images [n,3,hw,hw] bf16."""
+    _chk(images, torch.bfloat16, "images"), _chk(weight_kp, torch.bfloat16, "weight")
+    n, hw = images.shape[0], images.shape[-1]
+    np_ = (hw // patch) ** 2
+    Kp = weight_kp.shape[1]
+    ws = torch.empty(n * np_, Kp, dtype=torch.bfloat16, device=images.device)
+    out = torch.empty(n, np_, d, dtype=torch.bfloat16, device=images.device)
+    call("halva_clip_patch_embed", ptr(images), ptr(weight_kp), ptr(ws), ptr(out), n, hw, patch, d, Kp, stream_ptr())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+class _TokenLogp(torch.autograd.Function):
+    """logits.log_softmax(-1).gather(target) (halva_trainer.py:406-407) over rows of a [R, V] matrix."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        _chk(logits, None, "logits"), _chk(target, torch.int32, "target")
+        R, V = logits.shape
+        logp = torch.empty(R, dtype=torch.float32, device=logits.device)
+        lse = torch.empty(R, dtype=torch.float32, device=logits.device)
+        call("halva_token_logp_fwd", ptr(logits), _DT[logits.dtype], V, ptr(target), ptr(logp), ptr(lse), R, V, stream_ptr())
+        ctx.save_for_backward(logits, target, lse)
+        return logp
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, lse = ctx.saved_tensors
+        g = _chk(g.contiguous().float(), torch.float32, "g")
+        d = torch.empty_like(logits)
+        R, V = logits.shape
+        call("halva_token_logp_bwd", ptr(logits), _DT[logits.dtype], V, ptr(target), ptr(lse), ptr(g), ptr(d), R, V,
+             stream_ptr())
+        return d, None
+
+
+def token_logp(logits2d, target_i32):
+    return _TokenLogp.apply(logits2d, target_i32)
+
+
+class _KLRows(torch.autograd.Function):
+    """Per-row KL(ref || policy) (halva_trainer.py:583-586) with the policy gradient produced in the same launch."""
+
+    @staticmethod
+    def forward(ctx, pol, ref, w):
+        _chk(pol, None, "policy logits"), _chk(ref, pol.dtype, "reference logits")
+        R, V = pol.shape
+        kl = torch.empty(R, dtype=torch.float32, device=pol.device)
+        need = pol.requires_grad
+        dpol = torch.empty_like(pol) if need else None
+        call("halva_kl_rows", ptr(pol), ptr(ref), _DT[pol.dtype], V, ptr(w), ptr(kl), ptr(dpol), 1.0, R, V, stream_ptr())
+        ctx.save_for_backward(dpol)
+        return kl
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpol,) = ctx.saved_tensors
+        return dpol * g.to(dpol.dtype).unsqueeze(1), None, None
+
+
+def kl_rows(pol2d, ref2d, w=None):
+    return _KLRows.apply(pol2d, ref2d, w)
+
+
+class _PhraseSum(torch.autograd.Function):
+    """accumulate_logps (halva_trainer.py:411-419) fused with the loss-mask multiply (:556-557)."""
+
+    @staticmethod
+    def forward(ctx, logp, labels, signs, slot_ids):
+        _chk(logp, torch.float32, "logp"), _chk(labels, torch.int64, "labels"), _chk(signs, torch.int64, "signs")
+        B, T1 = logp.shape
+        P = slot_ids.numel()
+        acc = torch.zeros(B, P, dtype=torch.float32, device=logp.device)
+        if P:
+            call("halva_phrase_sum_fwd", ptr(logp), ptr(labels), ptr(signs), ptr(slot_ids), P, ptr(acc), B, T1, stream_ptr())
+        ctx.save_for_backward(labels, signs, slot_ids)
+        return acc
+
+    @staticmethod
+    def backward(ctx, dacc):
+        labels, signs, slot_ids = ctx.saved_tensors
+        B, T1 = labels.shape
+        P = slot_ids.numel()
+        dlogp = torch.zeros(B, T1, dtype=torch.float32, device=labels.device)
+        if P:
+            dacc = dacc.contiguous().float()
+            call("halva_phrase_sum_bwd", ptr(dacc), ptr(labels), ptr(signs), ptr(slot_ids), P, ptr(dlogp), B, T1, stream_ptr())
+        return dlogp, None, None, None
+
+
+def phrase_sum(logp, labels, signs, slot_ids):
+    return _PhraseSum.apply(logp, labels, signs, slot_ids)
+
+
+def probe_layouts(device="cuda"):
+    out = torch.zeros(256 + 1024, dtype=torch.int32, device=device)
+    call("halva_probe_layouts", ptr(out), out.numel(), stream_ptr())
+    return out.cpu()

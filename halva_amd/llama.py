@@ -1,0 +1,355 @@
+"""Llama decoder with LoRA for the DPA step - the MI355X-native stand-in for HF LlamaForCausalLM + peft LoRA +
+the flash-attn monkey patch of the reference (llava/model/language_model/llava_llama.py:42-85 ->
+transformers 4.31 LlamaForCausalLM; numerics spec: llava/model/language_model/modelling_llama.py).
+
+MI355X-first choices:
+  * frozen base weights are stored fused ([q;k;v] and [gate;up]) so each decoder layer is 4 large hipBLASLt GEMMs
+    (PyTorch-ROCm) + 4 skinny LoRA GEMM pairs; residual adds ride in the GEMM epilogue (addmm, beta = 1);
+  * RMSNorm, RoPE, causal attention (MFMA), SwiGLU run as hand-written HIP kernels through the C ABI;
+  * LoRA/projector gradients accumulate straight into one flat fp32 buffer (`main_grad`) - the buffer the
+    data-parallel all-reduce and AdamW operate on - instead of per-parameter bf16 `.grad` tensors.
+No CPU fallback: every forward reaches libhalva_hip.so.
+"""
+import json
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+
+
+class LlamaConfig:
+    """Minimal HF-compatible config (reads/writes config.json; unknown keys are kept)."""
+    model_type = "llama"
+    _defaults = dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
+                     num_attention_heads=32, num_key_value_heads=None, hidden_act="silu", max_position_embeddings=4096,
+                     rms_norm_eps=1e-5, rope_theta=10000.0, pad_token_id=0, bos_token_id=1, eos_token_id=2,
+                     pretraining_tp=1, use_cache=True, tie_word_embeddings=False)
+
+    def __init__(self, **kw):
+        for k, v in self._defaults.items():
+            setattr(self, k, v)
+        for k, v in kw.items():
+            setattr(self, k, v)
+        if self.num_key_value_heads is None:
+            self.num_key_value_heads = self.num_attention_heads
+
+    def to_dict(self):
+        d = {k: v for k, v in self.__dict__.items() if not k.startswith("_") and _jsonable(v)}
+        d["model_type"] = self.model_type
+        return d
+
+    def save_pretrained(self, path):
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(self.to_dict(), f, indent=2, sort_keys=True)
+
+    @classmethod
+    def from_pretrained(cls, path, **kw):
+        with open(os.path.join(path, "config.json")) as f:
+            d = json.load(f)
+        d.pop("model_type", None)
+        d.update(kw)
+        return cls(**d)
+
+
+def _jsonable(v):
+    try:
+        json.dumps(v)
+        return True
+    except TypeError:
+        return False
+
+
+LORA_TARGETS = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
+
+
+class _LoraGroupFn(torch.autograd.Function):
+    """y = [residual +] x W^T + scale * concat_g( (x A_g^T) B_g^T )  for G LoRA targets sharing one fused base weight.
+
+    peft 0.4.0 Linear.forward semantics (result += lora_B(lora_A(dropout(x))) * scaling; dropout forced to 0 by the
+    reference, llava/train/halva_trainer.py:35-38,184-187).  Base weight frozen: backward yields dx, dA, dB only.
+    With `sink` set the LoRA grads are added into the parameters' fp32 `main_grad` views and None is returned."""
+
+    @staticmethod
+    def forward(ctx, x, residual, W, A, scale, sink, *Bs):
+        d_in = x.shape[-1]
+        x2 = x.reshape(-1, d_in)
+        N = W.shape[0]
+        if residual is None:
+            y = torch.mm(x2, W.t())
+        else:
+            y = torch.addmm(residual.reshape(-1, N), x2, W.t())
+        a = None
+        if A is not None:
+            r = A.shape[0] // len(Bs)
+            a = torch.mm(x2, A.t())
+            off = 0
+            for g, B in enumerate(Bs):
+                n = B.shape[0]
+                y[:, off:off + n].addmm_(a[:, g * r:(g + 1) * r], B.t(), alpha=scale)
+                off += n
+        ctx.save_for_backward(x2, a, W, A, *Bs)
+        ctx.scale, ctx.sink, ctx.has_res = scale, sink, residual is not None
+        ctx.x_shape = x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, a, W, A, *Bs = ctx.saved_tensors
+        N = W.shape[0]
+        dy2 = dy.reshape(-1, N)
+        dx = torch.mm(dy2, W)
+        dA = None
+        dBs = [None] * len(Bs)
+        if A is not None:
+            r = A.shape[0] // len(Bs)
+            da = torch.empty(dy2.shape[0], A.shape[0], dtype=dy2.dtype, device=dy2.device)
+            off = 0
+            for g, B in enumerate(Bs):
+                n = B.shape[0]
+                dyg = dy2[:, off:off + n]
+                torch.mm(dyg, B, out=da[:, g * r:(g + 1) * r])
+                gB = torch.mm(dyg.t(), a[:, g * r:(g + 1) * r])
+                if ctx.sink:
+                    B.main_grad.add_(gB, alpha=ctx.scale)
+                else:
+                    dBs[g] = gB * ctx.scale
+                off += n
+            da.mul_(ctx.scale)
+            dx.addmm_(da, A)
+            gA = torch.mm(da.t(), x2)
+            if ctx.sink:
+                A.main_grad.add_(gA)
+            else:
+                dA = gA
+        return (dx.view(ctx.x_shape), dy if ctx.has_res else None, None, dA, None, None, *dBs)
+
+
+class LoraTarget(nn.Module):
+    """Holder of one target's LoRA factors, named like peft (`<target>.lora_A.default.weight`)."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.lora_A = nn.ModuleDict()
+        self.lora_B = nn.ModuleDict()
+
+
+class _W(nn.Module):
+    def __init__(self, t):
+        super().__init__()
+        self.weight = nn.Parameter(t)
+
+
+class RMSNormW(nn.Module):
+    def __init__(self, d, eps, dtype, device):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d, dtype=dtype, device=device), requires_grad=False)
+        self.variance_epsilon = eps
+
+    def forward(self, x):
+        return K.rmsnorm(x, self.weight, self.variance_epsilon)
+
+
+class LoraGroup(nn.Module):
+    """A fused frozen weight [sum(out_g), in] plus the LoRA factors of its G targets."""
+
+    def __init__(self, names, in_features, outs, dtype, device):
+        super().__init__()
+        self.names, self.outs, self.in_features = tuple(names), tuple(outs), in_features
+        self.weight = nn.Parameter(torch.empty(sum(outs), in_features, dtype=dtype, device=device), requires_grad=False)
+        for n, o in zip(names, outs):
+            setattr(self, n, LoraTarget(in_features, o))
+        self.A_cat = None          # [G*r, in] view-concatenation target (rebuilt by attach_lora)
+        self.scale = 0.0
+        self.grad_sink = False
+
+    def targets(self):
+        return [getattr(self, n) for n in self.names]
+
+    def attach_lora(self, r, alpha, dtype, device, generator=None):
+        """peft 0.4.0 init: A ~ kaiming_uniform(a=sqrt(5)), B = 0, scaling = alpha / r.  The G A-factors live in one
+        [G*r, in] parameter-backed buffer so the A-side GEMM is a single launch; each target's lora_A.default.weight
+        is a row-slice view of it."""
+        G = len(self.names)
+        A_all = torch.empty(G * r, self.in_features, dtype=torch.float32, device=device)
+        bound = 1.0 / math.sqrt(self.in_features)          # kaiming_uniform_(a=sqrt(5)) on [r, in] == U(-1/sqrt(in), 1/sqrt(in))
+        A_all.uniform_(-bound, bound, generator=generator)
+        self.A_cat = nn.Parameter(A_all.to(dtype))
+        for g, (n, o) in enumerate(zip(self.names, self.outs)):
+            t = getattr(self, n)
+            t.lora_B["default"] = _W(torch.zeros(o, r, dtype=dtype, device=device))
+        self.scale = float(alpha) / float(r)
+        self.r = r
+
+    def lora_state(self):
+        """{peft-style name: tensor} for this group's targets."""
+        out = {}
+        if self.A_cat is None:
+            return out
+        r = self.r
+        for g, n in enumerate(self.names):
+            out[n + ".lora_A.default.weight"] = self.A_cat.data[g * r:(g + 1) * r]
+            out[n + ".lora_B.default.weight"] = getattr(self, n).lora_B["default"].weight.data
+        return out
+
+    def forward(self, x, residual=None, use_lora=True):
+        if self.A_cat is not None and use_lora:
+            Bs = [getattr(self, n).lora_B["default"].weight for n in self.names]
+            return _LoraGroupFn.apply(x, residual, self.weight, self.A_cat, self.scale, self.grad_sink, *Bs)
+        return _LoraGroupFn.apply(x, residual, self.weight, None, 0.0, False)
+
+
+class SeqInfo:
+    """Per-forward constants shared by all layers: RoPE tables and the valid span of every padded row."""
+
+    def __init__(self, cos, sin, seq_start, seq_len):
+        self.cos, self.sin, self.seq_start, self.seq_len = cos, sin, seq_start, seq_len
+
+
+class DecoderLayer(nn.Module):
+    """LlamaDecoderLayer (modelling_llama.py:352-420) with attention per llama_flash_attn_monkey_patch.py:16-93."""
+
+    def __init__(self, cfg, dtype, device):
+        super().__init__()
+        d, Fd = cfg.hidden_size, cfg.intermediate_size
+        self.H = cfg.num_attention_heads
+        self.D = d // self.H
+        if cfg.num_key_value_heads != cfg.num_attention_heads:
+            raise NotImplementedError("grouped-query attention is not on the LLaVA-1.5 path (kv heads == heads)")
+        self.qkv = LoraGroup(("q_proj", "k_proj", "v_proj"), d, (d, d, d), dtype, device)
+        self.o = LoraGroup(("o_proj",), d, (d,), dtype, device)
+        self.gate_up = LoraGroup(("gate_proj", "up_proj"), d, (Fd, Fd), dtype, device)
+        self.down = LoraGroup(("down_proj",), Fd, (d,), dtype, device)
+        self.input_layernorm = RMSNormW(d, cfg.rms_norm_eps, dtype, device)
+        self.post_attention_layernorm = RMSNormW(d, cfg.rms_norm_eps, dtype, device)
+
+    def groups(self):
+        return (("self_attn", self.qkv), ("self_attn", self.o), ("mlp", self.gate_up), ("mlp", self.down))
+
+    def forward(self, x, info, use_lora=True):
+        h = self.input_layernorm(x)
+        qkv = self.qkv(h, None, use_lora)
+        a = K.attention(qkv, info.cos, info.sin, info.seq_start, info.seq_len, self.H, self.D)
+        x = self.o(a, x, use_lora)
+        h = self.post_attention_layernorm(x)
+        act = K.swiglu(self.gate_up(h, None, use_lora))
+        return self.down(act, x, use_lora)
+
+
+class LlamaModel(nn.Module):
+    def __init__(self, cfg, dtype=torch.bfloat16, device="cuda"):
+        super().__init__()
+        self.config = cfg
+        self.embed_tokens = nn.Embedding(cfg.vocab_size, cfg.hidden_size, dtype=dtype, device=device)
+        self.embed_tokens.weight.requires_grad_(False)
+        self.layers = nn.ModuleList([DecoderLayer(cfg, dtype, device) for _ in range(cfg.num_hidden_layers)])
+        self.norm = RMSNormW(cfg.hidden_size, cfg.rms_norm_eps, dtype, device)
+        self.gradient_checkpointing = False
+        self._rope = {}
+
+    def rope(self, T, device):
+        key = (str(device), max(T, 1))
+        if key not in self._rope:
+            n = max(T, getattr(self.config, "tokenizer_model_max_length", 0) or 0, 16)
+            self._rope = {key: K.rope_tables(self.config.hidden_size // self.config.num_attention_heads, n,
+                                             getattr(self.config, "rope_theta", 10000.0), device)}
+            self._rope[(str(device), n)] = self._rope[key]
+        return self._rope[key]
+
+    def run_layers(self, x, seq_start, seq_len, use_lora=True):
+        """x [S, T, d] bf16 -> last hidden state after the final RMSNorm (modelling_llama.py:580-705)."""
+        T = x.shape[1]
+        cos, sin = self.rope(T, x.device)
+        if cos.shape[0] < T:
+            self._rope = {}
+            cos, sin = self.rope(T, x.device)
+        info = SeqInfo(cos, sin, seq_start, seq_len)
+        for layer in self.layers:
+            if self.gradient_checkpointing and torch.is_grad_enabled() and x.requires_grad:
+                x = torch.utils.checkpoint.checkpoint(layer, x, info, use_lora, use_reentrant=False)
+            else:
+                x = layer(x, info, use_lora)
+        return self.norm(x)
+
+
+def add_lora(model, r, alpha, generator=None):
+    """get_peft_model(model, LoraConfig(r, lora_alpha, target_modules=all Llama linears)) of the reference
+    (llava/train/train_halva.py:1085-1101): every base parameter frozen, LoRA factors trainable."""
+    for p in model.parameters():
+        p.requires_grad_(False)
+    for layer in model.model.layers:
+        for _, grp in layer.groups():
+            grp.attach_lora(r, alpha, grp.weight.dtype, grp.weight.device, generator)
+    return model
+
+
+def lora_named_parameters(model):
+    """(name, parameter) of every trainable LoRA tensor, grouped-A first then each B (stable order)."""
+    out = []
+    for i, layer in enumerate(model.model.layers):
+        for sub, grp in layer.groups():
+            if grp.A_cat is None:
+                continue
+            out.append(("model.layers.%d.%s.%s.lora_A_cat" % (i, sub, "+".join(grp.names)), grp.A_cat))
+            for n in grp.names:
+                out.append(("model.layers.%d.%s.%s.lora_B.default.weight" % (i, sub, n), getattr(grp, n).lora_B["default"].weight))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# HF checkpoint <-> fused layout
+# ------------------------------------------------------------------------------------------------
+def load_hf_llama_weights(model, sd, strict=True):
+    """Copy an HF Llama state dict ({model.layers.i.self_attn.q_proj.weight, ...}) into the fused layout."""
+    def get(name):
+        if name not in sd:
+            if strict:
+                raise KeyError(name)
+            return None
+        return sd[name]
+
+    m = model.model
+    with torch.no_grad():
+        w = get("model.embed_tokens.weight")
+        if w is not None:
+            m.embed_tokens.weight.copy_(w)
+        w = get("model.norm.weight")
+        if w is not None:
+            m.norm.weight.copy_(w)
+        w = get("lm_head.weight")
+        if w is not None:
+            model.lm_head.weight.copy_(w)
+        for i, layer in enumerate(m.layers):
+            p = "model.layers.%d." % i
+            for sub, grp in layer.groups():
+                off = 0
+                for n, o in zip(grp.names, grp.outs):
+                    w = get(p + sub + "." + n + ".weight")
+                    if w is not None:
+                        grp.weight[off:off + o].copy_(w)
+                    off += o
+            for n in ("input_layernorm", "post_attention_layernorm"):
+                w = get(p + n + ".weight")
+                if w is not None:
+                    getattr(layer, n).weight.copy_(w)
+
+
+def hf_llama_state_dict(model):
+    """Inverse of load_hf_llama_weights (views, no copies)."""
+    m = model.model
+    out = {"model.embed_tokens.weight": m.embed_tokens.weight.data, "model.norm.weight": m.norm.weight.data,
+           "lm_head.weight": model.lm_head.weight.data}
+    for i, layer in enumerate(m.layers):
+        p = "model.layers.%d." % i
+        for sub, grp in layer.groups():
+            off = 0
+            for n, o in zip(grp.names, grp.outs):
+                out[p + sub + "." + n + ".weight"] = grp.weight.data[off:off + o]
+                off += o
+        out[p + "input_layernorm.weight"] = layer.input_layernorm.weight.data
+        out[p + "post_attention_layernorm.weight"] = layer.post_attention_layernorm.weight.data
+    return out

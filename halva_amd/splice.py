@@ -1,0 +1,108 @@
+"""Host-side index plan for the text/image splice (product code; integer work only).
+
+The reference builds `inputs_embeds` with a per-sample Python loop of small device ops and `.tolist()` syncs
+(reference llava/model/llava_arch.py:277-374).  Everything in that loop except the final row copies depends
+only on `input_ids` / `attention_mask`, which are host data before the H2D copy - so the plan (which source row
+feeds every output row, the spliced labels / signs / attention mask, the per-sequence valid span) is computed
+here on the host, and one gather kernel (halva_splice_rows) materialises the embeddings on the GPU.
+
+Semantics reproduced exactly (tests/test_hip_kernels.py::test_splice_rows_against_golden, bit-exact):
+  * padding is removed with the attention mask, each IMAGE_TOKEN_INDEX expands to the image's n_patch feature rows
+    with labels/signs := IGNORE_INDEX, one image is consumed per image token - and also by an image-less sample
+    (llava_arch.py:287-294);
+  * sequences are truncated to tokenizer_model_max_length AFTER the splice (:334-339);
+  * right (or left) padding with zero vectors / IGNORE_INDEX / False (:341-374).
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+IGNORE_INDEX = -100
+IMAGE_TOKEN_INDEX = -200
+
+
+@dataclass
+class SplicePlan:
+    src: torch.Tensor                 # int32 [S*T]: >=0 token id, -1 zero pad, <=-2 feature row -(idx)-2
+    labels: torch.Tensor              # int64 [S, T]
+    signs: Optional[torch.Tensor]     # int64 [S, T] or None
+    mask: torch.Tensor                # bool  [S, T]
+    seq_start: torch.Tensor           # int32 [S]
+    seq_len: torch.Tensor             # int32 [S]
+    S: int
+    T: int
+    n_images: int                     # image slots consumed (running index of the reference)
+
+
+def plan_splice(input_ids, attention_mask, labels, signs, n_patch, max_len=None, padding_side="right", image_map=None):
+    """input_ids/labels/signs: int64 [S, L] (CPU), attention_mask bool [S, L] or None.  image_map (optional) maps the
+    running image-slot index of the reference to a row of the feature tensor (lets pos/neg rows share one encode)."""
+    ids = np.asarray(input_ids)
+    S, L = ids.shape
+    att = np.ones((S, L), dtype=bool) if attention_mask is None else np.asarray(attention_mask).astype(bool)
+    lab = np.full((S, L), IGNORE_INDEX, dtype=np.int64) if labels is None else np.asarray(labels)
+    sgn = None if signs is None else np.asarray(signs)
+    rows_src, rows_lab, rows_sgn = [], [], []
+    slot = 0
+    for b in range(S):
+        keep = att[b]
+        cur = ids[b][keep]
+        is_img = cur == IMAGE_TOKEN_INDEX
+        n_img = int(is_img.sum())
+        reps = np.where(is_img, n_patch, 1)
+        src = np.repeat(cur, reps).astype(np.int64)
+        l = np.repeat(lab[b][keep], reps)
+        s = np.repeat(sgn[b][keep], reps) if sgn is not None else None
+        if n_img:
+            starts = np.cumsum(reps) - reps                       # output offset of every kept token
+            for j, pos in enumerate(np.nonzero(is_img)[0]):
+                feat = slot + j if image_map is None else int(image_map[slot + j])
+                o = starts[pos]
+                src[o:o + n_patch] = -(feat * n_patch + np.arange(n_patch)) - 2
+                l[o:o + n_patch] = IGNORE_INDEX
+                if s is not None:
+                    s[o:o + n_patch] = IGNORE_INDEX
+            slot += n_img
+        else:
+            slot += 1                                             # an image-less sample still consumes one image
+        if max_len is not None:
+            src, l = src[:max_len], l[:max_len]
+            if s is not None:
+                s = s[:max_len]
+        rows_src.append(src)
+        rows_lab.append(l)
+        rows_sgn.append(s)
+    T = max(len(r) for r in rows_src)
+    out_src = np.full((S, T), -1, dtype=np.int32)
+    out_lab = np.full((S, T), IGNORE_INDEX, dtype=np.int64)
+    out_sgn = np.full((S, T), IGNORE_INDEX, dtype=np.int64) if sgn is not None else None
+    out_mask = np.zeros((S, T), dtype=bool)
+    start = np.zeros(S, dtype=np.int32)
+    length = np.zeros(S, dtype=np.int32)
+    for b in range(S):
+        n = len(rows_src[b])
+        o = T - n if padding_side == "left" else 0
+        out_src[b, o:o + n] = rows_src[b]
+        out_lab[b, o:o + n] = rows_lab[b]
+        if out_sgn is not None:
+            out_sgn[b, o:o + n] = rows_sgn[b]
+        out_mask[b, o:o + n] = True
+        start[b], length[b] = o, n
+    return SplicePlan(src=torch.from_numpy(out_src.reshape(-1)), labels=torch.from_numpy(out_lab),
+                      signs=None if out_sgn is None else torch.from_numpy(out_sgn), mask=torch.from_numpy(out_mask),
+                      seq_start=torch.from_numpy(start), seq_len=torch.from_numpy(length), S=S, T=T, n_images=slot)
+
+
+def spans_from_mask(mask):
+    """[S, T] bool key-padding mask -> (seq_start, seq_len) int32; the valid tokens must be one contiguous run
+    (what right/left padding produces; the reference's unpad_input accepts holes, the splice never makes them)."""
+    m = np.asarray(mask).astype(bool)
+    S, T = m.shape
+    length = m.sum(1).astype(np.int32)
+    start = np.where(length > 0, m.argmax(1), 0).astype(np.int32)
+    idx = np.arange(T)[None]
+    if not np.array_equal(m, (idx >= start[:, None]) & (idx < (start + length)[:, None])):
+        raise ValueError("attention_mask must mark one contiguous run of valid tokens per sequence")
+    return torch.from_numpy(start), torch.from_numpy(length)

@@ -1,0 +1,127 @@
+/* libhalva_hip.so - C ABI of the hand-written gfx950 (MI355X / CDNA4) kernels behind the HALVA DPA step.
+ *
+ * The reference (pritamqu/HALVA) is pure Python and owns no FFI; its only optimisation seam is the
+ * attention monkey-patch (reference llava/train/llama_flash_attn_monkey_patch.py:16-115).  This header is
+ * therefore the drop-in boundary defined by this build: each entry point names the reference call it
+ * replaces (file:line, relative to the reference tree).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - plain C: raw device pointers + explicit sizes; no torch types.  The caller owns every buffer; no entry
+ *     point allocates, frees or synchronises.  All work is enqueued on `stream` (a hipStream_t, NULL = default).
+ *   - return value: 0 on success, a negative HALVA_ERR_* otherwise; halva_last_error() gives the text
+ *     (thread-local).  Entry points are re-entrant and hold no mutable global state.
+ *   - dtype arguments use halva_dtype.  "rows" are tokens (S*T); matrices are row-major.
+ *   - sequences are described by seq_start[S], seq_len[S] (int32): the valid tokens of sequence s are
+ *     [seq_start[s], seq_start[s]+seq_len[s]) on its T-long padded row (right padding: start 0).
+ */
+#ifndef HALVA_HIP_H
+#define HALVA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HALVA_ABI_VERSION 1
+
+typedef enum { HALVA_BF16 = 0, HALVA_F32 = 1 } halva_dtype;
+
+#define HALVA_OK 0
+#define HALVA_ERR_INVALID_ARG (-1)
+#define HALVA_ERR_LAUNCH (-2)
+#define HALVA_ERR_UNSUPPORTED (-3)
+
+int halva_abi_version(void);
+const char* halva_last_error(void);
+
+/* ---- Llama RMSNorm.  replaces LlamaRMSNorm.forward (llava/model/language_model/modelling_llama.py:65-70)
+ * y = w * cast(x_f32 * rsqrt(mean(x_f32^2) + eps)); rstd[rows] (f32) is saved for the backward.
+ * bwd gives dx only (norm weights are frozen on the LoRA DPA path; llava/train/train_halva.py:1085-1101). */
+int halva_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int d, float eps, void* stream);
+int halva_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, int64_t rows, int d,
+                      void* stream);
+
+/* ---- RoPE, in place on the q and k thirds of a packed qkv buffer [rows, 3, H, D] (bf16).
+ * replaces apply_rotary_pos_emb (modelling_llama.py:154-169) as called from
+ * llava/train/llama_flash_attn_monkey_patch.py:51-55.  cos/sin: [max_pos, D/2] bf16 (the table halves are equal,
+ * modelling_llama.py:98-100).  pos: int32 [rows] or NULL for pos = row % T.  inverse != 0 applies the transpose
+ * rotation (the backward). */
+int halva_rope_qk(void* qkv, const void* cos, const void* sin, const int32_t* pos, int64_t rows, int T, int H, int D,
+                  int max_pos, int inverse, void* stream);
+
+/* ---- SwiGLU.  replaces act_fn(gate_proj(x)) * up_proj(x) (modelling_llama.py:197).  gu = [rows, 2F] (gate | up). */
+int halva_swiglu_fwd(const void* gu, void* out, int64_t rows, int F, void* stream);
+int halva_swiglu_bwd(const void* dout, const void* gu, void* dgu, int64_t rows, int F, void* stream);
+
+/* ---- causal self-attention on right/left padded rows, bf16, head_dim 128 (Llama) - THE headline kernel.
+ * replaces flash_attn_varlen_qkvpacked_func(qkv, cu_q_lens, max_s, 0.0, softmax_scale=None, causal=True)
+ * together with unpad_input / pad_input (llava/train/llama_flash_attn_monkey_patch.py:71-91).
+ * qkv: [S, T, 3, H, D] packed (RoPE already applied); out: [S, T, H, D]; lse: [S, H, T] f32 (natural log).
+ * Padded query rows get zeros (pad_input semantics).  scale = 1/sqrt(D) when <= 0.
+ * bwd: dqkv [S, T, 3, H, D] bf16 is fully written (zeros on padded rows); delta_ws: [S, H, T] f32 and
+ * dq_ws: [S, T, H, D] f32 scratch owned by the caller (dq_ws must be zero-filled by the caller). */
+int halva_sdpa_causal_fwd(const void* qkv, void* out, float* lse, const int32_t* seq_start, const int32_t* seq_len,
+                          int S, int T, int H, int D, float scale, void* stream);
+int halva_sdpa_causal_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                          float* delta_ws, float* dq_ws, const int32_t* seq_start, const int32_t* seq_len, int S, int T,
+                          int H, int D, float scale, void* stream);
+
+/* ---- non-causal self-attention, bf16, head_dim 64, forward only (the CLIP tower runs under no_grad:
+ * llava/model/multimodal_encoder/clip_encoder.py:37-49; replaces HF CLIPAttention's softmax(QK^T*scale)V).
+ * qkv: [N, S, 3, H, D] packed; out [N, S, H, D]. */
+int halva_sdpa_full_fwd(const void* qkv, void* out, int N, int S, int H, int D, float scale, void* stream);
+
+/* ---- bf16 GEMM on MFMA with fused epilogue: C[M,N] = epi(A[M,K] @ B[N,K]^T + bias[N]).
+ * replaces the mm_projector Linear/GELU/Linear (llava/model/multimodal_projector/builder.py:39-46) and,
+ * with im2col addressing, CLIP's patch-embed Conv2d(3, d, k=14, s=14, bias=False) reached through
+ * clip_encoder.py:46.  epilogue: 0 none, 1 GELU(erf).  trans_a / trans_b select the backward forms
+ * (A given as [K,M] / B given as [K,N]).  bias may be NULL.  pre_act (optional) receives A B^T + bias before the
+ * epilogue (needed by the GELU backward); accumulate != 0 adds into C (gradient accumulation, f32 or bf16). */
+int halva_gemm_bf16(const void* A, const void* B, const void* bias, void* C, void* pre_act, int M, int N, int K,
+                    int trans_a, int trans_b, int epilogue, halva_dtype out_dtype, int accumulate, void* stream);
+/* images [n, 3, hw, hw] bf16; weight_kp [d, Kp] bf16 = the conv weight flattened to [d, 3*p*p] and zero padded to
+ * Kp (multiple of 8); col_ws: caller scratch [n * (hw/p)^2, Kp] bf16 -> out [n, (hw/p)^2, d] bf16 */
+int halva_clip_patch_embed(const void* images, const void* weight_kp, void* col_ws, void* out, int n, int hw, int p, int d,
+                           int Kp, void* stream);
+/* dh[M,N] = dy[M,N] * gelu'(h[M,N]) (h = pre-activation), and column sums for the bias grads. */
+int halva_gelu_bwd(const void* dy, const void* h, void* dh, int64_t M, int N, void* stream);
+int halva_colsum(const void* x, float* out, int64_t M, int N, void* stream);
+
+/* ---- splice gather.  replaces the per-sample python loop of prepare_inputs_labels_for_multimodal[_signed]
+ * (llava/model/llava_arch.py:285-374): out[r] = embed[src[r]] if src[r] >= 0, feats[-src[r]-2] if src[r] <= -2,
+ * zeros if src[r] == -1 (padding).  src is the host-computed index plan, rows = S*T. */
+int halva_splice_rows(const void* embed, const void* feats, const int32_t* src, void* out, int64_t rows, int d,
+                      void* stream);
+
+/* ---- token log-prob.  replaces logits.log_softmax(-1) + gather (llava/train/halva_trainer.py:406-407).
+ * logits [R, V] (row stride ld elements), target int32 [R] (already shifted; IGNORE_INDEX mapped to 0 by the
+ * caller exactly as halva_trainer.py:406).  logp[R], lse[R] f32.
+ * bwd: dlogits[r, v] = g[r] * (1[v == target[r]] - exp(logits[r,v] - lse[r])); may alias logits. */
+int halva_token_logp_fwd(const void* logits, halva_dtype dt, int64_t ld, const int32_t* target, float* logp, float* lse,
+                         int64_t R, int V, void* stream);
+int halva_token_logp_bwd(const void* logits, halva_dtype dt, int64_t ld, const int32_t* target, const float* lse,
+                         const float* g, void* dlogits, int64_t R, int V, void* stream);
+
+/* ---- KL(ref || policy) per row.  replaces the softmax/log/product/mask/sum chain (halva_trainer.py:583-588).
+ * kl[r] = w[r] * sum_v p_ref (log p_ref - log p_pol), computed with log-softmax algebra (identical where the
+ * reference's softmax().log() is finite).  If dpol != NULL it also receives d kl[r] / d pol_logits[r, :]
+ * = w[r] * (p_pol - p_ref) * gscale (may alias pol). */
+int halva_kl_rows(const void* pol, const void* ref, halva_dtype dt, int64_t ld, const float* w, float* kl, void* dpol,
+                  float gscale, int64_t R, int V, void* stream);
+
+/* ---- phrase accumulation.  replaces accumulate_logps (halva_trainer.py:411-419) incl. the loss-mask multiply
+ * (:556-557): acc[b, p] = sum_t logp[b,t] * (labels[b,t] != -100) * (signs[b,t] == slot_ids[p]).
+ * slot_ids: sorted unique non-zero sign ids of the WHOLE half batch (host computed).  bwd scatters dacc back. */
+int halva_phrase_sum_fwd(const float* logp, const int64_t* labels, const int64_t* signs, const int64_t* slot_ids, int P,
+                         float* acc, int B, int T1, void* stream);
+int halva_phrase_sum_bwd(const float* dacc, const int64_t* labels, const int64_t* signs, const int64_t* slot_ids, int P,
+                         float* dlogp, int B, int T1, void* stream);
+
+/* ---- hardware-layout probes used by the GPU tests (MFMA fragment maps, ds_read_b64_tr_b16). */
+int halva_probe_layouts(int32_t* out, int n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HALVA_HIP_H */

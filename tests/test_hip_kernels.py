@@ -1,0 +1,325 @@
+"""GPU parity tests: every C-ABI kernel (through halva_amd.kernels -> libhalva_hip.so) against the oracle.
+
+Floating-point tolerances are stated per test; the oracle is evaluated in fp32 on the SAME bf16-rounded inputs, so
+the remaining error is the kernel's bf16 output rounding + accumulation order.  Integer/index results are exact.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from golden_util import load_npz, meta_of  # noqa: E402
+from oracle import dpa, host, nets  # noqa: E402
+
+DEV = "cuda"
+
+
+def K():
+    from halva_amd import kernels
+    return kernels
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def rel_err(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def test_library_loads_and_probe_layouts():
+    out = K().probe_layouts().numpy()
+    tr = out[:256].reshape(64, 4)
+    exp_tr = np.zeros((64, 4), dtype=np.int64)
+    for l in range(64):
+        for e in range(4):
+            exp_tr[l, e] = 64 * (l >> 4) + 16 * e + (l & 15)
+    assert (tr == exp_tr).all(), "ds_read_b64_tr_b16 map differs from the model:\n%s" % tr
+    c = out[256:].reshape(64, 16)
+    A = np.array([[((i * 7 + k * 3) % 5) - 2 for k in range(16)] for i in range(32)])
+    B = np.array([[((k * 5 + j * 11) % 7) - 3 for j in range(32)] for k in range(16)])
+    C = A @ B
+    exp = np.zeros((64, 16), dtype=np.int64)
+    for l in range(64):
+        for r in range(16):
+            exp[l, r] = C[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31]
+    assert (c == exp).all(), "MFMA 32x32x16 operand/accumulator map differs from the model"
+
+
+@pytest.mark.parametrize("rows,d", [(7, 64), (1000, 4096), (33, 5120)])
+def test_rmsnorm(rows, d):
+    g = torch.Generator().manual_seed(0)
+    x = bf(torch.randn(rows, d, generator=g) * 2)
+    w = bf(1 + 0.1 * torch.randn(d, generator=g))
+    dy = bf(torch.randn(rows, d, generator=g))
+    xr = x.float().requires_grad_(True)
+    # spec: y = w * bf16(x * rstd); the oracle applies the same rounding point when fed bf16
+    y_ref = nets.rmsnorm(x, w, 1e-5)
+    xg = x.to(DEV).requires_grad_(True)
+    y = K().rmsnorm(xg, w.to(DEV), 1e-5)
+    assert torch.equal(y.cpu().view(torch.int16), y_ref.view(torch.int16)) or rel_err(y, y_ref) < 2e-3
+    y.backward(dy.to(DEV))
+    yf = nets.rmsnorm(xr, w.float(), 1e-5)
+    yf.backward(dy.float())
+    assert rel_err(xg.grad, xr.grad) < 6e-3          # bf16 output rounding of dx (2^-9 relative per element)
+
+
+def test_rope_forward_and_inverse():
+    S, T, H, D = 2, 37, 3, 128
+    g = torch.Generator().manual_seed(1)
+    qkv = bf(torch.randn(S, T, 3, H, D, generator=g))
+    cos, sin = K().rope_tables(D, 64, device=DEV)
+    work = qkv.to(DEV).clone().view(S, T, 3 * H * D)
+    from halva_amd.kernels import _rope_inplace
+    _rope_inplace(work, cos, sin, T, H, D, False)
+    got = work.view(S, T, 3, H, D).cpu()
+    c32, s32 = nets.rope_tables(D, T, dtype=torch.bfloat16)
+    pos = torch.arange(T)[None]
+    for part in (0, 1):
+        x = qkv[:, :, part].permute(0, 2, 1, 3).float()
+        ref = nets.rope_apply(x, c32.float(), s32.float(), pos).permute(0, 2, 1, 3)
+        assert rel_err(got[:, :, part], ref) < 4e-3
+    assert torch.equal(got[:, :, 2], qkv[:, :, 2])          # v untouched
+    _rope_inplace(work, cos, sin, T, H, D, True)             # inverse rotation restores q, k up to bf16 rounding
+    assert rel_err(work.view(S, T, 3, H, D).cpu(), qkv) < 8e-3
+
+
+def test_swiglu():
+    rows, Fd = 50, 11008
+    g = torch.Generator().manual_seed(2)
+    gu = bf(torch.randn(rows, 2 * Fd, generator=g) * 1.5)
+    dout = bf(torch.randn(rows, Fd, generator=g))
+    gug = gu.to(DEV).requires_grad_(True)
+    out = K().swiglu(gug)
+    out.backward(dout.to(DEV))
+    r = gu.float().requires_grad_(True)
+    ref = F.silu(r[:, :Fd]) * r[:, Fd:]
+    ref.backward(dout.float())
+    assert rel_err(out, ref) < 6e-3
+    assert rel_err(gug.grad, r.grad) < 6e-3
+
+
+def _attn_ref(qkv, starts, lens, causal=True):
+    """fp32 reference on bf16-rounded inputs: un-padded causal softmax attention, zeros on padded rows
+    (oracle.nets.attention_varlen semantics; reference llama_flash_attn_monkey_patch.py:71-91)."""
+    S, T, _, H, D = qkv.shape
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3).float() for i in range(3))
+    keep = torch.zeros(S, T, dtype=torch.bool)
+    for s in range(S):
+        keep[s, starts[s]:starts[s] + lens[s]] = True
+    if causal:
+        return nets.attention_varlen(q, k, v, keep).permute(0, 2, 1, 3)
+    att = torch.softmax(q @ k.transpose(2, 3) / math.sqrt(D), -1)
+    return (att @ v).permute(0, 2, 1, 3)
+
+
+@pytest.mark.parametrize("slow_tr", ["0", "1"])
+@pytest.mark.parametrize("T,lens,starts,H,D", [
+    (20, [20, 13], [0, 0], 2, 128),            # tiny, right padded
+    (200, [200, 77, 1], [0, 0, 0], 2, 128),    # ragged, len 1
+    (333, [333, 300], [0, 33], 1, 128),        # left padded second row (tokenizer_padding_side == "left")
+    (512, [512, 129], [0, 0], 2, 128),         # multiple q blocks, tile-aligned
+    (96, [96, 50], [0, 0], 4, 64),             # head_dim 64 instantiation
+])
+def test_sdpa_causal_fwd_bwd(T, lens, starts, H, D, slow_tr):
+    os.environ["HALVA_SDPA_SLOW_TR"] = slow_tr
+    try:
+        S = len(lens)
+        g = torch.Generator().manual_seed(3)
+        qkv = bf(torch.randn(S, T, 3, H, D, generator=g))
+        dout = bf(torch.randn(S, T, H, D, generator=g))
+        for s in range(S):                                   # gradient only flows from valid rows
+            dout[s, :starts[s]] = 0
+            dout[s, starts[s] + lens[s]:] = 0
+        ident_cos = torch.ones(T, D // 2, dtype=torch.bfloat16, device=DEV)     # RoPE == identity: isolate attention
+        ident_sin = torch.zeros(T, D // 2, dtype=torch.bfloat16, device=DEV)
+        qg = qkv.to(DEV).view(S, T, 3 * H * D).clone().requires_grad_(True)
+        ss = torch.tensor(starts, dtype=torch.int32, device=DEV)
+        sl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+        out = K().attention(qg * 1, ident_cos, ident_sin, ss, sl, H, D)
+        out.backward(dout.to(DEV).view(S, T, H * D))
+        r = qkv.float().requires_grad_(True)
+        ref = _attn_ref(r, starts, lens)
+        ref.backward(dout.float())
+        o = out.view(S, T, H, D).cpu().float()
+        # padded rows are exactly zero (pad_input)
+        for s in range(S):
+            assert float(o[s, :starts[s]].abs().sum()) == 0 and float(o[s, starts[s] + lens[s]:].abs().sum()) == 0
+        assert rel_err(o, ref) < 1e-2, "fwd"
+        assert float((o - ref.detach()).abs().max()) < 3e-2
+        dq = qg.grad.view(S, T, 3, H, D).cpu().float()
+        names = "dq dk dv".split()
+        for i in range(3):
+            assert rel_err(dq[:, :, i], r.grad[:, :, i]) < 2e-2, names[i]
+    finally:
+        os.environ["HALVA_SDPA_SLOW_TR"] = "0"
+
+
+def test_sdpa_full_clip_shape():
+    N, S, H, D = 2, 577, 16, 64
+    g = torch.Generator().manual_seed(4)
+    qkv = bf(torch.randn(N, S, 3, H, D, generator=g))
+    out = K().sdpa_full(qkv.to(DEV).view(N, S, 3 * H * D), H, D).view(N, S, H, D).cpu()
+    ref = _attn_ref(qkv, [0] * N, [S] * N, causal=False)
+    assert rel_err(out, ref) < 1e-2
+
+
+@pytest.mark.parametrize("M,N,Kd", [(100, 64, 32), (576, 4096, 1024), (300, 200, 72)])
+def test_gemm_forms(M, N, Kd):
+    g = torch.Generator().manual_seed(5)
+    A = bf(torch.randn(M, Kd, generator=g))
+    B = bf(torch.randn(N, Kd, generator=g))
+    bias = bf(torch.randn(N, generator=g))
+    k = K()
+    ref = A.float() @ B.float().T + bias.float()
+    out = k.gemm(A.to(DEV), B.to(DEV), bias.to(DEV))
+    assert rel_err(out, ref) < 6e-3
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    out = k.gemm(A.to(DEV), B.to(DEV), bias.to(DEV), epilogue=1, pre_act=pre)
+    assert rel_err(pre, ref) < 6e-3
+    assert rel_err(out, F.gelu(ref.bfloat16().float())) < 8e-3
+    if N % 8 == 0 and M % 8 == 0:
+        Bt = B.T.contiguous()                                   # [K, N]
+        out = k.gemm(A.to(DEV), Bt.to(DEV), trans_b=True)
+        assert rel_err(out, A.float() @ B.float().T) < 6e-3
+        At = A.T.contiguous()                                   # [K, M]
+        out = k.gemm(At.to(DEV), Bt.to(DEV), trans_a=True, trans_b=True, out_dtype=torch.float32)
+        assert rel_err(out, A.float() @ B.float().T) < 1e-3
+        acc = torch.ones(M, N, dtype=torch.float32, device=DEV)
+        k.gemm(At.to(DEV), Bt.to(DEV), trans_a=True, trans_b=True, out=acc, accumulate=True)
+        assert rel_err(acc, A.float() @ B.float().T + 1) < 1e-3
+
+
+def test_projector_fwd_bwd():
+    M, dv, d = 576 * 2, 1024, 512
+    g = torch.Generator().manual_seed(6)
+    x = bf(torch.randn(2, 576, dv, generator=g))
+    W = {"model.mm_projector.0.weight": bf(torch.randn(d, dv, generator=g) * 0.03),
+         "model.mm_projector.0.bias": bf(torch.randn(d, generator=g) * 0.1),
+         "model.mm_projector.2.weight": bf(torch.randn(d, d, generator=g) * 0.05),
+         "model.mm_projector.2.bias": bf(torch.randn(d, generator=g) * 0.1)}
+    dy = bf(torch.randn(2, 576, d, generator=g))
+    dev = {k: v.to(DEV).requires_grad_(True) for k, v in W.items()}
+    y = K().projector_mlp(x.to(DEV), dev["model.mm_projector.0.weight"], dev["model.mm_projector.0.bias"],
+                          dev["model.mm_projector.2.weight"], dev["model.mm_projector.2.bias"])
+    y.backward(dy.to(DEV))
+    Wf = {k: v.float().requires_grad_(True) for k, v in W.items()}
+    ref = nets.projector(x.float(), Wf)
+    ref.backward(dy.float())
+    assert rel_err(y, ref) < 8e-3
+    for k_ in W:
+        assert rel_err(dev[k_].grad, Wf[k_].grad) < 1.5e-2, k_
+
+
+def test_clip_patch_embed():
+    n, hw, p, d = 3, 336, 14, 256
+    g = torch.Generator().manual_seed(7)
+    img = bf(torch.randn(n, 3, hw, hw, generator=g))
+    w = bf(torch.randn(d, 3, p, p, generator=g) * 0.05)
+    Kp = (3 * p * p + 7) // 8 * 8
+    wkp = torch.zeros(d, Kp, dtype=torch.bfloat16)
+    wkp[:, :3 * p * p] = w.reshape(d, -1)
+    out = K().clip_patch_embed(img.to(DEV), wkp.to(DEV), p, d)
+    ref = F.conv2d(img.float(), w.float(), stride=p).flatten(2).transpose(1, 2)
+    assert rel_err(out, ref) < 6e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_token_logp_and_golden(dtype):
+    z = load_npz("loss_small.npz")
+    logits = torch.from_numpy(z["logits"])
+    labels = torch.from_numpy(z["labels"])
+    S, T, V = logits.shape
+    tgt = labels[:, 1:].clone()
+    tgt[tgt == -100] = 0
+    lg = logits[:, :-1].reshape(-1, V).to(dtype).contiguous()
+    got = K().token_logp(lg.to(DEV), tgt.reshape(-1).int().to(DEV)).view(S, T - 1).cpu()
+    tol = 1e-5 if dtype == torch.float32 else 5e-2
+    np.testing.assert_allclose(got.numpy(), z["logps"], atol=tol)
+    # big row + backward against the oracle on identical (rounded) inputs
+    g = torch.Generator().manual_seed(8)
+    R, V = 37, 32000
+    big = (torch.randn(R, V, generator=g) * 4).to(dtype)
+    t = torch.randint(0, V, (R,), generator=g)
+    gout = torch.randn(R, generator=g)
+    gout[5] = 0.0
+    bg = big.to(DEV).requires_grad_(True)
+    lp = K().token_logp(bg, t.int().to(DEV))
+    lp.backward(gout.to(DEV))
+    br = big.float().requires_grad_(True)
+    ref = torch.gather(br.log_softmax(-1), 1, t[:, None]).squeeze(1)
+    ref.backward(gout)
+    np.testing.assert_allclose(lp.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-5)
+    assert rel_err(bg.grad, br.grad) < (1e-5 if dtype == torch.float32 else 4e-3)
+    assert float(bg.grad[5].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_kl_rows(dtype):
+    g = torch.Generator().manual_seed(9)
+    R, V = 29, 32000
+    pol = (torch.randn(R, V, generator=g) * 3).to(dtype)
+    ref = (pol.float() + 0.3 * torch.randn(R, V, generator=g)).to(dtype)
+    w = torch.ones(R)
+    w[3] = 0
+    w[17] = 0
+    pg = pol.to(DEV).requires_grad_(True)
+    kl = K().kl_rows(pg, ref.to(DEV), w.to(DEV))
+    kl.sum().backward()
+    pr = pol.float().requires_grad_(True)
+    labels = torch.where(w > 0, torch.ones(R, dtype=torch.long), torch.full((R,), -100))
+    kl_ref = dpa.kl_to_reference(pr[None], ref.float()[None], labels[None])       # sum / 1
+    kl_ref.backward()
+    assert abs(float(kl.sum()) - float(kl_ref)) < 2e-4 * max(1.0, abs(float(kl_ref)))
+    assert rel_err(pg.grad, pr.grad) < (1e-5 if dtype == torch.float32 else 6e-3)
+    same = K().kl_rows(pol.to(DEV), pol.to(DEV).clone(), None)
+    assert float(same.abs().max()) < 1e-5                    # identical models -> exactly ~0
+
+
+def test_phrase_sum_golden_and_grad():
+    z = load_npz("loss_small.npz")
+    logps = torch.from_numpy(z["logps"])
+    signs = torch.from_numpy(z["signs"])
+    labels = torch.zeros_like(signs)                          # all valid: the golden was made without the mask multiply
+    slots = torch.unique(signs)[1:]
+    lp = logps.to(DEV).requires_grad_(True)
+    acc = K().phrase_sum(lp, labels.to(DEV), signs.to(DEV), slots.to(DEV))
+    np.testing.assert_allclose(acc.detach().cpu().numpy(), z["acc"], atol=1e-5)
+    gacc = torch.randn(acc.shape)
+    acc.backward(gacc.to(DEV))
+    lr = logps.clone().requires_grad_(True)
+    dpa.accumulate_logps(lr, signs).backward(gacc)
+    np.testing.assert_allclose(lp.grad.cpu().numpy(), lr.grad.numpy(), atol=1e-6)
+    # mask multiply + IGNORE_INDEX signs (halva_trainer.py:556-560)
+    labels2 = labels.clone()
+    labels2[0, 4] = -100
+    signs2 = signs.clone()
+    signs2[1, 0] = -100
+    acc2 = K().phrase_sum(logps.to(DEV), labels2.to(DEV), signs2.to(DEV), slots.to(DEV)).cpu()
+    ref2 = dpa.accumulate_logps(logps * (labels2 != -100).float(), signs2.masked_fill(signs2 == -100, 0))
+    np.testing.assert_allclose(acc2.numpy(), ref2.numpy(), atol=1e-5)
+
+
+def test_splice_rows_against_golden():
+    from halva_amd import splice as sp
+    z = load_npz("splice.npz")
+    for ci, m in enumerate(meta_of(z)):
+        p = "s%d_" % ci
+        plan = sp.plan_splice(torch.from_numpy(z[p + "ids"]), torch.from_numpy(z[p + "mask"]), torch.from_numpy(z[p + "labels"]),
+                              torch.from_numpy(z[p + "signs"]), n_patch=z[p + "features"].shape[1], max_len=m["max_len"],
+                              padding_side=m["padding_side"])
+        np.testing.assert_array_equal(plan.labels.numpy(), z[p + "out_labels"])
+        np.testing.assert_array_equal(plan.signs.numpy(), z[p + "out_signs"])
+        np.testing.assert_array_equal(plan.mask.numpy(), z[p + "out_mask"])
+        emb = bf(torch.from_numpy(z[p + "embed_tokens"]))
+        feats = bf(torch.from_numpy(z[p + "features"]))
+        out = K().splice_rows(emb.to(DEV), feats.to(DEV), plan.src.to(DEV), plan.S, plan.T).cpu()
+        ref, _, _, _ = host.splice(z[p + "ids"], z[p + "mask"], z[p + "labels"], z[p + "signs"], feats.float().numpy(),
+                                   emb.float().numpy(), m["max_len"], m["padding_side"])
+        assert torch.equal(out.float(), torch.from_numpy(ref))          # pure row copies: bit exact
