@@ -1,0 +1,394 @@
+"""The DPA loss and step engine (product code).
+
+Restructures reference llava/train/halva_trainer.py:421-592 (concatenated_forward / reference_forward / compute_loss)
+for one MI355X without changing its arithmetic:
+
+  * the loss decomposes exactly over pairs: alignment = sum_b sum_p softplus(neg_acc[b,p] - pos_acc[b,p]) / (B*P) and
+    divergence = sum_b KL_b / B, where the only cross-sample coupling - the batch-global phrase slots (torch.unique over
+    the half batch, halva_trainer.py:412) and the divisors - depends on integer inputs alone and is computed on the host
+    before any forward.  The engine therefore runs forward + backward per GROUP of pairs (then per group of reference
+    rows): activations of one group live at a time, no recomputation (the reference re-runs every layer under gradient
+    checkpointing), gradients accumulate in the flat fp32 buffer;
+  * pos/neg rows of a pair share one CLIP encode (the reference encodes the same image twice, halva_trainer.py:464);
+  * the [rows, 32000] logits never reach HBM as fp32: lm_head is applied chunk-wise to the response rows only (rows whose
+    shifted label is IGNORE_INDEX are multiplied by 0 in the reference, halva_trainer.py:556-557) and each bf16 chunk is
+    consumed in place by the token-logp / KL kernels, which also emit the gradient w.r.t. the hidden state.
+"""
+import math
+import warnings
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from . import splice as SP
+from .hip import BF16, call, ptr, stream_ptr
+
+IGNORE_INDEX = -100
+LOGIT_CHUNK_ROWS = 8192            # 8192 x 32000 bf16 = 0.5 GB of transient logits
+
+
+class _LmHeadLogp(torch.autograd.Function):
+    """log p(target) for rows of hidden states: lm_head (modelling_llama.py:801-806) fused chunk-wise with
+    log_softmax + gather (halva_trainer.py:406-407).  Backward recomputes the chunk's logits (1 extra lm_head GEMM,
+    2 % of a sequence forward) and turns them in place into dlogits, then dh = dlogits @ W."""
+
+    @staticmethod
+    def forward(ctx, h, W, target):
+        R = h.shape[0]
+        V = W.shape[0]
+        logp = torch.empty(R, dtype=torch.float32, device=h.device)
+        lse = torch.empty(R, dtype=torch.float32, device=h.device)
+        st = stream_ptr()
+        for c0 in range(0, R, LOGIT_CHUNK_ROWS):
+            c1 = min(R, c0 + LOGIT_CHUNK_ROWS)
+            logits = torch.mm(h[c0:c1], W.t())
+            call("halva_token_logp_fwd", ptr(logits), BF16, V, ptr(target[c0:c1]), ptr(logp[c0:c1]), ptr(lse[c0:c1]), c1 - c0, V, st)
+        ctx.save_for_backward(h, target, lse)
+        ctx.W = W
+        return logp
+
+    @staticmethod
+    def backward(ctx, g):
+        h, target, lse = ctx.saved_tensors
+        W = ctx.W
+        V = W.shape[0]
+        g = g.contiguous().float()
+        dh = torch.empty_like(h)
+        st = stream_ptr()
+        for c0 in range(0, h.shape[0], LOGIT_CHUNK_ROWS):
+            c1 = min(h.shape[0], c0 + LOGIT_CHUNK_ROWS)
+            logits = torch.mm(h[c0:c1], W.t())
+            call("halva_token_logp_bwd", ptr(logits), BF16, V, ptr(target[c0:c1]), ptr(lse[c0:c1]), ptr(g[c0:c1]), ptr(logits),
+                 c1 - c0, V, st)
+            torch.mm(logits, W, out=dh[c0:c1])
+        return dh, None, None
+
+
+class _LmHeadKL(torch.autograd.Function):
+    """sum_rows KL(ref || policy) with both lm_heads fused (halva_trainer.py:583-588 before the /B).  The output is a
+    scalar, so d/dh_pol is produced in the forward pass (one launch per chunk yields kl and p_pol - p_ref in place)."""
+
+    @staticmethod
+    def forward(ctx, h_pol, h_ref, W_pol, W_ref):
+        R = h_pol.shape[0]
+        V = W_pol.shape[0]
+        kl = torch.empty(R, dtype=torch.float32, device=h_pol.device)
+        need = h_pol.requires_grad
+        dh = torch.empty_like(h_pol) if need else None
+        st = stream_ptr()
+        for c0 in range(0, R, LOGIT_CHUNK_ROWS):
+            c1 = min(R, c0 + LOGIT_CHUNK_ROWS)
+            lp = torch.mm(h_pol[c0:c1], W_pol.t())
+            lr = torch.mm(h_ref[c0:c1], W_ref.t())
+            call("halva_kl_rows", ptr(lp), ptr(lr), BF16, V, None, ptr(kl[c0:c1]), ptr(lp) if need else None, 1.0, c1 - c0, V, st)
+            if need:
+                torch.mm(lp, W_pol, out=dh[c0:c1])
+        ctx.save_for_backward(dh)
+        return kl.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dh,) = ctx.saved_tensors
+        return dh * g.to(dh.dtype), None, None, None
+
+
+def lm_head_logp(h_rows, lm_weight, target_i32):
+    return _LmHeadLogp.apply(h_rows.contiguous(), lm_weight, target_i32)
+
+
+def lm_head_kl(h_pol_rows, h_ref_rows, w_pol, w_ref):
+    return _LmHeadKL.apply(h_pol_rows.contiguous(), h_ref_rows.contiguous(), w_pol, w_ref)
+
+
+# ------------------------------------------------------------------------------------------------
+# host-side batch bookkeeping
+# ------------------------------------------------------------------------------------------------
+def concat_pos_neg(batch):
+    """halva_trainer.py:434-447 on host tensors: rows 0..B-1 = pos, B..2B-1 = neg; ids 0-filled, labels -100, signs 0."""
+    ids, neg = _np(batch["input_ids"]), _np(batch["neg_input_ids"])
+    B = ids.shape[0]
+    W = max(ids.shape[1], neg.shape[1])
+    c_ids = np.zeros((2 * B, W), dtype=np.int64)
+    c_lab = np.full((2 * B, W), IGNORE_INDEX, dtype=np.int64)
+    c_att = np.zeros((2 * B, W), dtype=bool)
+    c_sig = np.zeros((2 * B, W), dtype=np.int64)
+    for off, (i, l, a, s) in ((0, ("input_ids", "labels", "attention_mask", "pos_signs")),
+                              (B, ("neg_input_ids", "neg_labels", "neg_attention_mask", "neg_signs"))):
+        w = _np(batch[i]).shape[1]
+        c_ids[off:off + B, :w] = _np(batch[i])
+        c_lab[off:off + B, :w] = _np(batch[l])
+        c_att[off:off + B, :w] = _np(batch[a])
+        c_sig[off:off + B, :w] = _np(batch[s])
+    return c_ids, c_lab, c_att, c_sig
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def phrase_slots(signs_shifted_half):
+    """Slots of accumulate_logps (halva_trainer.py:412-415): sorted unique ids of the half batch minus the first one."""
+    s = np.where(signs_shifted_half == IGNORE_INDEX, 0, signs_shifted_half)
+    return np.unique(s)[1:].astype(np.int64)
+
+
+class DPAStepPlan:
+    """Everything about one micro-batch that is decidable from its integer tensors (host only)."""
+
+    def __init__(self, batch, n_patch, max_len, padding_side="right"):
+        c_ids, c_lab, c_att, c_sig = concat_pos_neg(batch)
+        self.B = c_ids.shape[0] // 2
+        self.cat = (c_ids, c_lab, c_att, c_sig)
+        self.n_patch, self.max_len, self.side = n_patch, max_len, padding_side
+        B = self.B
+        full = SP.plan_splice(c_ids, c_att, c_lab, c_sig, n_patch, max_len, padding_side,
+                              image_map=list(range(B)) + list(range(B)))
+        sg = full.signs.numpy()[:, 1:]
+        self.pos_slots = phrase_slots(sg[:B])
+        self.neg_slots = phrase_slots(sg[B:])
+        if len(self.pos_slots) != len(self.neg_slots):
+            # the reference fails on `neg_logps_acc - pos_logps_acc` (halva_trainer.py:567) with a broadcast error
+            raise RuntimeError("pos/neg halves have different numbers of phrase slots (%d vs %d): "
+                               "The size of tensor a must match the size of tensor b" % (len(self.pos_slots), len(self.neg_slots)))
+        self.P = len(self.pos_slots)
+        self.T_full = full.T
+        self.ref = tuple(_np(batch[k]) for k in ("ref_input_ids", "ref_labels", "ref_attention_mask"))
+
+    def pair_group(self, idx):
+        """Splice plan of the 2*len(idx) rows [pos(idx) ; neg(idx)]; both rows of a pair read image slot of the pair."""
+        c_ids, c_lab, c_att, c_sig = self.cat
+        rows = list(idx) + [self.B + b for b in idx]
+        g = len(idx)
+        return SP.plan_splice(c_ids[rows], c_att[rows], c_lab[rows], c_sig[rows], self.n_patch, self.max_len, self.side,
+                              image_map=list(range(g)) + list(range(g)))
+
+    def ref_group(self, idx):
+        ids, lab, att = self.ref
+        idx = list(idx)
+        return SP.plan_splice(ids[idx], att[idx], lab[idx], None, self.n_patch, self.max_len, self.side)
+
+
+def _kept_rows(labels):
+    """Rows (flattened [S, T-1] index into the [S, T] hidden states) whose shifted label is a real token."""
+    lab = labels.numpy()
+    S, T = lab.shape
+    tgt = lab[:, 1:]
+    s_idx, t_idx = np.nonzero(tgt != IGNORE_INDEX)
+    hid = torch.from_numpy((s_idx * T + t_idx).astype(np.int64))            # position t predicts label t+1
+    dense = torch.from_numpy((s_idx * (T - 1) + t_idx).astype(np.int64))
+    target = torch.from_numpy(tgt[s_idx, t_idx].astype(np.int32))
+    return hid, dense, target
+
+
+class DPAEngine:
+    """Forward/backward of the DPA loss on one GPU.  `policy` / `ref_model` are LlavaLlamaForCausalLM instances."""
+
+    def __init__(self, policy, ref_model, loss_alpha, pairs_per_group=4, ref_rows_per_group=8):
+        self.policy, self.ref_model, self.alpha = policy, ref_model, float(loss_alpha)
+        self.pairs_per_group, self.ref_rows_per_group = pairs_per_group, ref_rows_per_group
+
+    # -- pieces ------------------------------------------------------------------------------------
+    def _images(self, batch, key, idx, dev):
+        im = batch[key]
+        if isinstance(im, (list, tuple)):
+            im = torch.stack([im[i] for i in idx])
+        else:
+            im = im[list(idx)]
+        return im.to(dev, torch.bfloat16, non_blocking=True)
+
+    def _hidden(self, model, plan, feats):
+        m = model.get_model()
+        dev = m.embed_tokens.weight.device
+        embeds = K.splice_rows(m.embed_tokens.weight, feats, plan.src.to(dev, non_blocking=True), plan.S, plan.T)
+        return model.hidden_states(embeds, None, plan.seq_start, plan.seq_len)
+
+    def pair_group_loss(self, batch, plan, idx):
+        """Contribution of the pairs `idx` to the alignment loss (already divided by B*P)."""
+        pol = self.policy
+        dev = pol.device
+        gp = plan.pair_group(idx)
+        g = len(idx)
+        feats = pol.encode_images(self._images(batch, "images", idx, dev))               # [g, n_patch, d]; grads -> projector
+        h = self._hidden(pol, gp, feats)
+        hid, dense, target = _kept_rows(gp.labels)
+        T1 = gp.T - 1
+        logp_dense = torch.zeros(2 * g * T1, dtype=torch.float32, device=dev)
+        if hid.numel():
+            rows = h.view(-1, h.shape[-1]).index_select(0, hid.to(dev, non_blocking=True))
+            lp = lm_head_logp(rows, pol.lm_head.weight, target.to(dev, non_blocking=True))
+            logp_dense = logp_dense.index_copy(0, dense.to(dev, non_blocking=True), lp)
+        logp_dense = logp_dense.view(2 * g, T1)
+        lab = gp.labels[:, 1:].contiguous().to(dev, non_blocking=True)
+        sgn = gp.signs[:, 1:].contiguous().to(dev, non_blocking=True)
+        if plan.P == 0:
+            warnings.warn("no phrase slots in this batch: the reference's alignment loss is mean(empty) = NaN")
+            return logp_dense.sum() * float("nan"), logp_dense, gp
+        pos_acc = K.phrase_sum(logp_dense[:g].contiguous(), lab[:g].contiguous(), sgn[:g].contiguous(),
+                               torch.from_numpy(plan.pos_slots).to(dev))
+        neg_acc = K.phrase_sum(logp_dense[g:].contiguous(), lab[g:].contiguous(), sgn[g:].contiguous(),
+                               torch.from_numpy(plan.neg_slots).to(dev))
+        contrib = torch.log(1 + torch.exp(neg_acc - pos_acc)).sum() / (plan.B * plan.P)        # halva_trainer.py:567-568
+        return contrib, (logp_dense, pos_acc, neg_acc), gp
+
+    def ref_group_loss(self, batch, plan, idx):
+        """Contribution of reference rows `idx` to loss_alpha * divergence (KL summed over tokens and vocab, / B)."""
+        pol, ref = self.policy, self.ref_model
+        dev = pol.device
+        gp = plan.ref_group(idx)
+        images = self._images(batch, "ref_images", idx, dev)
+        h_pol = self._hidden(pol, gp, pol.encode_images(images))
+        with torch.no_grad():
+            h_ref = self._hidden(ref, gp, ref.encode_images(images))
+        hid, _, _ = _kept_rows(gp.labels)
+        if hid.numel() == 0:
+            return h_pol.sum() * 0.0, gp
+        sel = hid.to(dev, non_blocking=True)
+        d = h_pol.shape[-1]
+        kl = lm_head_kl(h_pol.view(-1, d).index_select(0, sel), h_ref.view(-1, d).index_select(0, sel), pol.lm_head.weight,
+                        ref.lm_head.weight)
+        return self.alpha * kl / plan.B, gp
+
+    # -- whole micro-batch -------------------------------------------------------------------------
+    def make_plan(self, batch):
+        pol = self.policy
+        vt = pol.get_vision_tower()
+        return DPAStepPlan(batch, vt.num_patches, getattr(pol.config, "tokenizer_model_max_length", None),
+                           getattr(pol.config, "tokenizer_padding_side", "right"))
+
+    def _groups(self, n, per):
+        return [list(range(i, min(n, i + per))) for i in range(0, n, per)]
+
+    def loss(self, batch, backward=False, scale=1.0):
+        """compute_loss of the reference (halva_trainer.py:534-592).  backward=True runs loss.backward() group by group
+        (gradients accumulate; activations of one group alive at a time) and returns the detached loss value."""
+        plan = self.make_plan(batch)
+        total = None
+        parts = {"alignment": None, "divergence": None}
+        for idx in self._groups(plan.B, self.pairs_per_group):
+            c, _, _ = self.pair_group_loss(batch, plan, idx)
+            if backward:
+                (c * scale).backward()
+                c = c.detach()
+            parts["alignment"] = c if parts["alignment"] is None else parts["alignment"] + c
+        for idx in self._groups(plan.B, self.ref_rows_per_group):
+            c, _ = self.ref_group_loss(batch, plan, idx)
+            if backward:
+                (c * scale).backward()
+                c = c.detach()
+            parts["divergence"] = c if parts["divergence"] is None else parts["divergence"] + c
+        total = parts["alignment"] + parts["divergence"]
+        self.last_parts = {"alignment": parts["alignment"].detach(),
+                           "divergence": (parts["divergence"].detach() / self.alpha) if self.alpha else parts["divergence"].detach()}
+        return total
+
+
+# ------------------------------------------------------------------------------------------------
+# trainable parameters as one flat buffer: bf16 compute copy, fp32 master, fp32 gradient accumulator
+# ------------------------------------------------------------------------------------------------
+class FlatTrainables:
+    """DeepSpeed-bf16 numerics without DeepSpeed: bf16 parameters used in compute, fp32 master weights and fp32 Adam
+    moments (reference --bf16 True + ZeRO), and an fp32 gradient accumulator that the kernels' backward
+    adds into directly.  The accumulator is THE buffer all-reduced across ranks (halva_amd/dp.py)."""
+
+    def __init__(self, named_params):
+        named_params = [(n, p) for n, p in named_params if p.requires_grad]
+        if not named_params:
+            raise ValueError("no trainable parameters")
+        dev = named_params[0][1].device
+        self.names = [n for n, _ in named_params]
+        self.params = [p for _, p in named_params]
+        sizes = [p.numel() for p in self.params]
+        self.offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        total = int(self.offsets[-1])
+        self.flat = torch.empty(total, dtype=torch.bfloat16, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, o, n in zip(self.params, self.offsets[:-1], sizes):
+            self.flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + n].view_as(p)
+            p.main_grad = self.grad[o:o + n].view_as(p)
+            p.grad_sink = True
+        self.master = self.flat.float()
+        self.total = total
+
+    def segment(self, pred):
+        """Contiguous [lo, hi) covering the parameters whose name satisfies pred (they must be adjacent)."""
+        idx = [i for i, n in enumerate(self.names) if pred(n)]
+        if not idx:
+            return None
+        assert idx == list(range(idx[0], idx[-1] + 1)), "segment parameters must be adjacent in the flat buffer"
+        return int(self.offsets[idx[0]]), int(self.offsets[idx[-1] + 1])
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def sync_compute_copy(self):
+        self.flat.copy_(self.master)
+
+
+def set_grad_sink(model, on=True):
+    """Route LoRA gradients into `.main_grad` (True) or return them through autograd (False)."""
+    for layer in model.get_model().layers:
+        if hasattr(layer, "groups"):
+            for _, grp in layer.groups():
+                grp.grad_sink = on
+    proj = getattr(model.get_model(), "mm_projector", None)
+    if proj is not None:
+        for p in proj.parameters():
+            p.grad_sink = on
+
+
+def trainable_named_parameters(model):
+    """Trainable tensors in flat-buffer order: LoRA factors, then projector weights, then projector biases."""
+    from .llama import lora_named_parameters
+    out = list(lora_named_parameters(model))
+    proj = getattr(model.get_model(), "mm_projector", None)
+    if proj is not None:
+        named = [("model.mm_projector." + n, p) for n, p in proj.named_parameters() if p.requires_grad]
+        out += [x for x in named if "bias" not in x[0]] + [x for x in named if "bias" in x[0]]
+    return out
+
+
+class AdamWFlat:
+    """torch.optim.AdamW (reference optim="adamw_torch", llava/train/train_halva.py:70) on the fp32 master slices,
+    with the reference's parameter groups: {decay, no-decay} x {projector (lr = mm_projector_lr), rest}
+    (halva_trainer.py:291-337).  "decay" = not a bias (no LayerNorm weight is trainable on this path)."""
+
+    def __init__(self, flat, lr, weight_decay=0.0, mm_projector_lr=None, betas=(0.9, 0.999), eps=1e-8):
+        self.flat = flat
+        groups = []
+        segs = [("lora", lambda n: "mm_projector" not in n, lr, weight_decay),
+                ("proj_w", lambda n: "mm_projector" in n and "bias" not in n, lr if mm_projector_lr is None else mm_projector_lr,
+                 weight_decay),
+                ("proj_b", lambda n: "mm_projector" in n and "bias" in n, lr if mm_projector_lr is None else mm_projector_lr, 0.0)]
+        self._views = []
+        for name, pred, g_lr, wd in segs:
+            s = flat.segment(pred)
+            if s is None:
+                continue
+            p = torch.nn.Parameter(flat.master[s[0]:s[1]])
+            p.grad = flat.grad[s[0]:s[1]]
+            groups.append({"params": [p], "lr": g_lr, "weight_decay": wd, "name": name})
+        self.opt = torch.optim.AdamW(groups, lr=lr, betas=betas, eps=eps)
+        for g in self.opt.param_groups:
+            g["initial_lr"] = g["lr"]
+
+    def set_lr_factor(self, f):
+        for g in self.opt.param_groups:
+            g["lr"] = g["initial_lr"] * f
+
+    def step(self):
+        self.opt.step()
+        self.flat.sync_compute_copy()
+
+    def state_dict(self):
+        return self.opt.state_dict()
+
+
+def cosine_with_warmup(step, total_steps, warmup_ratio):
+    """HF get_cosine_schedule_with_warmup with num_warmup_steps = ceil(warmup_ratio * total_steps)."""
+    warm = math.ceil(warmup_ratio * total_steps)
+    if step < warm:
+        return float(step) / float(max(1, warm))
+    prog = float(step - warm) / float(max(1, total_steps - warm))
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))

@@ -65,42 +65,64 @@ def _rope_inplace(qkv, cos, sin, T, H, D, inverse):
     call("halva_rope_qk", ptr(qkv), ptr(cos), ptr(sin), None, rows, T, H, D, cos.shape[0], int(inverse), stream_ptr())
 
 
-class _Attention(torch.autograd.Function):
-    """RoPE + causal varlen attention on a packed qkv buffer: apply_rotary_pos_emb (modelling_llama.py:154-169) +
-    flash_attn_varlen_qkvpacked_func(causal=True) + pad_input (llama_flash_attn_monkey_patch.py:51-91).
-
-    qkv: [S, T, 3*H*D] bf16 (fresh GEMM output; rotated IN PLACE).  Returns [S, T, H*D]."""
+class _RopeQK(torch.autograd.Function):
+    """apply_rotary_pos_emb (modelling_llama.py:154-169) in place on the q,k thirds of a packed qkv buffer.
+    Its transpose is applied by _SdpaCausal.backward on the freshly written dqkv (same launch sequence, no extra
+    buffer), so this node's backward is the identity."""
 
     @staticmethod
-    def forward(ctx, qkv, cos, sin, seq_start, seq_len, H, D):
+    def forward(ctx, qkv, cos, sin, H, D):
+        _chk(qkv, torch.bfloat16, "qkv")
+        _rope_inplace(qkv, cos, sin, qkv.shape[1], H, D, False)
+        ctx.mark_dirty(qkv)
+        return qkv
+
+    @staticmethod
+    def backward(ctx, dqkv):
+        return dqkv, None, None, None, None
+
+
+class _SdpaCausal(torch.autograd.Function):
+    """flash_attn_varlen_qkvpacked_func(causal=True) + unpad/pad_input (llama_flash_attn_monkey_patch.py:71-91).
+    qkv: [S, T, 3*H*D] bf16 (already rotated).  Returns [S, T, H*D].  If cos/sin are given the backward also applies
+    the inverse rotation to dq, dk (see _RopeQK)."""
+
+    @staticmethod
+    def forward(ctx, qkv, seq_start, seq_len, H, D, cos, sin):
         _chk(qkv, torch.bfloat16, "qkv")
         S, T = qkv.shape[0], qkv.shape[1]
-        _rope_inplace(qkv, cos, sin, T, H, D, False)
         out = torch.empty(S, T, H * D, dtype=torch.bfloat16, device=qkv.device)
         lse = torch.empty(S, H, T, dtype=torch.float32, device=qkv.device)
         call("halva_sdpa_causal_fwd", ptr(qkv), ptr(out), ptr(lse), ptr(seq_start), ptr(seq_len), S, T, H, D, 0.0,
              stream_ptr())
-        ctx.mark_dirty(qkv)
-        ctx.save_for_backward(qkv, out, lse, cos, sin, seq_start, seq_len)
+        ctx.save_for_backward(qkv, out, lse, seq_start, seq_len)
+        ctx.rope = (cos, sin)
         ctx.dims = (S, T, H, D)
-        return out, qkv
+        return out
 
     @staticmethod
-    def backward(ctx, dout, _dqkv_unused):
-        qkv, out, lse, cos, sin, seq_start, seq_len = ctx.saved_tensors
+    def backward(ctx, dout):
+        qkv, out, lse, seq_start, seq_len = ctx.saved_tensors
         S, T, H, D = ctx.dims
         dout = _chk(dout.contiguous(), torch.bfloat16, "dout")
         dqkv = torch.empty_like(qkv)
         delta = torch.empty(S, H, T, dtype=torch.float32, device=qkv.device)
         call("halva_sdpa_causal_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), None, ptr(seq_start),
              ptr(seq_len), S, T, H, D, 0.0, stream_ptr())
-        _rope_inplace(dqkv, cos, sin, T, H, D, True)
+        cos, sin = ctx.rope
+        if cos is not None:
+            _rope_inplace(dqkv, cos, sin, T, H, D, True)
         return dqkv, None, None, None, None, None, None
 
 
 def attention(qkv, cos, sin, seq_start, seq_len, H, D):
-    out, _ = _Attention.apply(qkv, cos, sin, seq_start, seq_len, H, D)
-    return out
+    """RoPE (in place) + causal attention on a packed [S, T, 3*H*D] projection output."""
+    qkv = _RopeQK.apply(qkv, cos, sin, H, D)
+    return _SdpaCausal.apply(qkv, seq_start, seq_len, H, D, cos, sin)
+
+
+def sdpa_causal(qkv, seq_start, seq_len, H, D):
+    return _SdpaCausal.apply(qkv, seq_start, seq_len, H, D, None, None)
 
 
 def sdpa_full(qkv, H, D):
@@ -195,12 +217,14 @@ class _ProjectorMLP(torch.autograd.Function):
         h_pre = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.bfloat16, device=x.device)
         g = gemm(x2, w1, b1, epilogue=1, pre_act=h_pre)
         y = gemm(g, w2, b2)
-        ctx.save_for_backward(x2, w1, w2, h_pre, g)
+        ctx.save_for_backward(x2, h_pre, g)
+        ctx.params = (w1, b1, w2, b2)
         return y.view(*x.shape[:-1], w2.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w1, w2, h_pre, g = ctx.saved_tensors
+        x2, h_pre, g = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.params
         dy2 = _chk(dy.reshape(-1, dy.shape[-1]).contiguous(), torch.bfloat16, "dy")
         M = dy2.shape[0]
         st = stream_ptr()
@@ -213,7 +237,14 @@ class _ProjectorMLP(torch.autograd.Function):
         dw1 = gemm(dh, x2, trans_a=True, trans_b=True, out_dtype=torch.float32)
         db1 = torch.zeros(w1.shape[0], dtype=torch.float32, device=dy.device)
         call("halva_colsum", ptr(dh), ptr(db1), M, w1.shape[0], st)
-        return None, dw1.to(w1.dtype), db1.to(w1.dtype), dw2.to(w2.dtype), db2.to(w2.dtype)
+        grads = []
+        for prm, gr in ((w1, dw1), (b1, db1), (w2, dw2), (b2, db2)):
+            if getattr(prm, "main_grad", None) is not None and getattr(prm, "grad_sink", False):
+                prm.main_grad.add_(gr)             # fp32 accumulation straight into the flat DP/optimizer buffer
+                grads.append(None)
+            else:
+                grads.append(gr.to(prm.dtype))
+        return (None, *grads)
 
 
 def projector_mlp(x, w1, b1, w2, b2):

@@ -78,10 +78,12 @@ class _LoraGroupFn(torch.autograd.Function):
         d_in = x.shape[-1]
         x2 = x.reshape(-1, d_in)
         N = W.shape[0]
+        out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)   # returned as-is (not a view): later
+        y = out.view(-1, N)                                                     # in-place kernels (RoPE) may dirty it
         if residual is None:
-            y = torch.mm(x2, W.t())
+            torch.mm(x2, W.t(), out=y)
         else:
-            y = torch.addmm(residual.reshape(-1, N), x2, W.t())
+            torch.addmm(residual.reshape(-1, N), x2, W.t(), out=y)
         a = None
         if A is not None:
             r = A.shape[0] // len(Bs)
@@ -91,14 +93,16 @@ class _LoraGroupFn(torch.autograd.Function):
                 n = B.shape[0]
                 y[:, off:off + n].addmm_(a[:, g * r:(g + 1) * r], B.t(), alpha=scale)
                 off += n
-        ctx.save_for_backward(x2, a, W, A, *Bs)
+        ctx.save_for_backward(x2, a)
+        ctx.params = (W, A, Bs)            # long-lived parameters: kept as objects so `.main_grad` stays reachable
         ctx.scale, ctx.sink, ctx.has_res = scale, sink, residual is not None
         ctx.x_shape = x.shape
-        return y.view(*x.shape[:-1], N)
+        return out
 
     @staticmethod
     def backward(ctx, dy):
-        x2, a, W, A, *Bs = ctx.saved_tensors
+        x2, a = ctx.saved_tensors
+        W, A, Bs = ctx.params
         N = W.shape[0]
         dy2 = dy.reshape(-1, N)
         dx = torch.mm(dy2, W)

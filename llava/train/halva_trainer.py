@@ -1,0 +1,332 @@
+"""HalvaTrainer - the reference's trainer surface (llava/train/halva_trainer.py:155-592) on the MI355X-native engine.
+
+What stays: class / method names and signatures, batch-dict keys, loss semantics (every quirk listed in SURVEY.md 8a),
+the length-grouped sampler, optimizer parameter groups, LR schedule and the output artefacts.
+What changes underneath: no HF Trainer / accelerate / DeepSpeed.  One process per GPU holds full bf16 replicas of policy
+and reference model; `training_step` runs the fused group-wise engine (halva_amd/dpa.py); trainable gradients live in
+one flat fp32 buffer that is all-reduced over RCCL once per optimizer step (halva_amd/dp.py).
+`compute_loss` / `concatenated_forward` / `reference_forward` / `cal_batch_logp` / `accumulate_logps` keep the
+reference's tensor-level contracts (full logits included) for callers that use them directly.
+"""
+import json
+import math
+import os
+import time
+from collections import defaultdict
+from typing import Any, Dict, List, Optional
+
+import torch
+from torch.utils.data import DataLoader, Sampler
+
+from halva_amd import dp, dpa
+from halva_amd import kernels as K
+
+IGNORE_INDEX = -100
+
+
+# ------------------------------------------------------------------------------------------------
+# sampler (reference halva_trainer.py:60-152)
+# ------------------------------------------------------------------------------------------------
+def split_to_even_chunks(indices, lengths, num_chunks):
+    """Greedy balance: each index goes to the chunk with the smallest summed length that still has room;
+    a megabatch that does not divide evenly is dealt out round-robin instead."""
+    if len(indices) % num_chunks != 0:
+        return [indices[i::num_chunks] for i in range(num_chunks)]
+    room = len(indices) // num_chunks
+    buckets = [[] for _ in range(num_chunks)]
+    weight = [0] * num_chunks
+    for idx in indices:
+        k = weight.index(min(weight))
+        buckets[k].append(idx)
+        weight[k] += lengths[idx]
+        if len(buckets[k]) == room:
+            weight[k] = float("inf")
+    return buckets
+
+
+def get_length_grouped_indices(lengths, batch_size, world_size, generator=None, merge=True):
+    order = torch.randperm(len(lengths), generator=generator).tolist()     # torch RNG: part of the contract
+    span = world_size * batch_size
+    out = []
+    for lo in range(0, len(lengths), span):
+        mega = sorted(order[lo:lo + span], key=lambda i: lengths[i], reverse=True)
+        for chunk in split_to_even_chunks(mega, lengths, world_size):
+            out.extend(chunk)
+    return out
+
+
+def get_modality_length_grouped_indices(lengths, batch_size, world_size, generator=None):
+    assert all(l != 0 for l in lengths), "Should not have zero length."
+    if all(l > 0 for l in lengths) or all(l < 0 for l in lengths):
+        return get_length_grouped_indices(lengths, batch_size, world_size, generator=generator)
+    mm = [(i, l) for i, l in enumerate(lengths) if l > 0]
+    lang = [(i, -l) for i, l in enumerate(lengths) if l < 0]
+    mm_order = [mm[i][0] for i in get_length_grouped_indices([l for _, l in mm], batch_size, world_size, generator=None)]
+    lang_order = [lang[i][0] for i in get_length_grouped_indices([l for _, l in lang], batch_size, world_size, generator=None)]
+    span = world_size * batch_size
+    mm_mega = [mm_order[i:i + span] for i in range(0, len(mm_order), span)]
+    lang_mega = [lang_order[i:i + span] for i in range(0, len(lang_order), span)]
+    leftovers = mm_mega[-1] + lang_mega[-1]
+    full = mm_mega[:-1] + lang_mega[:-1]
+    perm = torch.randperm(len(full), generator=generator).tolist()
+    full = [full[i] for i in perm]
+    if leftovers:
+        full.append(sorted(leftovers))
+    return [i for mega in full for i in mega]
+
+
+class LengthGroupedSampler(Sampler):
+    """Groups samples of similar length into the same megabatch while keeping randomness."""
+
+    def __init__(self, batch_size: int, world_size: int, lengths: Optional[List[int]] = None, generator=None,
+                 group_by_modality: bool = False):
+        if lengths is None:
+            raise ValueError("Lengths must be provided.")
+        self.batch_size, self.world_size, self.lengths = batch_size, world_size, lengths
+        self.generator, self.group_by_modality = generator, group_by_modality
+
+    def __len__(self):
+        return len(self.lengths)
+
+    def __iter__(self):
+        fn = get_modality_length_grouped_indices if self.group_by_modality else get_length_grouped_indices
+        return iter(fn(self.lengths, self.batch_size, self.world_size, generator=self.generator))
+
+
+def disable_dropout_in_model(model: torch.nn.Module) -> None:
+    for module in model.modules():
+        if isinstance(module, torch.nn.Dropout):
+            module.p = 0
+
+
+# ------------------------------------------------------------------------------------------------
+class TrainerState:
+    def __init__(self):
+        self.global_step = 0
+        self.epoch = 0.0
+        self.log_history = []
+
+
+class HalvaTrainer:
+    def __init__(self, model=None, ref_model=None, args=None, data_collator=None, label_pad_token_id: int = -100,
+                 padding_value: int = 0, is_encoder_decoder: bool = False, loss_alpha: Optional[float] = 0.1,
+                 train_dataset=None, eval_dataset=None, tokenizer=None, model_init=None, callbacks=None,
+                 optimizers=(None, None), preprocess_logits_for_metrics=None, disable_dropout: bool = True,
+                 compute_metrics=None):
+        self.model, self.ref_model, self.args = model, ref_model, args
+        if ref_model is None:
+            raise ValueError("HalvaTrainer needs a frozen ref_model (adapter-disabling is not implemented on this path)")
+        if disable_dropout:
+            disable_dropout_in_model(model)
+            disable_dropout_in_model(ref_model)
+        self.loss_alpha = loss_alpha
+        self.label_pad_token_id = label_pad_token_id
+        self.padding_value = padding_value
+        self.is_encoder_decoder = is_encoder_decoder
+        self.loss_holder = defaultdict(list)
+        self.data_collator, self.train_dataset, self.eval_dataset, self.tokenizer = data_collator, train_dataset, eval_dataset, tokenizer
+        self.callbacks = list(callbacks or [])
+        self.optimizer, self.lr_scheduler = optimizers
+        self.state = TrainerState()
+        self.ref_model.eval()
+        for p in self.ref_model.parameters():
+            p.requires_grad_(False)
+        self._engine = None
+        self._flat = None
+        self.dist = dp.DistContext.from_env()
+
+    # -- reference tensor-level API ---------------------------------------------------------------
+    def cal_batch_logp(self, logits: torch.FloatTensor, labels: torch.LongTensor) -> torch.FloatTensor:
+        """[S, T, V] logits, [S, T] labels -> [S, T-1] log p(label[t+1] | ..t); IGNORE_INDEX scored as token 0."""
+        if logits.shape[:-1] != labels.shape:
+            raise ValueError("Logits (batch and sequence length dim) and labels must have the same shape.")
+        if not self.is_encoder_decoder:
+            labels = labels[:, 1:]
+            logits = logits[:, :-1, :]
+        tgt = labels.masked_fill(labels == self.label_pad_token_id, 0)
+        S, T1, V = logits.shape
+        lp = K.token_logp(logits.reshape(S * T1, V).contiguous(), tgt.reshape(-1).to(torch.int32).contiguous())
+        return lp.view(S, T1)
+
+    def accumulate_logps(self, logps, signs):
+        """Per-phrase sums: column i collects the tokens whose sign equals the (i+1)-th smallest id present anywhere in
+        `signs` (batch-global slots; rows lacking a phrase keep 0)."""
+        slots = torch.unique(signs, sorted=True)[1:]
+        all_valid = torch.zeros_like(signs)
+        return K.phrase_sum(logps.float().contiguous(), all_valid, signs.contiguous(), slots.contiguous())
+
+    def concatenated_forward(self, model, inputs):
+        ids, neg = inputs["input_ids"], inputs["neg_input_ids"]
+        B = ids.shape[0]
+        width = max(ids.shape[1], neg.shape[1])
+        dev = ids.device
+
+        def stack(pos, negt, fill, dtype):
+            out = torch.full((2 * B, width), fill, dtype=dtype, device=dev)
+            out[:B, :pos.shape[1]] = pos
+            out[B:, :negt.shape[1]] = negt
+            return out
+
+        cat_ids = stack(ids, neg, 0, ids.dtype)
+        cat_labels = stack(inputs["labels"], inputs["neg_labels"], IGNORE_INDEX, inputs["labels"].dtype)
+        cat_mask = stack(inputs["attention_mask"], inputs["neg_attention_mask"], False, torch.bool)
+        cat_signs = stack(inputs["pos_signs"], inputs["neg_signs"], 0, inputs["pos_signs"].dtype)
+        images = inputs["images"]
+        (_, _, mask, _, embeds, labels, signs) = model.prepare_inputs_labels_for_multimodal_signed(
+            input_ids=cat_ids, position_ids=None, attention_mask=cat_mask, past_key_values=None, labels=cat_labels,
+            images=torch.cat([images, images], dim=0), signs=cat_signs)
+        all_logits = model.forward(inputs_embeds=embeds, labels=None, attention_mask=mask).logits.to(torch.float32)
+        all_logps = self.cal_batch_logp(all_logits, labels)
+        if not self.is_encoder_decoder:
+            labels = labels[:, 1:].clone()
+            signs = signs[:, 1:].clone()
+            all_logits = all_logits[:, :-1, :]
+        return all_logps[:B], all_logps[B:], labels, all_logits, signs
+
+    def reference_forward(self, model, inputs):
+        (_, _, mask, _, embeds, labels) = model.prepare_inputs_labels_for_multimodal(
+            input_ids=inputs["ref_input_ids"], position_ids=None, attention_mask=inputs["ref_attention_mask"],
+            past_key_values=None, labels=inputs["ref_labels"], images=inputs["ref_images"])
+        logits = model.forward(inputs_embeds=embeds, labels=None, attention_mask=mask).logits.to(torch.float32)
+        logps = self.cal_batch_logp(logits, labels)
+        if not self.is_encoder_decoder:
+            labels = labels[:, 1:].clone()
+            logits = logits[:, :-1, :]
+        return logps, labels, logits
+
+    def compute_loss(self, model, inputs: Dict[str, Any], return_outputs=False):
+        """loss = mean_{b,p} log(1 + exp(neg_acc - pos_acc)) + loss_alpha * sum(KL(ref || policy)) / B.
+        Like the reference (halva_trainer.py:548,573) the `model` argument is ignored in favour of self.model."""
+        pos_logps, neg_logps, labels, _, signs = self.concatenated_forward(self.model, inputs)
+        B = pos_logps.shape[0]
+        valid = (labels != IGNORE_INDEX)
+        pos_logps = pos_logps * valid[:B].float()
+        neg_logps = neg_logps * valid[B:].float()
+        signs = signs.masked_fill(signs == IGNORE_INDEX, 0)
+        pos_acc = self.accumulate_logps(pos_logps, signs[:B])
+        neg_acc = self.accumulate_logps(neg_logps, signs[B:])
+        alignment = torch.log(1 + torch.exp(neg_acc - pos_acc)).mean()
+
+        _, _, pol_logits = self.reference_forward(self.model, inputs)
+        with torch.no_grad():
+            _, ref_labels, ref_logits = self.reference_forward(self.ref_model, inputs)
+        w = (ref_labels != IGNORE_INDEX).float().reshape(-1).contiguous()
+        V = ref_logits.shape[-1]
+        kl = K.kl_rows(pol_logits.reshape(-1, V).contiguous(), ref_logits.reshape(-1, V).contiguous(), w)
+        divergence = kl.sum() / ref_logits.shape[0]
+        return alignment + self.loss_alpha * divergence
+
+    # -- engine-backed training -------------------------------------------------------------------
+    def _setup_engine(self):
+        if self._engine is not None:
+            return
+        a = self.args
+        self._flat = dpa.FlatTrainables(dpa.trainable_named_parameters(self.model))
+        dpa.set_grad_sink(self.model, True)
+        self._engine = dpa.DPAEngine(self.model, self.ref_model, self.loss_alpha,
+                                     pairs_per_group=int(os.environ.get("HALVA_PAIRS_PER_GROUP", "4")),
+                                     ref_rows_per_group=int(os.environ.get("HALVA_REF_ROWS_PER_GROUP", "8")))
+        if getattr(a, "gradient_checkpointing", False) and os.environ.get("HALVA_FORCE_CHECKPOINT", "0") == "1":
+            self.model.get_model().gradient_checkpointing = True
+
+    def create_optimizer(self):
+        self._setup_engine()
+        if self.optimizer is None:
+            a = self.args
+            self.optimizer = dpa.AdamWFlat(self._flat, lr=a.learning_rate, weight_decay=a.weight_decay,
+                                           mm_projector_lr=getattr(a, "mm_projector_lr", None),
+                                           betas=(getattr(a, "adam_beta1", 0.9), getattr(a, "adam_beta2", 0.999)),
+                                           eps=getattr(a, "adam_epsilon", 1e-8))
+        return self.optimizer
+
+    def training_step(self, inputs, scale=1.0):
+        """One micro-batch: forward + backward group by group; gradients accumulate in the flat fp32 buffer."""
+        self._setup_engine()
+        return self._engine.loss(inputs, backward=True, scale=scale)
+
+    def _get_train_sampler(self):
+        a = self.args
+        if self.train_dataset is None:
+            return None
+        if getattr(a, "group_by_modality_length", False):
+            # reference quirk kept: world_size := world_size * gradient_accumulation_steps (halva_trainer.py:269)
+            return LengthGroupedSampler(a.per_device_train_batch_size * 1, world_size=self.dist.world * a.gradient_accumulation_steps,
+                                        lengths=self.train_dataset.modality_lengths, group_by_modality=True)
+        g = torch.Generator().manual_seed(getattr(a, "seed", 42))
+        return torch.utils.data.RandomSampler(self.train_dataset, generator=g)
+
+    def get_train_dataloader(self):
+        a = self.args
+        sampler = self._get_train_sampler()
+        order = list(iter(sampler))
+        bs = a.per_device_train_batch_size
+        # accelerate-style batch sharding: global batches of bs, rank r takes batches r, r+world, ...
+        batches = [order[i:i + bs] for i in range(0, len(order), bs)]
+        if not getattr(a, "dataloader_drop_last", False) and len(batches) % self.dist.world:
+            batches += batches[:self.dist.world - len(batches) % self.dist.world]      # wrap around like accelerate even_batches
+        mine = batches[self.dist.rank::self.dist.world]
+        return DataLoader(self.train_dataset, batch_sampler=mine, collate_fn=self.data_collator,
+                          num_workers=getattr(a, "dataloader_num_workers", 0))
+
+    def add_callback(self, cb):
+        self.callbacks.append(cb() if isinstance(cb, type) else cb)
+
+    def log(self, rec):
+        self.state.log_history.append(rec)
+        if self.dist.rank == 0:
+            print(json.dumps(rec), flush=True)
+
+    def train(self, resume_from_checkpoint=None):
+        a = self.args
+        torch.manual_seed(getattr(a, "seed", 42))
+        self.create_optimizer()
+        accum = a.gradient_accumulation_steps
+        steps_per_epoch_hint = None
+        t0 = time.time()
+        for epoch in range(int(math.ceil(a.num_train_epochs))):
+            loader = self.get_train_dataloader()
+            n_micro = len(loader)
+            steps_per_epoch = max(1, math.ceil(n_micro / accum))
+            total_steps = getattr(a, "max_steps", -1) if getattr(a, "max_steps", -1) > 0 else int(steps_per_epoch * a.num_train_epochs)
+            running, seen = 0.0, 0
+            self._flat.zero_grad()
+            for i, batch in enumerate(loader):
+                batch = self._to_device(batch)
+                loss = self.training_step(batch, scale=1.0 / accum)
+                running, seen = running + float(loss), seen + 1
+                last = (i + 1) == n_micro
+                if (i + 1) % accum == 0 or last:
+                    dp.allreduce_mean_(self._flat.grad, self.dist)
+                    self.optimizer.set_lr_factor(dpa.cosine_with_warmup(self.state.global_step, total_steps,
+                                                                        getattr(a, "warmup_ratio", 0.0)))
+                    self.optimizer.step()
+                    self._flat.zero_grad()
+                    self.state.global_step += 1
+                    self.state.epoch = epoch + (i + 1) / n_micro
+                    if self.state.global_step % max(1, int(getattr(a, "logging_steps", 1))) == 0:
+                        mean = dp.mean_scalar(running / seen, self.dist)
+                        self.log({"loss": round(mean, 6), "step": self.state.global_step, "epoch": round(self.state.epoch, 4),
+                                  "learning_rate": self.optimizer.opt.param_groups[0]["lr"], "elapsed_s": round(time.time() - t0, 1)})
+                    running, seen = 0.0, 0
+                    if self.state.global_step >= total_steps:
+                        break
+        for cb in self.callbacks:
+            if hasattr(cb, "on_train_end"):
+                cb.on_train_end(a, self.state, None, model=self.model)
+        return self.state
+
+    def _to_device(self, batch):
+        dev = self.model.device
+        out = dict(batch)
+        for k in ("images", "ref_images"):
+            v = out[k]
+            out[k] = (torch.stack(v) if isinstance(v, (list, tuple)) else v).to(dev, torch.bfloat16, non_blocking=True)
+        return out          # integer tensors stay on the host: the splice plan is computed there
+
+    def save_state(self):
+        a = self.args
+        if self.dist.rank == 0 and getattr(a, "output_dir", None):
+            os.makedirs(a.output_dir, exist_ok=True)
+            with open(os.path.join(a.output_dir, "trainer_state.json"), "w") as f:
+                json.dump({"global_step": self.state.global_step, "epoch": self.state.epoch, "log_history": self.state.log_history}, f,
+                          indent=1)

@@ -227,9 +227,9 @@ VIS = dict(hidden_size=32, intermediate_size=48, num_hidden_layers=3, num_attent
            patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5, num_channels=3)
 
 
-def build_vision_tower(seed):
+def build_vision_tower(seed, vis=None, bf16_round=False):
     from transformers import CLIPVisionConfig, CLIPVisionModel
-    cfg = CLIPVisionConfig(**VIS)
+    cfg = CLIPVisionConfig(**(vis or VIS))
     orig = CLIPVisionConfig.from_pretrained
     CLIPVisionConfig.from_pretrained = classmethod(lambda cls, *a, **k: cfg)
     try:
@@ -246,14 +246,18 @@ def build_vision_tower(seed):
             if "layer_norm" in n or "layrnorm" in n:
                 if n.endswith("weight"):
                     p.add_(1.0)
+        if bf16_round:
+            for p in tower.vision_tower.parameters():
+                p.copy_(p.bfloat16().float())
     tower.vision_tower.requires_grad_(False)
     tower.is_loaded = True
     return tower
 
 
-def build_llava(seed, tower, max_len=64, padding_side="right"):
+def build_llava(seed, tower, max_len=64, padding_side="right", tiny=None, vis=None, bf16_round=False, std=0.06):
+    tiny, vis = tiny or TINY, vis or VIS
     torch.manual_seed(seed)
-    cfg = LlavaConfig(**TINY)
+    cfg = LlavaConfig(**tiny)
     cfg._attn_implementation = "eager"
     m = LlavaLlamaForCausalLM(cfg)
     with torch.no_grad():
@@ -261,13 +265,17 @@ def build_llava(seed, tower, max_len=64, padding_side="right"):
             if "norm" in n:
                 p.copy_(1.0 + 0.1 * torch.randn_like(p))
             else:
-                p.copy_(torch.randn_like(p) * 0.06)
+                p.copy_(torch.randn_like(p) * std)
     m.model.vision_tower = tower
-    m.model.mm_projector = torch.nn.Sequential(torch.nn.Linear(VIS["hidden_size"], TINY["hidden_size"]), torch.nn.GELU(),
-                                               torch.nn.Linear(TINY["hidden_size"], TINY["hidden_size"]))
+    m.model.mm_projector = torch.nn.Sequential(torch.nn.Linear(vis["hidden_size"], tiny["hidden_size"]), torch.nn.GELU(),
+                                               torch.nn.Linear(tiny["hidden_size"], tiny["hidden_size"]))
     with torch.no_grad():
         for p in m.model.mm_projector.parameters():
             p.copy_(torch.randn_like(p) * 0.1)
+        if bf16_round:
+            for n, p in m.named_parameters():
+                if "vision_tower" not in n:
+                    p.copy_(p.bfloat16().float())
     m.config.tokenizer_model_max_length = max_len
     m.config.tokenizer_padding_side = padding_side
     m.eval()
@@ -283,10 +291,11 @@ def export_llava(m, prefix):
     return out
 
 
-def make_batch(B, seed, n_patch, long_resp=False):
+def make_batch(B, seed, n_patch, long_resp=False, vis=None, vocab=None):
     """Synthetic collated batch in the reference's key layout (train_halva.py:963-989)."""
+    vis = vis or VIS
     g = torch.Generator().manual_seed(seed)
-    V = TINY["vocab_size"]
+    V = vocab or TINY["vocab_size"]
 
     def seq(resp_len, phrases):
         pre = torch.randint(3, V, (4,), generator=g).tolist()
@@ -324,8 +333,8 @@ def make_batch(B, seed, n_patch, long_resp=False):
         inst.append(dict(input_ids=torch.tensor(ids), labels=torch.tensor(labels), neg_input_ids=torch.tensor(nids),
                          neg_labels=torch.tensor(nlabels), pos_signs=torch.tensor(signs), neg_signs=torch.tensor(nsigns),
                          ref_input_ids=torch.tensor(rids), ref_labels=torch.tensor(rlabels),
-                         image=torch.randn(3, VIS["image_size"], VIS["image_size"], generator=g),
-                         ref_image=torch.randn(3, VIS["image_size"], VIS["image_size"], generator=g)))
+                         image=torch.randn(3, vis["image_size"], vis["image_size"], generator=g).bfloat16().float(),
+                         ref_image=torch.randn(3, vis["image_size"], vis["image_size"], generator=g).bfloat16().float()))
     tok = FakeLlamaTokenizer(model_max_length=2048)
     return TH.DataCollatorForHallDataset(tokenizer=tok)(inst)
 
@@ -431,7 +440,7 @@ def gen_loss_small():
 # ----------------------------------------------------------------------------------------------
 # G5: full compute_loss on tiny models, fp32 (halva_trainer.py:534-592)
 # ----------------------------------------------------------------------------------------------
-def lora_merge(model, seed, r=4, alpha=8.0):
+def lora_merge(model, seed, r=4, alpha=8.0, bf16_round=False, std=0.05):
     """Emulate peft-0.4 LoRA (W x + (alpha/r) B A x) by merging into the dense reference weights;
     returns the A/B factors so the build's explicit-LoRA model can be checked against the merge."""
     g = torch.Generator().manual_seed(seed)
@@ -439,8 +448,10 @@ def lora_merge(model, seed, r=4, alpha=8.0):
     with torch.no_grad():
         for n, mod in model.named_modules():
             if isinstance(mod, torch.nn.Linear) and "mm_projector" not in n and "vision_tower" not in n and "lm_head" not in n:
-                A = torch.randn(r, mod.in_features, generator=g) * 0.05
-                Bm = torch.randn(mod.out_features, r, generator=g) * 0.05
+                A = torch.randn(r, mod.in_features, generator=g) * std
+                Bm = torch.randn(mod.out_features, r, generator=g) * std
+                if bf16_round:
+                    A, Bm = A.bfloat16().float(), Bm.bfloat16().float()
                 mod.weight.add_((alpha / r) * (Bm @ A))
                 fac["lora." + n + ".A"] = t2n(A)
                 fac["lora." + n + ".B"] = t2n(Bm)
@@ -500,6 +511,67 @@ def gen_dpa_step(tower):
 # ----------------------------------------------------------------------------------------------
 # G8: one decoder layer of the vendored transformers-4.31 spec, fwd/bwd (modelling_llama.py:56-420)
 # ----------------------------------------------------------------------------------------------
+TINY64 = dict(vocab_size=160, hidden_size=128, intermediate_size=192, num_hidden_layers=2, num_attention_heads=2,
+              num_key_value_heads=2, max_position_embeddings=128, rms_norm_eps=1e-5, pad_token_id=0)
+VIS64 = dict(hidden_size=128, intermediate_size=192, num_hidden_layers=3, num_attention_heads=2, image_size=28,
+             patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5, num_channels=3)
+
+
+def gen_dpa_step_d64(name="dpa_step_d64", std=0.06, lora_std=0.05):
+    """Geometry the HIP kernels support (head_dim 64) with bf16-representable weights/images, so the GPU path (bf16)
+    and the reference (fp32 here) start from identical numbers.  Weights are stored as raw bf16 bits (uint16)."""
+    def bits(t):
+        return t.detach().bfloat16().view(torch.int16).numpy().view(np.uint16)
+    tower = build_vision_tower(41, VIS64, bf16_round=True)
+    n_patch = (VIS64["image_size"] // VIS64["patch_size"]) ** 2
+    B, seed, max_len, alpha = 3, 51, 64, 0.4
+    ref = build_llava(300, tower, max_len=max_len, tiny=TINY64, vis=VIS64, bf16_round=True, std=std)
+    policy = copy.deepcopy(ref)
+    policy.model.vision_tower = tower
+    ref.requires_grad_(False)
+    packs = {}
+    for n, p in ref.state_dict().items():
+        if "rotary_emb" in n or "vision_tower" in n:
+            continue
+        packs["base." + n] = bits(p)
+    fac = lora_merge(policy, seed + 1, bf16_round=True, std=lora_std)
+    for k, v in fac.items():
+        packs[k] = bits(torch.from_numpy(v))
+    packs["lora_cfg"] = np.array([4, 8.0])
+    batch = make_batch(B, seed, n_patch, vis=VIS64, vocab=TINY64["vocab_size"])
+    stub = trainer_stub(policy, ref, alpha)
+    policy.zero_grad()
+    pos_logps, neg_logps, batch_labels, all_logits, batch_signs = stub.concatenated_forward(policy, batch)
+    loss = stub.compute_loss(policy, batch)
+    loss.backward()
+    with torch.no_grad():
+        mask = (batch_labels != -100)
+        half = pos_logps.shape[0]
+        sg = batch_signs.masked_fill(batch_signs == -100, 0)
+        pa = stub.accumulate_logps(pos_logps * mask[:half].float(), sg[:half])
+        na = stub.accumulate_logps(neg_logps * mask[half:].float(), sg[half:])
+        align = torch.log(1 + torch.exp(na - pa)).mean()
+        div = (loss - align) / alpha
+    for k, v in batch.items():
+        packs["batch." + k] = t2n(v)
+    packs.update({"out.loss": t2n(loss), "out.alignment": t2n(align), "out.divergence": t2n(div),
+                  "out.pos_logps": t2n(pos_logps), "out.neg_logps": t2n(neg_logps), "out.batch_labels": t2n(batch_labels),
+                  "out.batch_signs": t2n(batch_signs), "out.pos_acc": t2n(pa), "out.neg_acc": t2n(na),
+                  "alpha": np.array(alpha), "max_len": np.array(max_len)})
+    for n, p in policy.named_parameters():
+        if p.grad is not None and ("layers.0.self_attn.q_proj" in n or "layers.1.mlp.down_proj" in n or "mm_projector" in n
+                                   or "layers.1.self_attn.v_proj" in n or "layers.0.mlp.gate_proj" in n
+                                   or "layers.1.self_attn.o_proj" in n or "layers.0.self_attn.k_proj" in n):
+            packs["grad." + n] = t2n(p.grad)
+    for n, p in tower.vision_tower.state_dict().items():
+        if "position_ids" not in n:
+            packs["clip." + n] = bits(p)
+    packs["clip_cfg"] = np.frombuffer(json.dumps(VIS64).encode(), dtype=np.uint8)
+    packs["llama_cfg"] = np.frombuffer(json.dumps(TINY64).encode(), dtype=np.uint8)
+    save_npz(name + ".npz", **packs)
+    print("   ", name, "loss", float(loss), "align", float(align), "div", float(div))
+
+
 def gen_llama_layer():
     from transformers import LlamaConfig
     torch.manual_seed(77)
@@ -553,6 +625,8 @@ def main():
     gen_splice(tower)
     gen_loss_small()
     gen_dpa_step(tower)
+    gen_dpa_step_d64()
+    gen_dpa_step_d64("dpa_step_d64_init", std=0.02, lora_std=0.02)
     gen_llama_layer()
 
 

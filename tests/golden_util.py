@@ -21,6 +21,13 @@ def meta_of(npz, key="meta"):
     return json.loads(bytes(npz[key]).decode())
 
 
+def to_tensor(a):
+    """numpy -> torch; uint16 arrays hold raw bf16 bits (weights stored bf16-exact) and come back as fp32."""
+    if a.dtype == np.uint16:
+        return torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16).float()
+    return torch.from_numpy(a)
+
+
 def tensors(npz, prefix):
     """{name-without-prefix: torch tensor} for every key starting with prefix."""
-    return {k[len(prefix):]: torch.from_numpy(npz[k]) for k in npz.files if k.startswith(prefix)}
+    return {k[len(prefix):]: to_tensor(npz[k]) for k in npz.files if k.startswith(prefix)}

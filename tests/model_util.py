@@ -1,0 +1,52 @@
+"""Build product models (halva_amd) from golden fixtures - test helper."""
+import numpy as np
+import torch
+
+from golden_util import meta_of, tensors
+
+
+def build_product_models(z, device="cuda", lora=True):
+    from halva_amd.clip import CLIPVisionConfig, CLIPVisionTower, build_vision_projector
+    from halva_amd.llama import add_lora, load_hf_llama_weights
+    from halva_amd.llava_model import LlavaConfig, LlavaLlamaForCausalLM
+    cfg_d, clip_d = meta_of(z, "llama_cfg"), meta_of(z, "clip_cfg")
+    base, clipW, fac = tensors(z, "base."), tensors(z, "clip."), tensors(z, "lora.")
+    r, alpha = int(z["lora_cfg"][0]), float(z["lora_cfg"][1])
+    max_len = int(z["max_len"])
+
+    def make(with_lora):
+        cfg = LlavaConfig(**cfg_d)
+        cfg.mm_projector_type, cfg.mm_hidden_size = "mlp2x_gelu", clip_d["hidden_size"]
+        cfg.tokenizer_model_max_length, cfg.tokenizer_padding_side = max_len, "right"
+        m = LlavaLlamaForCausalLM(cfg, dtype=torch.bfloat16, device=device)
+        load_hf_llama_weights(m, base)
+        vt = CLIPVisionTower("fixture", args=None, delay_load=True, config=CLIPVisionConfig(**clip_d), device=device)
+        vt._alloc()
+        vt.load_hf_state_dict(clipW)
+        vt.requires_grad_(False)
+        vt.is_loaded = True
+        m.model.vision_tower = vt
+        m.model.mm_projector = build_vision_projector(cfg, device=device)
+        m.model.mm_projector.load_state_dict({k.split("mm_projector.")[1]: v for k, v in base.items() if "mm_projector." in k})
+        for p in m.parameters():
+            p.requires_grad_(False)
+        if with_lora and fac:
+            add_lora(m, r, alpha)
+            with torch.no_grad():
+                for i, layer in enumerate(m.model.layers):
+                    for sub, grp in layer.groups():
+                        for g, n in enumerate(grp.names):
+                            key = "model.layers.%d.%s.%s" % (i, sub, n)
+                            grp.A_cat[g * r:(g + 1) * r].copy_(fac[key + ".A"])
+                            getattr(grp, n).lora_B["default"].weight.copy_(fac[key + ".B"])
+            for p in m.model.mm_projector.parameters():
+                p.requires_grad_(True)
+        else:
+            m._use_lora = False
+        return m
+
+    return make(lora), make(False), (r, alpha, fac)
+
+
+def batch_of(z):
+    return {k[len("batch."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("batch.")}

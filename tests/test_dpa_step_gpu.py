@@ -1,0 +1,132 @@
+"""GPU parity of the whole DPA step (product engine through the C-ABI kernels) against (a) the reference's own
+outputs captured in tests/golden/dpa_step_d64.npz (fp32 CPU run of the reference on bf16-exact weights) and (b) the
+oracle.  Tolerances: loss / alignment / divergence / phrase log-prob sums within 1e-3 relative-or-absolute combined
+bound stated per assert (north_star: "within 1e-3 bf16"); integer masks bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from golden_util import load_npz, tensors  # noqa: E402
+from model_util import batch_of, build_product_models  # noqa: E402
+
+
+def _engine(z, pairs_per_group, ref_rows_per_group):
+    from halva_amd import dpa
+    pol, ref, lora = build_product_models(z)
+    flat = dpa.FlatTrainables(dpa.trainable_named_parameters(pol))
+    dpa.set_grad_sink(pol, True)
+    eng = dpa.DPAEngine(pol, ref, float(z["alpha"]), pairs_per_group, ref_rows_per_group)
+    return eng, pol, ref, flat, lora
+
+
+# Two fixtures of the same head_dim-64 geometry, both produced by the reference itself:
+#   dpa_step_d64_init  weights N(0, 0.02) like a real checkpoint/init; running the ORACLE in bf16 instead of fp32 moves its
+#                      loss by 4e-4, so the north-star bound (1e-3) is meaningful here;
+#   dpa_step_d64       "stress": weights N(0, 0.06), KL 0.55; bf16 alone moves the oracle's loss by 2.7e-3, so the bound is
+#                      8e-3 (3x the bf16 noise floor); used for the gradient checks (large, well-conditioned gradients).
+FIXTURES = {"dpa_step_d64_init": (1e-3, 1e-3, 1e-3), "dpa_step_d64": (8e-3, 8e-3, 8e-3)}
+
+
+@pytest.mark.parametrize("fixture", list(FIXTURES))
+@pytest.mark.parametrize("ppg,rpg", [(8, 8), (2, 1)])
+def test_step_matches_reference_golden(ppg, rpg, fixture):
+    tol_loss, tol_align, tol_div = FIXTURES[fixture]
+    z = load_npz(fixture + ".npz")
+    eng, pol, ref, flat, (r, alpha, fac) = _engine(z, ppg, rpg)
+    batch = batch_of(z)
+    loss = eng.loss(batch, backward=True)
+    torch.cuda.synchronize()
+    got = float(loss)
+    parts = {k: float(v) for k, v in eng.last_parts.items()}
+    assert abs(got - float(z["out.loss"])) < tol_loss, (got, float(z["out.loss"]))
+    assert abs(parts["alignment"] - float(z["out.alignment"])) < tol_align, (parts, float(z["out.alignment"]))
+    assert abs(parts["divergence"] - float(z["out.divergence"])) < tol_div, (parts, float(z["out.divergence"]))
+    if fixture != "dpa_step_d64":
+        return
+    # gradients: LoRA factors via the chain rule from the reference's dense dL/dW; projector directly
+    s = alpha / r
+    checked = 0
+    for i, layer in enumerate(pol.model.layers):
+        for sub, grp in layer.groups():
+            for g, n in enumerate(grp.names):
+                key = "grad.model.layers.%d.%s.%s.weight" % (i, sub, n)
+                if key not in z.files:
+                    continue
+                dW = torch.from_numpy(z[key])
+                A = fac["model.layers.%d.%s.%s.A" % (i, sub, n)]
+                Bm = fac["model.layers.%d.%s.%s.B" % (i, sub, n)]
+                gA = grp.A_cat.main_grad[g * r:(g + 1) * r].cpu()
+                gB = getattr(grp, n).lora_B["default"].weight.main_grad.cpu()
+                refA, refB = s * Bm.T @ dW, s * dW @ A.T
+                assert float((gA - refA).norm() / refA.norm()) < 3e-2, key
+                assert float((gB - refB).norm() / refB.norm()) < 3e-2, key
+                checked += 1
+    assert checked >= 5
+    for k in [k for k in z.files if k.startswith("grad.") and "mm_projector" in k]:
+        idx = int(k.split("mm_projector.")[1].split(".")[0])
+        kind = k.rsplit(".", 1)[1]
+        p = getattr(pol.model.mm_projector[idx], kind)
+        refg = torch.from_numpy(z[k])
+        assert float((p.main_grad.cpu() - refg).norm() / refg.norm()) < 3e-2, k
+
+
+def test_compat_api_matches_golden():
+    """The reference-shaped API (HalvaTrainer.concatenated_forward / compute_loss with full logits) on the same fixture."""
+    import types
+    from llava.train.halva_trainer import HalvaTrainer
+    z = load_npz("dpa_step_d64_init.npz")
+    from halva_amd import dpa
+    pol, ref, _ = build_product_models(z)
+    dpa.set_grad_sink(pol, False)
+    stub = types.SimpleNamespace(model=pol, ref_model=ref, loss_alpha=float(z["alpha"]), label_pad_token_id=-100,
+                                 is_encoder_decoder=False)
+    for n in ("cal_batch_logp", "accumulate_logps", "concatenated_forward", "reference_forward", "compute_loss"):
+        setattr(stub, n, types.MethodType(getattr(HalvaTrainer, n), stub))
+    batch = {k: (v.cuda() if v.dtype.is_floating_point else v.cuda()) for k, v in batch_of(z).items()}
+    batch["images"], batch["ref_images"] = batch["images"].bfloat16(), batch["ref_images"].bfloat16()
+    pos_logps, neg_logps, labels, logits, signs = stub.concatenated_forward(pol, batch)
+    np.testing.assert_array_equal(labels.cpu().numpy(), z["out.batch_labels"])          # token-index masks: bit exact
+    np.testing.assert_array_equal(signs.cpu().numpy(), z["out.batch_signs"])
+    m = z["out.batch_labels"] != -100
+    B = pos_logps.shape[0]
+    assert np.abs(pos_logps.detach().cpu().numpy() - z["out.pos_logps"])[m[:B]].max() < 2e-2
+    loss = stub.compute_loss(pol, batch)
+    assert abs(float(loss) - float(z["out.loss"])) < 1e-3
+    loss.backward()
+    assert pol.model.mm_projector[0].weight.grad is not None
+
+
+def test_identity_policy_has_zero_divergence():
+    """LoRA B = 0 (fresh adapter) => policy == reference => divergence == 0."""
+    from halva_amd import dpa
+    from halva_amd.llama import add_lora
+    z = load_npz("dpa_step_d64.npz")
+    pol, ref, _ = build_product_models(z, lora=False)
+    add_lora(pol, 4, 8.0)
+    pol._use_lora = True
+    for p in pol.model.mm_projector.parameters():
+        p.requires_grad_(True)
+    flat = dpa.FlatTrainables(dpa.trainable_named_parameters(pol))
+    dpa.set_grad_sink(pol, True)
+    eng = dpa.DPAEngine(pol, ref, 0.4, 8, 8)
+    eng.loss(batch_of(z), backward=True)
+    assert abs(float(eng.last_parts["divergence"])) < 1e-6
+    assert float(flat.grad.abs().sum()) > 0
+
+
+def test_optimizer_step_moves_lora_not_projector():
+    from halva_amd import dpa
+    z = load_npz("dpa_step_d64.npz")
+    eng, pol, ref, flat, _ = _engine(z, 8, 8)
+    opt = dpa.AdamWFlat(flat, lr=1e-3, weight_decay=0.0, mm_projector_lr=0.0)
+    before = flat.master.clone()
+    l0 = float(eng.loss(batch_of(z), backward=True))
+    opt.step()
+    flat.zero_grad()
+    lo, hi = flat.segment(lambda n: "mm_projector" in n and "bias" not in n)
+    assert torch.equal(flat.master[lo:hi], before[lo:hi])                 # mm_projector_lr 0 (src/hallava_7b.sh:33)
+    assert not torch.equal(flat.master[:lo], before[:lo])
+    l1 = float(eng.loss(batch_of(z), backward=False))
+    assert l1 < l0
