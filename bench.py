@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Benchmark of the HALVA DPA step on MI355X (driver contract: `python bench.py --gpus N --steps K --warmup W`).
+
+Metric (BASELINE.json): paired-samples/sec of one full DPA optimizer step - 4 forward + 3 backward sequence passes per
+pair (pos, neg, policy-on-ref with grad, frozen reference without), the phrase-level contrastive + KL loss, gradient
+all-reduce and AdamW on the LoRA/projector parameters - LLaVA-1.5-7B geometry, 336 px images, T = 2048 post-splice,
+LoRA r=128, bf16, synthetic data and random-init weights (no datasets/checkpoints offline).
+
+N = 1: configs[1] (bs = 16 pairs on one MI355X).  N > 1: the same 16 pairs PER GPU (weak scaling), one process per GPU
+(launched by torch.distributed.run), one RCCL all-reduce of the flat trainable-gradient buffer per step.
+Prints ONE JSON line on rank 0 with `roofline` (dominant hand-written kernel: the fused causal SDPA backward, timed live
+with HIP events on the launch stream) and `cpu_baseline` (the oracle's CPU restatement timed on the host cores, rank 0,
+N = 1 only, bounded sample).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+LLAMA_7B = dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32,
+                num_key_value_heads=32, rms_norm_eps=1e-5, max_position_embeddings=4096)
+LLAMA_13B = dict(vocab_size=32000, hidden_size=5120, intermediate_size=13824, num_hidden_layers=40, num_attention_heads=40,
+                 num_key_value_heads=40, rms_norm_eps=1e-5, max_position_embeddings=4096)
+CLIP_L_336 = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=336,
+                  patch_size=14)
+TFLOP_PER_PAIR = 214.7            # BASELINE.md section 2 (7B, T = 2048, LoRA r = 128, no recompute)
+PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def synthetic_batch(B, seed, resp_len=1419, vocab=32000, image=336):
+    """BASELINE.md section 3 layout: [BOS, 34 prompt, <image>, 12 question, 5 'ASSISTANT:', R response, EOS]."""
+    g = torch.Generator().manual_seed(seed)
+    pre = 1 + 34
+    post = 12 + 5
+    L = pre + 1 + post + resp_len + 1
+    off = pre + 1 + post
+
+    def ids():
+        x = torch.randint(3, vocab, (B, L), generator=g)
+        x[:, 0] = 1
+        x[:, pre] = -200
+        x[:, -1] = 2
+        return x
+
+    pos = ids()
+    neg = pos.clone()
+    signs = torch.zeros(B, L, dtype=torch.long)
+    for k in range(6):
+        s = off + 40 + 200 * k
+        signs[:, s:s + 3] = k + 1
+        neg[:, s:s + 3] = torch.randint(3, vocab, (B, 3), generator=g)
+    labels = pos.clone()
+    labels[:, :off] = -100
+    neg_labels = neg.clone()
+    neg_labels[:, :off] = -100
+    ref = ids()
+    ref_labels = ref.clone()
+    ref_labels[:, :off] = -100
+    ones = torch.ones(B, L, dtype=torch.bool)
+    return dict(input_ids=pos, labels=labels, attention_mask=ones, neg_input_ids=neg, neg_labels=neg_labels,
+                neg_attention_mask=ones.clone(), pos_signs=signs, neg_signs=signs.clone(), ref_input_ids=ref,
+                ref_labels=ref_labels, ref_attention_mask=ones.clone(),
+                images=torch.randn(B, 3, image, image, generator=g), ref_images=torch.randn(B, 3, image, image, generator=g))
+
+
+def sdpa_roofline(dev, S=8, T=2048, H=32, D=128, iters=10):
+    """Times the hand-written causal SDPA kernels at the workload's per-layer shape with HIP events on the stream they
+    are launched on (torch's current stream).  Algorithmic FLOPs: fwd 2*T^2*D*H per sequence (QK^T + PV,
+    causal half), bwd 2.5x that."""
+    from halva_amd import kernels as K
+    g = torch.Generator(device=dev).manual_seed(0)
+    qkv = torch.randn(S, T, 3 * H * D, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    dout = torch.randn(S, T, H * D, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    ss = torch.zeros(S, dtype=torch.int32, device=dev)
+    sl = torch.full((S,), T, dtype=torch.int32, device=dev)
+    q = qkv.clone().requires_grad_(True)
+    out = K.sdpa_causal(q, ss, sl, H, D)
+    out.backward(dout)
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    tf = tb = 0.0
+    for _ in range(iters):
+        q.grad = None
+        e[0].record()
+        out = K.sdpa_causal(q, ss, sl, H, D)
+        e[1].record()
+        out.backward(dout)
+        e[2].record()
+        torch.cuda.synchronize()
+        tf += e[0].elapsed_time(e[1])
+        tb += e[1].elapsed_time(e[2])
+    tf, tb = tf / iters * 1e-3, tb / iters * 1e-3
+    fwd_flop = 2.0 * T * T * D * H * S
+    bwd_flop = 2.5 * fwd_flop
+    return {"bound": "mfma", "kernel": "sdpa_causal_bwd (delta + dQ + dK/dV launches, D=128)", "achieved": round(bwd_flop / tb / 1e12, 2),
+            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(bwd_flop / tb / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "launch_ms": round(tb * 1e3, 3), "shape": {"S": S, "T": T, "H": H, "D": D},
+            "fwd": {"achieved": round(fwd_flop / tf / 1e12, 2), "frac": round(fwd_flop / tf / 1e12 / PEAK_BF16_TFLOPS, 4),
+                    "launch_ms": round(tf * 1e3, 3)}}
+
+
+def cpu_baseline(budget_s=25.0):
+    """The oracle (CPU restatement of the reference's path, oracle/) timed on this box's host cores: ONE sequence of the
+    7B geometry at T = 2048 through a bounded number of decoder layers (fwd + bwd, LoRA r = 128, bf16) and the
+    lm_head + loss on its 1419 response rows; extrapolated to a pair as 3*(fwd+bwd) + 1*fwd over 32 layers."""
+    import torch.nn.functional as F
+    from oracle import dpa as odpa
+    from oracle import nets
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = dict(LLAMA_7B)
+    d, Fd, T, r, V = cfg["hidden_size"], cfg["intermediate_size"], 2048, 128, cfg["vocab_size"]
+    g = torch.Generator().manual_seed(0)
+    bf = torch.bfloat16
+    W, lora = {}, {}
+    p = "L."
+    for n, (o, i) in {"self_attn.q_proj": (d, d), "self_attn.k_proj": (d, d), "self_attn.v_proj": (d, d), "self_attn.o_proj": (d, d),
+                      "mlp.gate_proj": (Fd, d), "mlp.up_proj": (Fd, d), "mlp.down_proj": (d, Fd)}.items():
+        W[p + n + ".weight"] = (torch.randn(o, i, generator=g) * 0.02).to(bf)
+        lora[p + n + ".A"] = (torch.randn(r, i, generator=g) * 0.02).to(bf).requires_grad_(True)
+        lora[p + n + ".B"] = (torch.randn(o, r, generator=g) * 0.01).to(bf).requires_grad_(True)
+    W[p + "input_layernorm.weight"] = torch.ones(d, dtype=bf)
+    W[p + "post_attention_layernorm.weight"] = torch.ones(d, dtype=bf)
+    x = torch.randn(1, T, d, generator=g).to(bf).requires_grad_(True)
+    keep = torch.ones(1, T, dtype=torch.bool)
+    t0 = time.time()
+    with torch.no_grad():
+        nets.decoder_layer(x, W, p, keep, cfg, lora, 2.0, varlen=True)
+    t_fwd = time.time() - t0
+    t0 = time.time()
+    y = nets.decoder_layer(x, W, p, keep, cfg, lora, 2.0, varlen=True)
+    y.float().sum().backward()
+    t_fb = time.time() - t0
+    # lm_head + token log-prob + KL on the response rows
+    R = 1419
+    Wlm = (torch.randn(V, d, generator=g) * 0.02).to(bf)
+    h = torch.randn(1, R + 1, d, generator=g).to(bf).requires_grad_(True)
+    labels = torch.randint(3, V, (1, R + 1), generator=g)
+    t0 = time.time()
+    logits = F.linear(h, Wlm).float()
+    lp = odpa.cal_batch_logp(logits, labels)
+    ref_logits = logits.detach() + 0.01
+    kl = odpa.kl_to_reference(logits[:, :-1], ref_logits[:, :-1], labels[:, 1:])
+    (lp.sum() + kl).backward()
+    t_head = time.time() - t0
+    L = cfg["num_hidden_layers"]
+    pair_s = 3 * (L * t_fb) + 1 * (L * t_fwd) + 4 * t_head
+    return {"value": round(1.0 / pair_s, 6), "unit": "paired-samples/sec", "cores": cores, "kind": "port",
+            "sample": "oracle (torch-CPU bf16 restatement): 1 decoder layer of the 7B geometry at T=2048 timed fwd (%.2fs) and "
+                      "fwd+bwd (%.2fs), lm_head+logp+KL on 1419 rows (%.2fs); pair = 3x32 fwd+bwd + 1x32 fwd layers + 4 heads "
+                      "(CLIP tower omitted, <1%%) => %.0f s/pair" % (t_fwd, t_fb, t_head, pair_s)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs-per-gpu", type=int, default=16)
+    ap.add_argument("--model", default="7b", choices=["7b", "13b"])
+    ap.add_argument("--layers", type=int, default=0, help="debug: override the layer count (result is then marked invalid)")
+    ap.add_argument("--pairs-per-group", type=int, default=int(os.environ.get("HALVA_PAIRS_PER_GROUP", "4")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from halva_amd import dp, dpa, hip
+    from halva_amd.llava_model import build_random_llava
+    hip.load()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the DPA hot path)")
+    ctx = dp.DistContext.from_env("nccl")
+    if ctx.world != args.gpus:
+        if args.gpus > 1 and ctx.world == 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..."
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(ctx.local_rank)
+    dev = torch.device("cuda", ctx.local_rank)
+
+    geo = dict(LLAMA_7B if args.model == "7b" else LLAMA_13B)
+    if args.layers:
+        geo["num_hidden_layers"] = args.layers
+    policy = build_random_llava(geo, CLIP_L_336, lora_r=128, lora_alpha=256, seed=1234, device=dev, max_len=2048)
+    with torch.no_grad():                       # LoRA B ~ N(0, 0.01) so that KL != 0
+        gB = torch.Generator(device=dev).manual_seed(99)
+        for layer in policy.model.layers:
+            for _, grp in layer.groups():
+                for n in grp.names:
+                    getattr(grp, n).lora_B["default"].weight.normal_(0.0, 0.01, generator=gB)
+    ref = build_random_llava(geo, CLIP_L_336, seed=1234, device=dev, max_len=2048, share_base_from=policy)
+    flat = dpa.FlatTrainables(dpa.trainable_named_parameters(policy))
+    dpa.set_grad_sink(policy, True)
+    opt = dpa.AdamWFlat(flat, lr=5e-6, weight_decay=0.0, mm_projector_lr=0.0)
+    eng = dpa.DPAEngine(policy, ref, 0.4, pairs_per_group=args.pairs_per_group, ref_rows_per_group=2 * args.pairs_per_group)
+    B = args.pairs_per_gpu
+    batch = synthetic_batch(B, 1234 + ctx.rank)
+    batch["images"] = batch["images"].to(dev, torch.bfloat16)          # inputs resident in HBM before the timed region
+    batch["ref_images"] = batch["ref_images"].to(dev, torch.bfloat16)
+
+    def step():
+        flat.zero_grad()
+        loss = eng.loss(batch, backward=True)
+        dp.allreduce_mean_(flat.grad, ctx)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        last = step()
+    dp.barrier(ctx)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    dp.barrier(ctx)
+    dt = time.perf_counter() - t0
+    if ctx.world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    loss_val = float(last)
+    pairs_per_s = ctx.world * B * args.steps / dt
+
+    roof = None if args.no_roofline else sdpa_roofline(dev)
+    cpu = None
+    if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+    if ctx.rank == 0:
+        tf_pair = TFLOP_PER_PAIR if (args.model == "7b" and not args.layers) else None
+        rec = {"metric": "paired-samples/sec (DPA step) LLaVA-1.5-7B @336px", "value": round(pairs_per_s, 4),
+               "unit": "paired-samples/sec", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16", "data": "synthetic (BASELINE.md section 3), random-init weights",
+               "config": {"workload": "configs[1]: LLaVA-1.5-%s LoRA(r=128) DPA step, 336px, T=2048 post-splice, %d pairs per GPU per "
+                                      "step (fwd+bwd+loss+grad all-reduce+AdamW)" % (args.model.upper(), B),
+                          "pairs_per_gpu": B, "global_pairs": B * ctx.world, "seq_len": 2048, "parallelism": "dp%d" % ctx.world,
+                          "pairs_per_group": args.pairs_per_group, "recompute": "none",
+                          "valid": not bool(args.layers)},
+               "loss": round(loss_val, 5),
+               "step_tflops_per_gpu": None if tf_pair is None else round(pairs_per_s / ctx.world * tf_pair, 1),
+               "step_mfma_frac": None if tf_pair is None else round(pairs_per_s / ctx.world * tf_pair / PEAK_BF16_TFLOPS, 4),
+               "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(rec), flush=True)
+    if ctx.world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
