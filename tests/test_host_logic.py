@@ -1,0 +1,159 @@
+"""CPU tests of the PRODUCT's host-side integer logic (llava.train.*, halva_amd.splice / dpa planning) against the
+golden vectors produced by the reference.  Bit-exact."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from fake_tokenizer import FakeLlamaTokenizer
+from golden_util import load_json, load_npz, meta_of
+
+
+@pytest.fixture(scope="module")
+def TH():
+    import llava.train.train_halva as th
+    return th
+
+
+def test_masked_tokenisation_matches_reference(TH):
+    fx = load_json("tokenize_masks.json")
+    tok = FakeLlamaTokenizer(fx["model_max_length"], vocab=fx["vocab"], frozen=True)
+    for c in fx["cases"]:
+        src = [[{"from": "human", "value": "<image>\n" + c["question"]}, {"from": "gpt", "value": c["answer_masked"]},
+                {"from": "gpt-ref", "value": c["answer"]}]]
+        if c["result"].startswith("raise"):
+            with pytest.raises(RuntimeError):
+                TH.preprocess_v1(copy.deepcopy(src), tok, has_image=True)
+            continue
+        out = TH.preprocess_v1(copy.deepcopy(src), tok, has_image=True)
+        if c["result"] == "none":
+            assert out is None
+            continue
+        assert out["input_ids"][0].tolist() == c["input_ids"]
+        assert out["signs"][0].tolist() == c["signs"]
+        assert out["labels"][0].tolist() == c["labels"]
+    for c in fx["ref_cases"]:
+        src = [[{"from": "human", "value": "<image>\n" + c["question"]}, {"from": "gpt", "value": c["answer"]}]]
+        out = TH.preprocess_v1_ref(src, tok, has_image=True)
+        assert out["input_ids"][0].tolist() == c["input_ids"] and out["labels"][0].tolist() == c["labels"]
+    for w in fx["walk"]:
+        ids, signs = TH.split_string_by_mask_and_tokenize(w["string"], tok)
+        assert ids == w["ids"] and signs == w["signs"]
+
+
+def test_collator_matches_reference(TH):
+    z = load_npz("collator.npz")
+    for ci, m in enumerate(meta_of(z)):
+        inst = []
+        for k in range(m["n"]):
+            p = "c%d_in%d_" % (ci, k)
+            inst.append({key[len(p):]: torch.from_numpy(z[key]) for key in z.files if key.startswith(p)})
+        batch = TH.DataCollatorForHallDataset(tokenizer=FakeLlamaTokenizer(model_max_length=m["max_len"]))(inst)
+        p = "c%d_out_" % ci
+        keys = [key[len(p):] for key in z.files if key.startswith(p)]
+        assert sorted(keys) == sorted(batch.keys())
+        for key in keys:
+            assert batch[key].dtype == torch.from_numpy(z[p + key]).dtype, key
+            np.testing.assert_array_equal(batch[key].numpy(), z[p + key], err_msg=key)
+
+
+def test_sampler_matches_reference():
+    from llava.train import halva_trainer as H
+    fx = load_json("sampler.json")
+    for c in fx["cases"]:
+        g = torch.Generator().manual_seed(c["seed"])
+        torch.manual_seed(c["global_seed"])
+        s = H.LengthGroupedSampler(c["batch_size"], c["world_size"], lengths=c["lengths"], generator=g, group_by_modality=True)
+        assert list(iter(s)) == c["modality_indices"]
+        g = torch.Generator().manual_seed(c["seed"])
+        assert H.get_length_grouped_indices([abs(l) for l in c["lengths"]], c["batch_size"], c["world_size"], generator=g) == c["length_indices"]
+    for c in fx["chunks"]:
+        assert H.split_to_even_chunks(c["indices"], c["lengths"], c["num_chunks"]) == c["out"]
+
+
+def test_splice_plan_matches_reference():
+    from halva_amd import splice as sp
+    z = load_npz("splice.npz")
+    for ci, m in enumerate(meta_of(z)):
+        p = "s%d_" % ci
+        n_patch = z[p + "features"].shape[1]
+        plan = sp.plan_splice(z[p + "ids"], z[p + "mask"], z[p + "labels"], z[p + "signs"], n_patch, m["max_len"], m["padding_side"])
+        np.testing.assert_array_equal(plan.labels.numpy(), z[p + "out_labels"])
+        np.testing.assert_array_equal(plan.signs.numpy(), z[p + "out_signs"])
+        np.testing.assert_array_equal(plan.mask.numpy(), z[p + "out_mask"])
+        emb, feats = z[p + "embed_tokens"], z[p + "features"].reshape(-1, z[p + "embed_tokens"].shape[1])
+        src = plan.src.numpy()
+        out = np.zeros((len(src), emb.shape[1]), np.float32)          # CPU emulation of the gather kernel's contract
+        out[src >= 0] = emb[src[src >= 0]]
+        out[src <= -2] = feats[-src[src <= -2] - 2]
+        np.testing.assert_array_equal(out.reshape(plan.S, plan.T, -1), z[p + "out_embeds"])
+        start, length = sp.spans_from_mask(plan.mask)
+        assert torch.equal(start, plan.seq_start) and torch.equal(length, plan.seq_len)
+        rp = sp.plan_splice(z[p + "ref_ids"], z[p + "ref_mask"], z[p + "ref_labels"], None, n_patch, m["max_len"], m["padding_side"])
+        np.testing.assert_array_equal(rp.labels.numpy(), z[p + "ref_out_labels"])
+        np.testing.assert_array_equal(rp.mask.numpy(), z[p + "ref_out_mask"])
+    with pytest.raises(ValueError):
+        sp.spans_from_mask(np.array([[True, False, True]]))
+
+
+def test_step_plan_slots_and_shared_image_map():
+    """Batch-global phrase slots come out of the host plan; pos/neg rows share one image slot."""
+    from halva_amd import dpa
+    z = load_npz("dpa_step_a.npz")
+    batch = {k[len("batch."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("batch.")}
+    plan = dpa.DPAStepPlan(batch, n_patch=4, max_len=int(z["max_len"]))
+    sg = z["out.batch_signs"]
+    B = plan.B
+    assert plan.pos_slots.tolist() == np.unique(np.where(sg[:B] == -100, 0, sg[:B]))[1:].tolist()
+    assert plan.P == z["out.pos_acc"].shape[1]
+    g = plan.pair_group([1, 2])
+    full_lab = z["out.batch_labels"]                      # shifted labels of the whole batch from the reference
+    for row, b in enumerate([1, 2, B + 1, B + 2]):
+        n = int(g.seq_len[row])
+        np.testing.assert_array_equal(g.labels.numpy()[row, 1:n], full_lab[b, :n - 1])
+    feat = -g.src.view(g.S, g.T)[:, :].numpy() - 2
+    img_rows = [set((feat[r][feat[r] >= 0] // 4).tolist()) for r in range(4)]
+    assert img_rows == [{0}, {1}, {0}, {1}]
+
+
+def test_argument_parser_accepts_reference_flags(TH):
+    argv = ("--lora_enable True --lora_r 128 --lora_alpha 256 --mm_projector_lr 0 --deepspeed src/json/zero3.json --loss_alpha 0.4 "
+            "--model_name_or_path liuhaotian/llava-v1.5-7b --version v1 --data_path data/data.json --ref_data_path data/ref_data.json "
+            "--image_folder default --vision_tower openai/clip-vit-large-patch14-336 --mm_projector_type mlp2x_gelu "
+            "--mm_vision_select_layer -2 --mm_use_im_start_end False --mm_use_im_patch_token False --image_aspect_ratio pad "
+            "--group_by_modality_length True --bf16 True --output_dir /tmp/o --num_train_epochs 1 --per_device_train_batch_size 4 "
+            "--per_device_eval_batch_size 4 --gradient_accumulation_steps 4 --evaluation_strategy no --save_strategy steps "
+            "--save_steps 50000 --learning_rate 5e-6 --weight_decay 0. --warmup_ratio 0.03 --lr_scheduler_type cosine "
+            "--logging_steps 1 --tf32 True --model_max_length 2048 --gradient_checkpointing True --dataloader_num_workers 8 "
+            "--lazy_preprocess True --report_to wandb --save_total_limit 1 --run_name halva-7b-lora --local_rank=0").split()
+    m, d, t = TH.parse_args_into_dataclasses((TH.ModelArguments, TH.DataArguments, TH.TrainingArguments), argv)
+    assert t.lora_enable is True and t.lora_r == 128 and t.mm_projector_lr == 0.0 and m.loss_alpha == 0.4
+    assert t.warmup_ratio == 0.03 and t.bf16 and t.gradient_accumulation_steps == 4 and d.image_aspect_ratio == "pad"
+    with pytest.raises(ValueError):
+        TH.parse_args_into_dataclasses((TH.ModelArguments,), ["--no_such_flag", "1"])
+
+
+def test_cosine_schedule():
+    from halva_amd.dpa import cosine_with_warmup
+    assert cosine_with_warmup(0, 100, 0.03) == 0.0
+    assert cosine_with_warmup(3, 100, 0.03) == 1.0
+    assert abs(cosine_with_warmup(100, 100, 0.03)) < 1e-12
+    assert abs(cosine_with_warmup(51, 100, 0.03) - 0.5 * (1 + np.cos(np.pi * 48 / 97))) < 1e-12
+
+
+def test_product_fails_loudly_without_gpu():
+    """No CPU fallback: kernels reject host tensors; a missing library raises."""
+    from halva_amd import hip, kernels
+    if not torch.cuda.is_available():
+        with pytest.raises(hip.HalvaHipError):
+            kernels.rmsnorm(torch.zeros(2, 64, dtype=torch.bfloat16), torch.ones(64, dtype=torch.bfloat16), 1e-5)
+    import os
+    old = hip.LIB_PATH
+    hip.LIB_PATH, saved = "/nonexistent/libhalva_hip.so", hip._lib
+    hip._lib = None
+    try:
+        with pytest.raises(hip.HalvaHipError):
+            hip.load()
+    finally:
+        hip.LIB_PATH, hip._lib = old, saved
