@@ -167,7 +167,7 @@ def main():
     ap.add_argument("--pairs-per-gpu", type=int, default=16)
     ap.add_argument("--model", default="7b", choices=["7b", "13b"])
     ap.add_argument("--layers", type=int, default=0, help="debug: override the layer count (result is then marked invalid)")
-    ap.add_argument("--pairs-per-group", type=int, default=int(os.environ.get("HALVA_PAIRS_PER_GROUP", "4")))
+    ap.add_argument("--pairs-per-group", type=int, default=int(os.environ.get("HALVA_PAIRS_PER_GROUP", "8")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()

@@ -26,6 +26,9 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
+#ifndef DKV_BQ
+#define DKV_BQ 64       // query rows staged per barrier in the dK/dV kernel
+#endif
 
 struct SdpaParams {
     const bf16_t* q;      // [S, T, ...] row stride ld_qkv, head offset hd * D
@@ -44,6 +47,7 @@ struct SdpaParams {
     int64_t ld_qkv;       // elements between consecutive tokens in q/k/v
     int64_t ld_o;         // elements between consecutive tokens in out / dout
     int T, H;
+    int nblk, npairs;     // row blocks per (sequence, head) pair; number of pairs (S * H)
     float scale;          // softmax scale
 };
 
@@ -114,18 +118,18 @@ __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * 
 // ---------------------------------------------------------------------------------------------------
 // cooperative tile staging: ROWS x D bf16, 256 threads, register staged
 // ---------------------------------------------------------------------------------------------------
-template <int D, int ROWS>
+template <int D, int ROWS, int NT = 256>
 struct Stage {
     static constexpr int NCH = D / 8;
-    static constexpr int PER_THREAD = ROWS * NCH / 256;
-    static_assert(ROWS * NCH % 256 == 0, "tile must split evenly over 256 threads");
+    static constexpr int PER_THREAD = ROWS * NCH / NT;
+    static_assert(ROWS * NCH % NT == 0, "tile must split evenly over the workgroup");
     u32x4 r[PER_THREAD];
 
     // rows [row_local0, row_local0 + ROWS) of a sequence; rows with local index outside [0, limit) read as zeros
     __device__ __forceinline__ void load(const bf16_t* base, int64_t ld, int64_t grow0, int local0, int limit) {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
-            const int cid = threadIdx.x + 256 * i;
+            const int cid = threadIdx.x + NT * i;
             const int row = cid / NCH, ch = cid % NCH;
             const int loc = local0 + row;
             if (loc >= 0 && loc < limit)
@@ -137,7 +141,7 @@ struct Stage {
     __device__ __forceinline__ void store(char* tile) const {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
-            const int cid = threadIdx.x + 256 * i;
+            const int cid = threadIdx.x + NT * i;
             const int row = cid / NCH, ch = cid % NCH;
             *reinterpret_cast<u32x4*>(tile + tile_off<D>(row, ch)) = r[i];
         }
@@ -170,23 +174,38 @@ __device__ __forceinline__ void store_rows_zero(bf16_t* row_ptr, int lane) {
         for (int g = 0; g < 4; ++g) *reinterpret_cast<u32x2*>(row_ptr + 32 * dt + 8 * g + 4 * h) = u32x2{0u, 0u};
 }
 
+// Workgroup -> (sequence, head, row block).  1-D grid; workgroups are dealt round-robin over the 8 XCDs, so the blocks
+// L, L+8, L+16, ... share an L2: give those the row blocks of ONE (sequence, head) pair, whose K/V (or Q/dO) tiles they all
+// stream, heaviest (latest) block first under the causal mask.  Placement only changes speed, never results.
+__device__ __forceinline__ void map_block(int L, int nblk, int H, int npairs, bool heavy_first, int& s, int& hd, int& blk) {
+    int pair, o;
+    if ((npairs & 7) == 0) {
+        const int slot = L >> 3;
+        pair = (slot / nblk) * 8 + (L & 7);
+        o = slot % nblk;
+    } else {
+        pair = L / nblk;
+        o = L % nblk;
+    }
+    blk = heavy_first ? nblk - 1 - o : o;
+    hd = pair % H;
+    s = pair / H;
+}
+
 // ===================================================================================================
 // forward
 // ===================================================================================================
-template <int D, bool CAUSAL, bool SLOW_TR>
-__global__ __launch_bounds__(256, 2) void sdpa_fwd_kernel(const SdpaParams p) {
-    constexpr int BN = 64, KS = D / 16, DT = D / 32;
+template <int D, bool CAUSAL, bool SLOW_TR, int NW>
+__device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, int s, int hd, int qb) {
+    constexpr int BN = 64, KS = D / 16, DT = D / 32, BM = 32 * NW, NT = 64 * NW;
     constexpr int TILE_BYTES = BN * D * 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_lds = smem;                    // [2][BN][D]
     char* v_lds = smem + 2 * TILE_BYTES;   // [2][BN][D]
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-    const int s = blockIdx.z, hd = blockIdx.y;
-    const int qb = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;   // heavy (late) blocks first
     const int start = p.seq_start ? p.seq_start[s] : 0;
     const int len = p.seq_len ? p.seq_len[s] : p.T;
-    const int g0 = qb * 128;                         // first padded-row index of this block
+    const int g0 = qb * BM;                          // first padded-row index of this block
     const int64_t seq_row0 = (int64_t)s * p.T;
     const int gq = g0 + 32 * wave + (lane & 31);     // this lane's query row (padded index)
     const int ql = gq - start;                       // local (un-padded) query index
@@ -195,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_fwd_kernel(const SdpaParams p) {
 
     // key range this block needs (local indices)
     int kv_end = len;
-    if (CAUSAL) kv_end = min(len, g0 + 128 - start);
+    if (CAUSAL) kv_end = min(len, g0 + BM - start);
     const int ntiles = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
 
     const bf16_t* qp = p.q + hd * D;
@@ -232,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_fwd_kernel(const SdpaParams p) {
     // wave-level causal bounds (local indices)
     const int wq_min = g0 + 32 * wave - start, wq_max = wq_min + 31;
 
-    Stage<D, BN> kst, vst;
+    Stage<D, BN, NT> kst, vst;
     const int64_t krow0 = seq_row0 + start;
     kst.load(kp, p.ld_qkv, krow0, 0, len);
     vst.load(vp, p.ld_qkv, krow0, 0, len);
@@ -259,23 +278,21 @@ __global__ __launch_bounds__(256, 2) void sdpa_fwd_kernel(const SdpaParams p) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) st[t] = mfma32(frag_rows<D>(kt, 32 * t, ks, lane), qf[ks], st[t]);
             }
-            // ---- online softmax over the key axis (registers), log2 domain
-            const bool need_mask = (kv0 + BN > len) || (CAUSAL && kv0 + BN - 1 > wq_min);
-            float tmax = -INFINITY;
+            // ---- online softmax over the key axis (registers), log2 domain; the softmax scale rides in the exp2 FMA
+            if ((kv0 + BN > len) || (CAUSAL && kv0 + BN - 1 > wq_min)) {      // wave-uniform: boundary tiles only
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float x = st[t][r] * sc;
-                    if (need_mask) {
+                    for (int r = 0; r < 16; ++r) {
                         const int kl = kv0 + 32 * t + acc_row(r, h);
-                        if (kl >= len || (CAUSAL && kl > ql)) x = -INFINITY;
+                        if (kl >= len || (CAUSAL && kl > ql)) st[t][r] = -INFINITY;
                     }
-                    st[t][r] = x;
-                    tmax = fmaxf(tmax, x);
-                }
+            }
+            float tmax = fmaxf(st[0][0], st[1][0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(st[0][r], st[1][r]));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run, tmax);
+            const float m_new = fmaxf(m_run, tmax * sc);
             const float m_sub = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_sub);
             float psum = 0.f;
@@ -283,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_fwd_kernel(const SdpaParams p) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(st[t][r] - m_sub);
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][r], sc, -m_sub));
                     st[t][r] = e;
                     psum += e;
                 }
@@ -318,6 +335,22 @@ __global__ __launch_bounds__(256, 2) void sdpa_fwd_kernel(const SdpaParams p) {
     }
 }
 
+// Under the causal mask row block b needs (b+1) units of work; one workgroup takes blocks b and nblk-1-b so every
+// workgroup does the same (nblk+1) units and the grid has no heavy tail.
+template <int D, bool CAUSAL, bool SLOW_TR, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void sdpa_fwd_kernel(const SdpaParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int s, hd, b;
+    if (CAUSAL) {
+        map_block(blockIdx.x, (p.nblk + 1) / 2, p.H, p.npairs, false, s, hd, b);
+        sdpa_fwd_block<D, CAUSAL, SLOW_TR, NW>(p, smem, s, hd, p.nblk - 1 - b);
+        if (b != p.nblk - 1 - b) sdpa_fwd_block<D, CAUSAL, SLOW_TR, NW>(p, smem, s, hd, b);
+    } else {
+        map_block(blockIdx.x, p.nblk, p.H, p.npairs, false, s, hd, b);
+        sdpa_fwd_block<D, CAUSAL, SLOW_TR, NW>(p, smem, s, hd, b);
+    }
+}
+
 // ===================================================================================================
 // backward, part 0: delta[s, h, t] = sum_d dO * O
 // ===================================================================================================
@@ -349,20 +382,17 @@ __global__ __launch_bounds__(256) void sdpa_delta_kernel(const SdpaParams p, int
 // ===================================================================================================
 // backward, part 1: dQ  (same skeleton as the forward)
 // ===================================================================================================
-template <int D, bool CAUSAL, bool SLOW_TR>
-__global__ __launch_bounds__(256, 1) void sdpa_bwd_dq_kernel(const SdpaParams p) {
-    constexpr int BN = 64, KS = D / 16, DT = D / 32;
+template <int D, bool CAUSAL, bool SLOW_TR, int NW>
+__device__ __forceinline__ void sdpa_bwd_dq_block(const SdpaParams& p, char* smem, int s, int hd, int qb) {
+    constexpr int BN = 64, KS = D / 16, DT = D / 32, BM = 32 * NW, NT = 64 * NW;
     constexpr int TILE_BYTES = BN * D * 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_lds = smem;
     char* v_lds = smem + 2 * TILE_BYTES;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-    const int s = blockIdx.z, hd = blockIdx.y;
-    const int qb = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
     const int start = p.seq_start ? p.seq_start[s] : 0;
     const int len = p.seq_len ? p.seq_len[s] : p.T;
-    const int g0 = qb * 128;
+    const int g0 = qb * BM;
     const int64_t seq_row0 = (int64_t)s * p.T;
     const int gq = g0 + 32 * wave + (lane & 31);
     const int ql = gq - start;
@@ -370,7 +400,7 @@ __global__ __launch_bounds__(256, 1) void sdpa_bwd_dq_kernel(const SdpaParams p)
     const bool q_valid = q_in_T && ql >= 0 && ql < len;
 
     int kv_end = len;
-    if (CAUSAL) kv_end = min(len, g0 + 128 - start);
+    if (CAUSAL) kv_end = min(len, g0 + BM - start);
     const int ntiles = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
 
     const bf16_t* qp = p.q + hd * D;
@@ -394,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void sdpa_bwd_dq_kernel(const SdpaParams p)
         }
     }
     const int64_t stat = ((int64_t)s * p.H + hd) * p.T + gq;
-    const float lse2 = q_valid ? p.lse[stat] * kLog2e : 0.f;
+    const float lse2 = q_valid ? p.lse[stat] * kLog2e : INFINITY;      // padded query rows: P = exp2(-inf) = 0
     const float dlt = q_valid ? p.delta[stat] : 0.f;
     const float sc = p.scale * kLog2e;
 
@@ -405,7 +435,7 @@ __global__ __launch_bounds__(256, 1) void sdpa_bwd_dq_kernel(const SdpaParams p)
         for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.f;
 
     const int wq_min = g0 + 32 * wave - start, wq_max = wq_min + 31;
-    Stage<D, BN> kst, vst;
+    Stage<D, BN, NT> kst, vst;
     const int64_t krow0 = seq_row0 + start;
     kst.load(kp, p.ld_qkv, krow0, 0, len);
     vst.load(vp, p.ld_qkv, krow0, 0, len);
@@ -437,17 +467,20 @@ __global__ __launch_bounds__(256, 1) void sdpa_bwd_dq_kernel(const SdpaParams p)
                     dp[t] = mfma32(frag_rows<D>(vt, 32 * t, ks, lane), dof[ks], dp[t]);
                 }
             }
-            const bool need_mask = (kv0 + BN > len) || (CAUSAL && kv0 + BN - 1 > wq_min);
+            if ((kv0 + BN > len) || (CAUSAL && kv0 + BN - 1 > wq_min)) {      // wave-uniform: boundary tiles only
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kl = kv0 + 32 * t + acc_row(r, h);
+                        if (kl >= len || (CAUSAL && kl > ql)) st[t][r] = -INFINITY;      // -> P = 0
+                    }
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float pr = __builtin_amdgcn_exp2f(st[t][r] * sc - lse2);
-                    if (need_mask) {
-                        const int kl = kv0 + 32 * t + acc_row(r, h);
-                        if (kl >= len || (CAUSAL && kl > ql)) pr = 0.f;
-                    }
-                    if (!q_valid) pr = 0.f;
+                    const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][r], sc, -lse2));
                     st[t][r] = pr * (dp[t][r] - dlt);   // dZ^T
                 }
 #pragma unroll
@@ -467,23 +500,36 @@ __global__ __launch_bounds__(256, 1) void sdpa_bwd_dq_kernel(const SdpaParams p)
     if (q_in_T) store_rows_T<D>(dqrow, dqacc, q_valid ? p.scale : 0.f, true, lane);
 }
 
+template <int D, bool CAUSAL, bool SLOW_TR, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void sdpa_bwd_dq_kernel(const SdpaParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int s, hd, b;
+    if (CAUSAL) {
+        map_block(blockIdx.x, (p.nblk + 1) / 2, p.H, p.npairs, false, s, hd, b);
+        sdpa_bwd_dq_block<D, CAUSAL, SLOW_TR, NW>(p, smem, s, hd, p.nblk - 1 - b);
+        if (b != p.nblk - 1 - b) sdpa_bwd_dq_block<D, CAUSAL, SLOW_TR, NW>(p, smem, s, hd, b);
+    } else {
+        map_block(blockIdx.x, p.nblk, p.H, p.npairs, false, s, hd, b);
+        sdpa_bwd_dq_block<D, CAUSAL, SLOW_TR, NW>(p, smem, s, hd, b);
+    }
+}
+
 // ===================================================================================================
 // backward, part 2: dK, dV.  A workgroup owns 128 keys (32 per wave, K/V fragments in registers) and streams
 // 32-row tiles of Q and dO (one dual-use LDS image each) from the diagonal to the end of the sequence.
 // ===================================================================================================
 template <int D, bool CAUSAL, bool SLOW_TR>
-__global__ __launch_bounds__(256, 1) void sdpa_bwd_dkv_kernel(const SdpaParams p) {
-    constexpr int BQ = 32, KS = D / 16, DT = D / 32;
+__device__ __forceinline__ void sdpa_bwd_dkv_block(const SdpaParams& p, char* smem, int s, int hd, int kb) {
+    // BQ query rows are staged per barrier and consumed as BQ/32 sub-tiles of 32 rows: the longer compute phase per
+    // staging step covers the L2/HBM latency of the next Q/dO tile with ONE tile in flight.
+    constexpr int BQ = DKV_BQ, SUB = BQ / 32, KS = D / 16, DT = D / 32;
     constexpr int TILE_BYTES = BQ * D * 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* q_lds = smem;                       // [2][BQ][D]
     char* do_lds = smem + 2 * TILE_BYTES;     // [2][BQ][D]
     float* lse_lds = reinterpret_cast<float*>(smem + 4 * TILE_BYTES);   // [2][BQ]
     float* dlt_lds = lse_lds + 2 * BQ;                                  // [2][BQ]
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-    const int s = blockIdx.z, hd = blockIdx.y;
-    const int kb = blockIdx.x;
     const int start = p.seq_start ? p.seq_start[s] : 0;
     const int len = p.seq_len ? p.seq_len[s] : p.T;
     const int64_t seq_row0 = (int64_t)s * p.T;
@@ -531,6 +577,7 @@ __global__ __launch_bounds__(256, 1) void sdpa_bwd_dkv_kernel(const SdpaParams p
         }
     const float sc = p.scale * kLog2e;
     const int wk_min = kblk_min + 32 * wave;   // smallest local key index of this wave
+    const bool wave_has_pad_keys = __any(!k_valid);
 
     Stage<D, BQ> qst, dst;
     const int64_t qrow0 = seq_row0 + start;
@@ -559,18 +606,21 @@ __global__ __launch_bounds__(256, 1) void sdpa_bwd_dkv_kernel(const SdpaParams p
     __syncthreads();
 
     for (int it = 0; it < ntiles; ++it) {
-        const int q0 = q_begin + it * BQ;
+        const int qt0 = q_begin + it * BQ;
         const char* qt = q_lds + (it & 1) * TILE_BYTES;
         const char* dot = do_lds + (it & 1) * TILE_BYTES;
         const float* lse_t = lse_lds + (it & 1) * BQ;
         const float* dlt_t = dlt_lds + (it & 1) * BQ;
         if (it + 1 < ntiles) {
-            qst.load(qp, p.ld_qkv, qrow0 + q0 + BQ, q0 + BQ, len);
-            dst.load(dop, p.ld_o, qrow0 + q0 + BQ, q0 + BQ, len);
-            load_stats(q0 + BQ);
+            qst.load(qp, p.ld_qkv, qrow0 + qt0 + BQ, qt0 + BQ, len);
+            dst.load(dop, p.ld_o, qrow0 + qt0 + BQ, qt0 + BQ, len);
+            load_stats(qt0 + BQ);
         }
-        const bool active = !CAUSAL || (q0 + BQ - 1 >= wk_min);
-        if (active) {
+#pragma unroll
+        for (int sub = 0; sub < SUB; ++sub) {
+            const int q0 = qt0 + 32 * sub;
+            const bool active = (q0 < len) && (!CAUSAL || (q0 + 31 >= wk_min));
+            if (!active) continue;
             // S[q][key] and dP[q][key]: key on the lane, q on the accumulator rows
             f32x16 sa, dpa;
 #pragma unroll
@@ -580,19 +630,20 @@ __global__ __launch_bounds__(256, 1) void sdpa_bwd_dkv_kernel(const SdpaParams p
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                sa = mfma32(frag_rows<D>(qt, 0, ks, lane), kf[ks], sa);
-                dpa = mfma32(frag_rows<D>(dot, 0, ks, lane), vf[ks], dpa);
+                sa = mfma32(frag_rows<D>(qt, 32 * sub, ks, lane), kf[ks], sa);
+                dpa = mfma32(frag_rows<D>(dot, 32 * sub, ks, lane), vf[ks], dpa);
             }
-            const bool need_mask = (q0 + BQ > len) || (CAUSAL && q0 < wk_min + 31);
+            if ((q0 + 32 > len) || (CAUSAL && q0 < wk_min + 31) || wave_has_pad_keys) {      // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = q0 + acc_row(r, h);
+                    if (ql >= len || (CAUSAL && kl > ql) || !k_valid) sa[r] = -INFINITY;      // -> P = 0
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int qr = acc_row(r, h);
-                float pr = __builtin_amdgcn_exp2f(sa[r] * sc - lse_t[qr]);
-                if (need_mask) {
-                    const int ql = q0 + qr;
-                    if (ql >= len || (CAUSAL && kl > ql)) pr = 0.f;
-                }
-                if (!k_valid) pr = 0.f;
+                const int qr = 32 * sub + acc_row(r, h);
+                const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], sc, -lse_t[qr]));
                 sa[r] = pr;                              // P
                 dpa[r] = pr * (dpa[r] - dlt_t[qr]);      // dZ
             }
@@ -602,8 +653,8 @@ __global__ __launch_bounds__(256, 1) void sdpa_bwd_dkv_kernel(const SdpaParams p
                 const s16x8 zb = acc_to_frag(dpa, ks);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    dvacc[dt] = mfma32(frag_cols<D, SLOW_TR>(dot, 16 * ks, 32 * dt, lane), pb, dvacc[dt]);
-                    dkacc[dt] = mfma32(frag_cols<D, SLOW_TR>(qt, 16 * ks, 32 * dt, lane), zb, dkacc[dt]);
+                    dvacc[dt] = mfma32(frag_cols<D, SLOW_TR>(dot, 32 * sub + 16 * ks, 32 * dt, lane), pb, dvacc[dt]);
+                    dkacc[dt] = mfma32(frag_cols<D, SLOW_TR>(qt, 32 * sub + 16 * ks, 32 * dt, lane), zb, dkacc[dt]);
                 }
             }
         }
@@ -620,24 +671,55 @@ __global__ __launch_bounds__(256, 1) void sdpa_bwd_dkv_kernel(const SdpaParams p
     }
 }
 
+template <int D, bool CAUSAL, bool SLOW_TR>
+__global__ __launch_bounds__(256, 1) void sdpa_bwd_dkv_kernel(const SdpaParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int s, hd, b;
+    if (CAUSAL) {      // key block b is visited by (nblk - b) query blocks: pair b with nblk-1-b
+        map_block(blockIdx.x, (p.nblk + 1) / 2, p.H, p.npairs, false, s, hd, b);
+        sdpa_bwd_dkv_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, b);
+        if (b != p.nblk - 1 - b) sdpa_bwd_dkv_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, p.nblk - 1 - b);
+    } else {
+        map_block(blockIdx.x, p.nblk, p.H, p.npairs, false, s, hd, b);
+        sdpa_bwd_dkv_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, b);
+    }
+}
+
 bool slow_tr_requested() {
     const char* e = getenv("HALVA_SDPA_SLOW_TR");
     return e && e[0] == '1';
 }
 
+int sdpa_waves() {
+    const char* e = getenv("HALVA_SDPA_NW");
+    return (e && e[0] == '4') ? 4 : 8;
+}
+
+template <typename KernelT>
+int launch_one(KernelT kern, SdpaParams p, bool causal, int rows_per_block, int threads, size_t lds, int S, hipStream_t st,
+               const char* name) {
+    p.nblk = (p.T + rows_per_block - 1) / rows_per_block;
+    p.npairs = S * p.H;
+    const int wg_per_pair = causal ? (p.nblk + 1) / 2 : p.nblk;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(wg_per_pair * p.npairs)), dim3(threads), lds, st, p);
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) {
+        halva_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));
+        return HALVA_ERR_LAUNCH;
+    }
+    return HALVA_OK;
+}
+
 template <int D, bool CAUSAL>
 int launch_fwd(const SdpaParams& p, int S, hipStream_t st) {
-    const dim3 grid((p.T + 127) / 128, p.H, S), block(256);
     const size_t lds = 4 * 64 * D * 2;
-    if (slow_tr_requested()) {
-        (void)hipFuncSetAttribute((const void*)sdpa_fwd_kernel<D, CAUSAL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((sdpa_fwd_kernel<D, CAUSAL, true>), grid, block, lds, st, p);
-    } else {
-        (void)hipFuncSetAttribute((const void*)sdpa_fwd_kernel<D, CAUSAL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((sdpa_fwd_kernel<D, CAUSAL, false>), grid, block, lds, st, p);
-    }
-    HALVA_CHECK_LAUNCH("sdpa_fwd");
-    return HALVA_OK;
+    const bool slow = slow_tr_requested();
+    if (sdpa_waves() == 8)
+        return slow ? launch_one(sdpa_fwd_kernel<D, CAUSAL, true, 8>, p, CAUSAL, 256, 512, lds, S, st, "sdpa_fwd")
+                    : launch_one(sdpa_fwd_kernel<D, CAUSAL, false, 8>, p, CAUSAL, 256, 512, lds, S, st, "sdpa_fwd");
+    return slow ? launch_one(sdpa_fwd_kernel<D, CAUSAL, true, 4>, p, CAUSAL, 128, 256, lds, S, st, "sdpa_fwd")
+                : launch_one(sdpa_fwd_kernel<D, CAUSAL, false, 4>, p, CAUSAL, 128, 256, lds, S, st, "sdpa_fwd");
 }
 
 template <int D, bool CAUSAL>
@@ -648,20 +730,19 @@ int launch_bwd(const SdpaParams& p, int S, hipStream_t st) {
         hipLaunchKernelGGL((sdpa_delta_kernel<D>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, total);
         HALVA_CHECK_LAUNCH("sdpa_delta");
     }
-    const dim3 grid((p.T + 127) / 128, p.H, S), block(256);
     const size_t lds_dq = 4 * 64 * D * 2;
-    const size_t lds_dkv = 4 * 32 * D * 2 + 4 * 32 * sizeof(float);
-    if (slow_tr_requested()) {
-        (void)hipFuncSetAttribute((const void*)sdpa_bwd_dq_kernel<D, CAUSAL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
-        hipLaunchKernelGGL((sdpa_bwd_dq_kernel<D, CAUSAL, true>), grid, block, lds_dq, st, p);
-        hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<D, CAUSAL, true>), grid, block, lds_dkv, st, p);
-    } else {
-        (void)hipFuncSetAttribute((const void*)sdpa_bwd_dq_kernel<D, CAUSAL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
-        hipLaunchKernelGGL((sdpa_bwd_dq_kernel<D, CAUSAL, false>), grid, block, lds_dq, st, p);
-        hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<D, CAUSAL, false>), grid, block, lds_dkv, st, p);
-    }
-    HALVA_CHECK_LAUNCH("sdpa_bwd");
-    return HALVA_OK;
+    const size_t lds_dkv = 4 * DKV_BQ * D * 2 + 4 * DKV_BQ * sizeof(float);
+    const bool slow = slow_tr_requested();
+    int rc;
+    if (sdpa_waves() == 8)
+        rc = slow ? launch_one(sdpa_bwd_dq_kernel<D, CAUSAL, true, 8>, p, CAUSAL, 256, 512, lds_dq, S, st, "sdpa_bwd_dq")
+                  : launch_one(sdpa_bwd_dq_kernel<D, CAUSAL, false, 8>, p, CAUSAL, 256, 512, lds_dq, S, st, "sdpa_bwd_dq");
+    else
+        rc = slow ? launch_one(sdpa_bwd_dq_kernel<D, CAUSAL, true, 4>, p, CAUSAL, 128, 256, lds_dq, S, st, "sdpa_bwd_dq")
+                  : launch_one(sdpa_bwd_dq_kernel<D, CAUSAL, false, 4>, p, CAUSAL, 128, 256, lds_dq, S, st, "sdpa_bwd_dq");
+    if (rc != HALVA_OK) return rc;
+    return slow ? launch_one(sdpa_bwd_dkv_kernel<D, CAUSAL, true>, p, CAUSAL, 128, 256, lds_dkv, S, st, "sdpa_bwd_dkv")
+                : launch_one(sdpa_bwd_dkv_kernel<D, CAUSAL, false>, p, CAUSAL, 128, 256, lds_dkv, S, st, "sdpa_bwd_dkv");
 }
 
 }  // namespace
