@@ -51,13 +51,15 @@ struct SdpaParams {
     float scale;          // softmax scale
 };
 
-// byte offset of 16-byte chunk `ch` of row `row` in a [rows][D] bf16 LDS tile
+// Byte offset of 16-byte chunk `ch` of row `row` in a [rows][D] bf16 LDS tile.  The tile is cut into 8-row x 32-column
+// subtiles of 512 B; inside a subtile the four chunks of a row are XOR-ed with (row >> 2) & 3.  Conflict-free for the
+// ds_read_b128 row reads of an MFMA A/B operand and for ds_read_b64_tr_b16 transposed reads alike, and - unlike a
+// whole-row XOR - every fragment address is one of TWO per-lane bases plus an immediate (ch >> 2 and row >> 3 only add
+// multiples of 512 B), which keeps ~40 VGPRs of address arithmetic out of the main loops.
 template <int D>
 __device__ __forceinline__ int tile_off(int row, int ch) {
-    if (D == 128)
-        return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
-    else
-        return row * 128 + ((ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))) << 4);
+    constexpr int SUBROW = (D / 32) * 512;   // bytes of one 8-row band
+    return SUBROW * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
 }
 
 __device__ __forceinline__ f32x16 mfma32(const s16x8& a, const s16x8& b, const f32x16& c) {
@@ -138,6 +140,16 @@ struct Stage {
                 r[i] = u32x4{0u, 0u, 0u, 0u};
         }
     }
+    // branch-free variant: rows outside [0, limit) read the nearest valid row (finite data; callers mask those rows)
+    __device__ __forceinline__ void load_clamped(const bf16_t* base, int64_t ld, int64_t grow_local0, int local0, int limit) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int cid = threadIdx.x + NT * i;
+            const int row = cid / NCH, ch = cid % NCH;
+            const int loc = min(max(local0 + row, 0), limit - 1);
+            r[i] = *reinterpret_cast<const u32x4*>(base + (grow_local0 + loc) * ld + ch * 8);
+        }
+    }
     __device__ __forceinline__ void store(char* tile) const {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
@@ -195,9 +207,15 @@ __device__ __forceinline__ void map_block(int L, int nblk, int H, int npairs, bo
 // ===================================================================================================
 // forward
 // ===================================================================================================
-template <int D, bool CAUSAL, bool SLOW_TR, int NW>
+// Forward: 8 waves x 32 query rows (two waves per SIMD), 64-key K/V tiles double-buffered in LDS, register staged
+// (the loads of tile t+1 are issued before the MFMAs of tile t and written to LDS after them; one barrier per tile).
+// Variants that were built and measured slower on MI355X at S=8,T=2048,H=32 (kept out of the tree, numbers in DESIGN.md):
+// 4 waves x 64 rows at one wave per SIMD, a half-tile stagger between the two halves of the workgroup, and an
+// in-wave S(t+1) || softmax(t) software pipeline (hipcc either keeps the streams in separate blocks or over-hoists
+// and spills).
+template <int D, bool CAUSAL, bool SLOW_TR>
 __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, int s, int hd, int qb) {
-    constexpr int BN = 64, KS = D / 16, DT = D / 32, BM = 32 * NW, NT = 64 * NW;
+    constexpr int NW = 8, BN = 64, KS = D / 16, DT = D / 32, BM = 32 * NW, NT = 64 * NW;
     constexpr int TILE_BYTES = BN * D * 2;
     char* k_lds = smem;                    // [2][BN][D]
     char* v_lds = smem + 2 * TILE_BYTES;   // [2][BN][D]
@@ -212,12 +230,10 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
     const bool q_in_T = gq < p.T;
     const bool q_valid = q_in_T && ql >= 0 && ql < len;
 
-    // key range this block needs (local indices)
-    int kv_end = len;
+    int kv_end = len;                                // key range this block needs (local indices)
     if (CAUSAL) kv_end = min(len, g0 + BM - start);
     const int ntiles = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
 
-    const bf16_t* qp = p.q + hd * D;
     const bf16_t* kp = p.k + hd * D;
     const bf16_t* vp = p.v + hd * D;
     bf16_t* orow = p.o + (seq_row0 + gq) * p.ld_o + hd * D;
@@ -235,7 +251,7 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         if (q_valid)
-            qf[ks] = *reinterpret_cast<const s16x8*>(qp + (seq_row0 + gq) * p.ld_qkv + 16 * ks + 8 * h);
+            qf[ks] = *reinterpret_cast<const s16x8*>(p.q + hd * D + (seq_row0 + gq) * p.ld_qkv + 16 * ks + 8 * h);
         else
             qf[ks] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
@@ -247,14 +263,13 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const float sc = p.scale * kLog2e;
-
-    // wave-level causal bounds (local indices)
-    const int wq_min = g0 + 32 * wave - start, wq_max = wq_min + 31;
+    const int wq_min = g0 + 32 * wave - start, wq_max = wq_min + 31;      // wave-level causal bounds (local indices)
 
     Stage<D, BN, NT> kst, vst;
     const int64_t krow0 = seq_row0 + start;
-    kst.load(kp, p.ld_qkv, krow0, 0, len);
-    vst.load(vp, p.ld_qkv, krow0, 0, len);
+    __syncthreads();      // the previous row block of this workgroup may still be reading its last tile
+    kst.load_clamped(kp, p.ld_qkv, krow0, 0, len);
+    vst.load_clamped(vp, p.ld_qkv, krow0, 0, len);
     kst.store(k_lds);
     vst.store(v_lds);
     __syncthreads();
@@ -264,11 +279,10 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
         const char* kt = k_lds + (it & 1) * TILE_BYTES;
         const char* vt = v_lds + (it & 1) * TILE_BYTES;
         if (it + 1 < ntiles) {
-            kst.load(kp, p.ld_qkv, krow0 + kv0 + BN, kv0 + BN, len);
-            vst.load(vp, p.ld_qkv, krow0 + kv0 + BN, kv0 + BN, len);
+            kst.load_clamped(kp, p.ld_qkv, krow0, kv0 + BN, len);
+            vst.load_clamped(vp, p.ld_qkv, krow0, kv0 + BN, len);
         }
-        const bool active = !CAUSAL || kv0 <= wq_max;
-        if (active) {
+        if (!CAUSAL || kv0 <= wq_max) {
             // ---- S^T[key][q] for the 64 keys of the tile
             f32x16 st[2];
 #pragma unroll
@@ -330,24 +344,23 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
     const float inv = (q_valid && l_tot > 0.f) ? 1.f / l_tot : 0.f;
     if (q_in_T) {
         store_rows_T<D>(orow, oacc, inv, true, lane);
-        if (h == 0 && p.lse)
-            p.lse[((int64_t)s * p.H + hd) * p.T + gq] = q_valid ? (m_run + log2f(l_tot)) * kLn2 : 0.f;
+        if (h == 0 && p.lse) p.lse[((int64_t)s * p.H + hd) * p.T + gq] = q_valid ? (m_run + log2f(l_tot)) * kLn2 : 0.f;
     }
 }
 
 // Under the causal mask row block b needs (b+1) units of work; one workgroup takes blocks b and nblk-1-b so every
 // workgroup does the same (nblk+1) units and the grid has no heavy tail.
-template <int D, bool CAUSAL, bool SLOW_TR, int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void sdpa_fwd_kernel(const SdpaParams p) {
+template <int D, bool CAUSAL, bool SLOW_TR>
+__global__ __launch_bounds__(512) void sdpa_fwd_kernel(const SdpaParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int s, hd, b;
     if (CAUSAL) {
         map_block(blockIdx.x, (p.nblk + 1) / 2, p.H, p.npairs, false, s, hd, b);
-        sdpa_fwd_block<D, CAUSAL, SLOW_TR, NW>(p, smem, s, hd, p.nblk - 1 - b);
-        if (b != p.nblk - 1 - b) sdpa_fwd_block<D, CAUSAL, SLOW_TR, NW>(p, smem, s, hd, b);
+        sdpa_fwd_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, p.nblk - 1 - b);
+        if (b != p.nblk - 1 - b) sdpa_fwd_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, b);
     } else {
         map_block(blockIdx.x, p.nblk, p.H, p.npairs, false, s, hd, b);
-        sdpa_fwd_block<D, CAUSAL, SLOW_TR, NW>(p, smem, s, hd, b);
+        sdpa_fwd_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, b);
     }
 }
 
@@ -437,8 +450,9 @@ __device__ __forceinline__ void sdpa_bwd_dq_block(const SdpaParams& p, char* sme
     const int wq_min = g0 + 32 * wave - start, wq_max = wq_min + 31;
     Stage<D, BN, NT> kst, vst;
     const int64_t krow0 = seq_row0 + start;
-    kst.load(kp, p.ld_qkv, krow0, 0, len);
-    vst.load(vp, p.ld_qkv, krow0, 0, len);
+    __syncthreads();      // the previous row block of this workgroup may still be reading its last tile
+    kst.load_clamped(kp, p.ld_qkv, krow0, 0, len);
+    vst.load_clamped(vp, p.ld_qkv, krow0, 0, len);
     kst.store(k_lds);
     vst.store(v_lds);
     __syncthreads();
@@ -448,8 +462,8 @@ __device__ __forceinline__ void sdpa_bwd_dq_block(const SdpaParams& p, char* sme
         const char* kt = k_lds + (it & 1) * TILE_BYTES;
         const char* vt = v_lds + (it & 1) * TILE_BYTES;
         if (it + 1 < ntiles) {
-            kst.load(kp, p.ld_qkv, krow0 + kv0 + BN, kv0 + BN, len);
-            vst.load(vp, p.ld_qkv, krow0 + kv0 + BN, kv0 + BN, len);
+            kst.load_clamped(kp, p.ld_qkv, krow0, kv0 + BN, len);
+            vst.load_clamped(vp, p.ld_qkv, krow0, kv0 + BN, len);
         }
         const bool active = !CAUSAL || kv0 <= wq_max;
         if (active) {
@@ -597,8 +611,9 @@ __device__ __forceinline__ void sdpa_bwd_dkv_block(const SdpaParams& p, char* sm
             dlt_lds[buf * BQ + threadIdx.x] = st_dlt;
         }
     };
-    qst.load(qp, p.ld_qkv, qrow0 + q_begin, q_begin, len);
-    dst.load(dop, p.ld_o, qrow0 + q_begin, q_begin, len);
+    __syncthreads();      // the previous key block of this workgroup may still be reading its last tile
+    qst.load_clamped(qp, p.ld_qkv, qrow0, q_begin, len);
+    dst.load_clamped(dop, p.ld_o, qrow0, q_begin, len);
     load_stats(q_begin);
     qst.store(q_lds);
     dst.store(do_lds);
@@ -612,8 +627,8 @@ __device__ __forceinline__ void sdpa_bwd_dkv_block(const SdpaParams& p, char* sm
         const float* lse_t = lse_lds + (it & 1) * BQ;
         const float* dlt_t = dlt_lds + (it & 1) * BQ;
         if (it + 1 < ntiles) {
-            qst.load(qp, p.ld_qkv, qrow0 + qt0 + BQ, qt0 + BQ, len);
-            dst.load(dop, p.ld_o, qrow0 + qt0 + BQ, qt0 + BQ, len);
+            qst.load_clamped(qp, p.ld_qkv, qrow0, qt0 + BQ, len);
+            dst.load_clamped(dop, p.ld_o, qrow0, qt0 + BQ, len);
             load_stats(qt0 + BQ);
         }
 #pragma unroll
@@ -641,11 +656,16 @@ __device__ __forceinline__ void sdpa_bwd_dkv_block(const SdpaParams& p, char* sm
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qr = 32 * sub + acc_row(r, h);
-                const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], sc, -lse_t[qr]));
-                sa[r] = pr;                              // P
-                dpa[r] = pr * (dpa[r] - dlt_t[qr]);      // dZ
+            for (int g = 0; g < 4; ++g) {      // registers 4g..4g+3 hold query rows 8g + 4h + (0..3): one 16-byte read each
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_t + 32 * sub + 8 * g + 4 * h);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dlt_t + 32 * sub + 8 * g + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g + j;
+                    const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], sc, -l4[j]));
+                    sa[r] = pr;                          // P
+                    dpa[r] = pr * (dpa[r] - d4[j]);      // dZ
+                }
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -690,11 +710,6 @@ bool slow_tr_requested() {
     return e && e[0] == '1';
 }
 
-int sdpa_waves() {
-    const char* e = getenv("HALVA_SDPA_NW");
-    return (e && e[0] == '4') ? 4 : 8;
-}
-
 template <typename KernelT>
 int launch_one(KernelT kern, SdpaParams p, bool causal, int rows_per_block, int threads, size_t lds, int S, hipStream_t st,
                const char* name) {
@@ -714,12 +729,8 @@ int launch_one(KernelT kern, SdpaParams p, bool causal, int rows_per_block, int 
 template <int D, bool CAUSAL>
 int launch_fwd(const SdpaParams& p, int S, hipStream_t st) {
     const size_t lds = 4 * 64 * D * 2;
-    const bool slow = slow_tr_requested();
-    if (sdpa_waves() == 8)
-        return slow ? launch_one(sdpa_fwd_kernel<D, CAUSAL, true, 8>, p, CAUSAL, 256, 512, lds, S, st, "sdpa_fwd")
-                    : launch_one(sdpa_fwd_kernel<D, CAUSAL, false, 8>, p, CAUSAL, 256, 512, lds, S, st, "sdpa_fwd");
-    return slow ? launch_one(sdpa_fwd_kernel<D, CAUSAL, true, 4>, p, CAUSAL, 128, 256, lds, S, st, "sdpa_fwd")
-                : launch_one(sdpa_fwd_kernel<D, CAUSAL, false, 4>, p, CAUSAL, 128, 256, lds, S, st, "sdpa_fwd");
+    return slow_tr_requested() ? launch_one(sdpa_fwd_kernel<D, CAUSAL, true>, p, CAUSAL, 256, 512, lds, S, st, "sdpa_fwd")
+                               : launch_one(sdpa_fwd_kernel<D, CAUSAL, false>, p, CAUSAL, 256, 512, lds, S, st, "sdpa_fwd");
 }
 
 template <int D, bool CAUSAL>
@@ -733,13 +744,8 @@ int launch_bwd(const SdpaParams& p, int S, hipStream_t st) {
     const size_t lds_dq = 4 * 64 * D * 2;
     const size_t lds_dkv = 4 * DKV_BQ * D * 2 + 4 * DKV_BQ * sizeof(float);
     const bool slow = slow_tr_requested();
-    int rc;
-    if (sdpa_waves() == 8)
-        rc = slow ? launch_one(sdpa_bwd_dq_kernel<D, CAUSAL, true, 8>, p, CAUSAL, 256, 512, lds_dq, S, st, "sdpa_bwd_dq")
-                  : launch_one(sdpa_bwd_dq_kernel<D, CAUSAL, false, 8>, p, CAUSAL, 256, 512, lds_dq, S, st, "sdpa_bwd_dq");
-    else
-        rc = slow ? launch_one(sdpa_bwd_dq_kernel<D, CAUSAL, true, 4>, p, CAUSAL, 128, 256, lds_dq, S, st, "sdpa_bwd_dq")
-                  : launch_one(sdpa_bwd_dq_kernel<D, CAUSAL, false, 4>, p, CAUSAL, 128, 256, lds_dq, S, st, "sdpa_bwd_dq");
+    const int rc = slow ? launch_one(sdpa_bwd_dq_kernel<D, CAUSAL, true, 8>, p, CAUSAL, 256, 512, lds_dq, S, st, "sdpa_bwd_dq")
+                        : launch_one(sdpa_bwd_dq_kernel<D, CAUSAL, false, 8>, p, CAUSAL, 256, 512, lds_dq, S, st, "sdpa_bwd_dq");
     if (rc != HALVA_OK) return rc;
     return slow ? launch_one(sdpa_bwd_dkv_kernel<D, CAUSAL, true>, p, CAUSAL, 128, 256, lds_dkv, S, st, "sdpa_bwd_dkv")
                 : launch_one(sdpa_bwd_dkv_kernel<D, CAUSAL, false>, p, CAUSAL, 128, 256, lds_dkv, S, st, "sdpa_bwd_dkv");
