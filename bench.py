@@ -197,6 +197,7 @@ def main():
                     getattr(grp, n).lora_B["default"].weight.normal_(0.0, 0.01, generator=gB)
     ref = build_random_llava(geo, CLIP_L_336, seed=1234, device=dev, max_len=2048, share_base_from=policy)
     flat = dpa.FlatTrainables(dpa.trainable_named_parameters(policy))
+    dpa.bind_model(flat, policy)
     dpa.set_grad_sink(policy, True)
     opt = dpa.AdamWFlat(flat, lr=5e-6, weight_decay=0.0, mm_projector_lr=0.0)
     eng = dpa.DPAEngine(policy, ref, 0.4, pairs_per_group=args.pairs_per_group, ref_rows_per_group=2 * args.pairs_per_group)

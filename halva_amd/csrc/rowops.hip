@@ -27,7 +27,7 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ w,
                                                           u32x4* __restrict__ y, float* __restrict__ rstd, int64_t rows,
-                                                          int nchunk, float eps, float inv_d) {
+                                                          int nchunk, int64_t ldy_chunks, float eps, float inv_d) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const u32x4* __restric
     ss = wave_sum(ss);
     const float r = rsqrtf(ss * inv_d + eps);
     if (lane == 0) rstd[row] = r;
-    u32x4* yr = y + row * nchunk;
+    u32x4* yr = y + row * ldy_chunks;
 #pragma unroll
     for (int i = 0; i < kMaxChunks; ++i) {
         const int c = lane + 64 * i;
@@ -66,12 +66,13 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const u32x4* __restric
 // dx = r * (g - n * mean(g * n)),  g = dy * w,  n = x * r
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ x,
                                                           const u32x4* __restrict__ w, const float* __restrict__ rstd,
-                                                          u32x4* __restrict__ dx, int64_t rows, int nchunk, float inv_d) {
+                                                          u32x4* __restrict__ dx, int64_t rows, int nchunk, int64_t lddy_chunks,
+                                                          float inv_d) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row >= rows) return;
     const u32x4* xr = x + row * nchunk;
-    const u32x4* dyr = dy + row * nchunk;
+    const u32x4* dyr = dy + row * lddy_chunks;
     const float r = rstd[row];
     u32x4 bx[kMaxChunks], bg[kMaxChunks];   // bg holds g = dy * w packed back as two-halves? keep dy, recompute g
     float dot = 0.f;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(u32x4* __restrict__ qkv, c
 // SwiGLU on packed gate|up rows
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const u32x4* __restrict__ gu, u32x4* __restrict__ out,
-                                                         int chunksF, int64_t total) {
+                                                         int chunksF, int64_t ldo_chunks, int64_t total) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = i / chunksF;
         const int c = (int)(i - row * chunksF);
@@ -152,19 +153,19 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const u32x4* __restrict
         unpack8(gu[row * 2 * chunksF + chunksF + c], u);
 #pragma unroll
         for (int j = 0; j < 8; ++j) g[j] = bf16_round(g[j] / (1.f + __expf(-g[j]))) * u[j];
-        out[i] = pack8(g);
+        out[row * ldo_chunks + c] = pack8(g);
     }
 }
 
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const u32x4* __restrict__ dout, const u32x4* __restrict__ gu,
-                                                         u32x4* __restrict__ dgu, int chunksF, int64_t total) {
+                                                         u32x4* __restrict__ dgu, int chunksF, int64_t lddo_chunks, int64_t total) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = i / chunksF;
         const int c = (int)(i - row * chunksF);
         float g[8], u[8], d[8], dg[8], du[8];
         unpack8(gu[row * 2 * chunksF + c], g);
         unpack8(gu[row * 2 * chunksF + chunksF + c], u);
-        unpack8(dout[i], d);
+        unpack8(dout[row * lddo_chunks + c], d);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float sg = 1.f / (1.f + __expf(-g[j]));
@@ -202,26 +203,38 @@ inline int grid_for(int64_t total, int block) {
 
 extern "C" int halva_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int d, float eps,
                                  void* stream) {
+    return halva_rmsnorm_fwd_ld(x, w, y, d, rstd, rows, d, eps, stream);
+}
+
+extern "C" int halva_rmsnorm_fwd_ld(const void* x, const void* w, void* y, int64_t ldy, float* rstd, int64_t rows, int d,
+                                    float eps, void* stream) {
     HALVA_CHECK_ARG(x && w && y && rstd, "rmsnorm_fwd: null pointer");
+    HALVA_CHECK_ARG(ldy >= d && ldy % 8 == 0, "rmsnorm_fwd: output row stride %lld must be >= d and a multiple of 8", (long long)ldy);
     HALVA_CHECK_ARG(d > 0 && d % 8 == 0 && d <= 8 * 64 * kMaxChunks, "rmsnorm_fwd: d=%d must be a multiple of 8 and <= %d", d,
                     8 * 64 * kMaxChunks);
     if (rows <= 0) return HALVA_OK;
     const int blocks = (int)((rows + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, (const u32x4*)w,
-                       (u32x4*)y, rstd, rows, d / 8, eps, 1.f / d);
+                       (u32x4*)y, rstd, rows, d / 8, ldy / 8, eps, 1.f / d);
     HALVA_CHECK_LAUNCH("rmsnorm_fwd");
     return HALVA_OK;
 }
 
 extern "C" int halva_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, int64_t rows,
                                  int d, void* stream) {
+    return halva_rmsnorm_bwd_ld(dy, d, x, w, rstd, dx, rows, d, stream);
+}
+
+extern "C" int halva_rmsnorm_bwd_ld(const void* dy, int64_t lddy, const void* x, const void* w, const float* rstd, void* dx,
+                                    int64_t rows, int d, void* stream) {
     HALVA_CHECK_ARG(dy && x && w && rstd && dx, "rmsnorm_bwd: null pointer");
+    HALVA_CHECK_ARG(lddy >= d && lddy % 8 == 0, "rmsnorm_bwd: dy row stride %lld must be >= d and a multiple of 8", (long long)lddy);
     HALVA_CHECK_ARG(d > 0 && d % 8 == 0 && d <= 8 * 64 * kMaxChunks, "rmsnorm_bwd: d=%d must be a multiple of 8 and <= %d", d,
                     8 * 64 * kMaxChunks);
     if (rows <= 0) return HALVA_OK;
     const int blocks = (int)((rows + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)dy, (const u32x4*)x,
-                       (const u32x4*)w, rstd, (u32x4*)dx, rows, d / 8, 1.f / d);
+                       (const u32x4*)w, rstd, (u32x4*)dx, rows, d / 8, lddy / 8, 1.f / d);
     HALVA_CHECK_LAUNCH("rmsnorm_bwd");
     return HALVA_OK;
 }
@@ -242,23 +255,33 @@ extern "C" int halva_rope_qk(void* qkv, const void* cos, const void* sin, const 
 }
 
 extern "C" int halva_swiglu_fwd(const void* gu, void* out, int64_t rows, int F, void* stream) {
+    return halva_swiglu_fwd_ld(gu, out, F, rows, F, stream);
+}
+
+extern "C" int halva_swiglu_fwd_ld(const void* gu, void* out, int64_t ldo, int64_t rows, int F, void* stream) {
     HALVA_CHECK_ARG(gu && out, "swiglu_fwd: null pointer");
+    HALVA_CHECK_ARG(ldo >= F && ldo % 8 == 0, "swiglu_fwd: output row stride %lld must be >= F and a multiple of 8", (long long)ldo);
     HALVA_CHECK_ARG(F > 0 && F % 8 == 0, "swiglu_fwd: F=%d must be a multiple of 8", F);
     if (rows <= 0) return HALVA_OK;
     const int64_t total = rows * (F / 8);
     hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)gu,
-                       (u32x4*)out, F / 8, total);
+                       (u32x4*)out, F / 8, ldo / 8, total);
     HALVA_CHECK_LAUNCH("swiglu_fwd");
     return HALVA_OK;
 }
 
 extern "C" int halva_swiglu_bwd(const void* dout, const void* gu, void* dgu, int64_t rows, int F, void* stream) {
+    return halva_swiglu_bwd_ld(dout, F, gu, dgu, rows, F, stream);
+}
+
+extern "C" int halva_swiglu_bwd_ld(const void* dout, int64_t lddo, const void* gu, void* dgu, int64_t rows, int F, void* stream) {
     HALVA_CHECK_ARG(dout && gu && dgu, "swiglu_bwd: null pointer");
+    HALVA_CHECK_ARG(lddo >= F && lddo % 8 == 0, "swiglu_bwd: dout row stride %lld must be >= F and a multiple of 8", (long long)lddo);
     HALVA_CHECK_ARG(F > 0 && F % 8 == 0, "swiglu_bwd: F=%d must be a multiple of 8", F);
     if (rows <= 0) return HALVA_OK;
     const int64_t total = rows * (F / 8);
     hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)dout,
-                       (const u32x4*)gu, (u32x4*)dgu, F / 8, total);
+                       (const u32x4*)gu, (u32x4*)dgu, F / 8, lddo / 8, total);
     HALVA_CHECK_LAUNCH("swiglu_bwd");
     return HALVA_OK;
 }

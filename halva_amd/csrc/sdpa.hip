@@ -45,7 +45,8 @@ struct SdpaParams {
     const int32_t* seq_start;
     const int32_t* seq_len;
     int64_t ld_qkv;       // elements between consecutive tokens in q/k/v
-    int64_t ld_o;         // elements between consecutive tokens in out / dout
+    int64_t ld_o;         // elements between consecutive tokens in out
+    int64_t ld_do;        // elements between consecutive tokens in dout
     int T, H;
     int nblk, npairs;     // row blocks per (sequence, head) pair; number of pairs (S * H)
     float scale;          // softmax scale
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256) void sdpa_delta_kernel(const SdpaParams p, int
         tok = gid / p.H;
         hd = (int)(gid % p.H);
         const u32x4 a = *reinterpret_cast<const u32x4*>(p.o_in + tok * p.ld_o + hd * D + c * 8);
-        const u32x4 b = *reinterpret_cast<const u32x4*>(p.d_o + tok * p.ld_o + hd * D + c * 8);
+        const u32x4 b = *reinterpret_cast<const u32x4*>(p.d_o + tok * p.ld_do + hd * D + c * 8);
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc += bf16_lo(a[i]) * bf16_lo(b[i]) + bf16_hi(a[i]) * bf16_hi(b[i]);
     }
@@ -430,7 +431,7 @@ __device__ __forceinline__ void sdpa_bwd_dq_block(const SdpaParams& p, char* sme
     for (int ks = 0; ks < KS; ++ks) {
         if (q_valid) {
             qf[ks] = *reinterpret_cast<const s16x8*>(qp + (seq_row0 + gq) * p.ld_qkv + 16 * ks + 8 * h);
-            dof[ks] = *reinterpret_cast<const s16x8*>(p.d_o + (seq_row0 + gq) * p.ld_o + hd * D + 16 * ks + 8 * h);
+            dof[ks] = *reinterpret_cast<const s16x8*>(p.d_o + (seq_row0 + gq) * p.ld_do + hd * D + 16 * ks + 8 * h);
         } else {
             qf[ks] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
             dof[ks] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -613,7 +614,7 @@ __device__ __forceinline__ void sdpa_bwd_dkv_block(const SdpaParams& p, char* sm
     };
     __syncthreads();      // the previous key block of this workgroup may still be reading its last tile
     qst.load_clamped(qp, p.ld_qkv, qrow0, q_begin, len);
-    dst.load_clamped(dop, p.ld_o, qrow0, q_begin, len);
+    dst.load_clamped(dop, p.ld_do, qrow0, q_begin, len);
     load_stats(q_begin);
     qst.store(q_lds);
     dst.store(do_lds);
@@ -628,7 +629,7 @@ __device__ __forceinline__ void sdpa_bwd_dkv_block(const SdpaParams& p, char* sm
         const float* dlt_t = dlt_lds + (it & 1) * BQ;
         if (it + 1 < ntiles) {
             qst.load_clamped(qp, p.ld_qkv, qrow0, qt0 + BQ, len);
-            dst.load_clamped(dop, p.ld_o, qrow0, qt0 + BQ, len);
+            dst.load_clamped(dop, p.ld_do, qrow0, qt0 + BQ, len);
             load_stats(qt0 + BQ);
         }
 #pragma unroll
@@ -755,7 +756,13 @@ int launch_bwd(const SdpaParams& p, int S, hipStream_t st) {
 
 extern "C" int halva_sdpa_causal_fwd(const void* qkv, void* out, float* lse, const int32_t* seq_start, const int32_t* seq_len,
                                      int S, int T, int H, int D, float scale, void* stream) {
+    return halva_sdpa_causal_fwd_ld(qkv, out, (int64_t)H * D, lse, seq_start, seq_len, S, T, H, D, scale, stream);
+}
+
+extern "C" int halva_sdpa_causal_fwd_ld(const void* qkv, void* out, int64_t ld_out, float* lse, const int32_t* seq_start,
+                                        const int32_t* seq_len, int S, int T, int H, int D, float scale, void* stream) {
     HALVA_CHECK_ARG(qkv && out && lse, "sdpa_causal_fwd: null pointer");
+    HALVA_CHECK_ARG(ld_out >= (int64_t)H * D && ld_out % 8 == 0, "sdpa_causal_fwd: bad output row stride %lld", (long long)ld_out);
     HALVA_CHECK_ARG(D == 128 || D == 64, "sdpa_causal_fwd: head_dim %d not supported (64 or 128)", D);
     HALVA_CHECK_ARG(S > 0 && T > 0 && H > 0, "sdpa_causal_fwd: bad sizes");
     SdpaParams p{};
@@ -768,7 +775,7 @@ extern "C" int halva_sdpa_causal_fwd(const void* qkv, void* out, float* lse, con
     p.seq_start = seq_start;
     p.seq_len = seq_len;
     p.ld_qkv = 3 * (int64_t)H * D;
-    p.ld_o = (int64_t)H * D;
+    p.ld_o = ld_out;
     p.T = T;
     p.H = H;
     p.scale = scale > 0.f ? scale : 1.f / sqrtf((float)D);
@@ -778,7 +785,16 @@ extern "C" int halva_sdpa_causal_fwd(const void* qkv, void* out, float* lse, con
 extern "C" int halva_sdpa_causal_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                                      float* delta_ws, float* dq_ws, const int32_t* seq_start, const int32_t* seq_len, int S,
                                      int T, int H, int D, float scale, void* stream) {
-    (void)dq_ws;   // reserved for an atomics-based dQ variant; the shipped dQ kernel needs no scratch
+    return halva_sdpa_causal_bwd_ld(qkv, out, (int64_t)H * D, dout, (int64_t)H * D, lse, dqkv, delta_ws, dq_ws, seq_start, seq_len,
+                                    S, T, H, D, scale, stream);
+}
+
+extern "C" int halva_sdpa_causal_bwd_ld(const void* qkv, const void* out, int64_t ld_out, const void* dout, int64_t ld_dout,
+                                        const float* lse, void* dqkv, float* delta_ws, float* dq_ws, const int32_t* seq_start,
+                                        const int32_t* seq_len, int S, int T, int H, int D, float scale, void* stream) {
+    (void)dq_ws;
+    HALVA_CHECK_ARG(ld_out >= (int64_t)H * D && ld_out % 8 == 0 && ld_dout >= (int64_t)H * D && ld_dout % 8 == 0,
+                    "sdpa_causal_bwd: bad row strides %lld / %lld", (long long)ld_out, (long long)ld_dout);   // reserved for an atomics-based dQ variant; the shipped dQ kernel needs no scratch
     HALVA_CHECK_ARG(qkv && out && dout && lse && dqkv && delta_ws, "sdpa_causal_bwd: null pointer");
     HALVA_CHECK_ARG(D == 128 || D == 64, "sdpa_causal_bwd: head_dim %d not supported (64 or 128)", D);
     HALVA_CHECK_ARG(S > 0 && T > 0 && H > 0, "sdpa_causal_bwd: bad sizes");
@@ -798,7 +814,8 @@ extern "C" int halva_sdpa_causal_bwd(const void* qkv, const void* out, const voi
     p.seq_start = seq_start;
     p.seq_len = seq_len;
     p.ld_qkv = 3 * (int64_t)H * D;
-    p.ld_o = (int64_t)H * D;
+    p.ld_o = ld_out;
+    p.ld_do = ld_dout;
     p.T = T;
     p.H = H;
     p.scale = scale > 0.f ? scale : 1.f / sqrtf((float)D);

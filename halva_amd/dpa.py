@@ -310,6 +310,7 @@ class FlatTrainables:
             p.grad_sink = True
         self.master = self.flat.float()
         self.total = total
+        self.post_sync = []          # callbacks run after the bf16 compute copy was refreshed from the fp32 master
 
     def segment(self, pred):
         """Contiguous [lo, hi) covering the parameters whose name satisfies pred (they must be adjacent)."""
@@ -324,6 +325,15 @@ class FlatTrainables:
 
     def sync_compute_copy(self):
         self.flat.copy_(self.master)
+        for fn in self.post_sync:
+            fn()
+
+
+def bind_model(flat, model):
+    """After every optimizer step the fused LoRA weights of `model` must pick up the new B factors."""
+    from .llama import refresh_lora
+    flat.post_sync.append(lambda: refresh_lora(model))
+    refresh_lora(model)
 
 
 def set_grad_sink(model, on=True):

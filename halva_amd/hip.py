@@ -18,6 +18,12 @@ _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "halva_rmsnorm_fwd": [_P, _P, _P, _P, _L, _I, _F, _P],
     "halva_rmsnorm_bwd": [_P, _P, _P, _P, _P, _L, _I, _P],
+    "halva_rmsnorm_fwd_ld": [_P, _P, _P, _L, _P, _L, _I, _F, _P],
+    "halva_rmsnorm_bwd_ld": [_P, _L, _P, _P, _P, _P, _L, _I, _P],
+    "halva_swiglu_fwd_ld": [_P, _P, _L, _L, _I, _P],
+    "halva_swiglu_bwd_ld": [_P, _L, _P, _P, _L, _I, _P],
+    "halva_sdpa_causal_fwd_ld": [_P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "halva_sdpa_causal_bwd_ld": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "halva_rope_qk": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
     "halva_swiglu_fwd": [_P, _P, _L, _I, _P],
     "halva_swiglu_bwd": [_P, _P, _P, _L, _I, _P],

@@ -25,17 +25,21 @@ def _chk(t, dtype=None, name="tensor"):
 
 # ------------------------------------------------------------------------------------------------
 class _RMSNorm(torch.autograd.Function):
-    """LlamaRMSNorm.forward (modelling_llama.py:65-70).  Weight is frozen on the DPA path -> dx only."""
+    """LlamaRMSNorm.forward (modelling_llama.py:65-70).  Weight is frozen on the DPA path -> dx only.
+    out_width > d: the rows are written into the left d columns of a [.., out_width] buffer (the operand buffer of the
+    next LoRA projection, whose right columns that projection fills) and the incoming gradient has that width too."""
 
     @staticmethod
-    def forward(ctx, x, w, eps):
+    def forward(ctx, x, w, eps, out_width):
         _chk(x, torch.bfloat16, "x"), _chk(w, torch.bfloat16, "w")
         d = x.shape[-1]
         rows = x.numel() // d
-        y = torch.empty_like(x)
+        width = out_width or d
+        y = torch.empty(*x.shape[:-1], width, dtype=x.dtype, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-        call("halva_rmsnorm_fwd", ptr(x), ptr(w), ptr(y), ptr(rstd), rows, d, float(eps), stream_ptr())
+        call("halva_rmsnorm_fwd_ld", ptr(x), ptr(w), ptr(y), width, ptr(rstd), rows, d, float(eps), stream_ptr())
         ctx.save_for_backward(x, w, rstd)
+        ctx.width = width
         return y
 
     @staticmethod
@@ -44,12 +48,12 @@ class _RMSNorm(torch.autograd.Function):
         dy = _chk(dy.contiguous(), torch.bfloat16, "dy")
         dx = torch.empty_like(x)
         d = x.shape[-1]
-        call("halva_rmsnorm_bwd", ptr(dy), ptr(x), ptr(w), ptr(rstd), ptr(dx), x.numel() // d, d, stream_ptr())
-        return dx, None, None
+        call("halva_rmsnorm_bwd_ld", ptr(dy), ctx.width, ptr(x), ptr(w), ptr(rstd), ptr(dx), x.numel() // d, d, stream_ptr())
+        return dx, None, None, None
 
 
-def rmsnorm(x, w, eps):
-    return _RMSNorm.apply(x, w, eps)
+def rmsnorm(x, w, eps, out_width=None):
+    return _RMSNorm.apply(x, w, eps, out_width)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -88,37 +92,42 @@ class _SdpaCausal(torch.autograd.Function):
     the inverse rotation to dq, dk (see _RopeQK)."""
 
     @staticmethod
-    def forward(ctx, qkv, seq_start, seq_len, H, D, cos, sin):
+    def forward(ctx, qkv, seq_start, seq_len, H, D, cos, sin, out_width=None):
         _chk(qkv, torch.bfloat16, "qkv")
         S, T = qkv.shape[0], qkv.shape[1]
-        out = torch.empty(S, T, H * D, dtype=torch.bfloat16, device=qkv.device)
+        width = out_width or H * D
+        out = torch.empty(S, T, width, dtype=torch.bfloat16, device=qkv.device)
         lse = torch.empty(S, H, T, dtype=torch.float32, device=qkv.device)
-        call("halva_sdpa_causal_fwd", ptr(qkv), ptr(out), ptr(lse), ptr(seq_start), ptr(seq_len), S, T, H, D, 0.0,
+        call("halva_sdpa_causal_fwd_ld", ptr(qkv), ptr(out), width, ptr(lse), ptr(seq_start), ptr(seq_len), S, T, H, D, 0.0,
              stream_ptr())
-        ctx.save_for_backward(qkv, out, lse, seq_start, seq_len)
+        ctx.save_for_backward(qkv, lse, seq_start, seq_len)
+        # `out` may be the (wider) operand buffer of the next LoRA projection, which fills its right columns in place; the
+        # backward only reads the left H*D columns, so keep a detached alias instead of a version-checked saved tensor
+        ctx.out_alias = out.detach()
         ctx.rope = (cos, sin)
-        ctx.dims = (S, T, H, D)
+        ctx.dims = (S, T, H, D, width)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, out, lse, seq_start, seq_len = ctx.saved_tensors
-        S, T, H, D = ctx.dims
+        qkv, lse, seq_start, seq_len = ctx.saved_tensors
+        out = ctx.out_alias
+        S, T, H, D, width = ctx.dims
         dout = _chk(dout.contiguous(), torch.bfloat16, "dout")
         dqkv = torch.empty_like(qkv)
         delta = torch.empty(S, H, T, dtype=torch.float32, device=qkv.device)
-        call("halva_sdpa_causal_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), None, ptr(seq_start),
-             ptr(seq_len), S, T, H, D, 0.0, stream_ptr())
+        call("halva_sdpa_causal_bwd_ld", ptr(qkv), ptr(out), width, ptr(dout), dout.shape[-1], ptr(lse), ptr(dqkv), ptr(delta),
+             None, ptr(seq_start), ptr(seq_len), S, T, H, D, 0.0, stream_ptr())
         cos, sin = ctx.rope
         if cos is not None:
             _rope_inplace(dqkv, cos, sin, T, H, D, True)
-        return dqkv, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None
 
 
-def attention(qkv, cos, sin, seq_start, seq_len, H, D):
+def attention(qkv, cos, sin, seq_start, seq_len, H, D, out_width=None):
     """RoPE (in place) + causal attention on a packed [S, T, 3*H*D] projection output."""
     qkv = _RopeQK.apply(qkv, cos, sin, H, D)
-    return _SdpaCausal.apply(qkv, seq_start, seq_len, H, D, cos, sin)
+    return _SdpaCausal.apply(qkv, seq_start, seq_len, H, D, cos, sin, out_width)
 
 
 def sdpa_causal(qkv, seq_start, seq_len, H, D):
@@ -136,16 +145,19 @@ def sdpa_full(qkv, H, D):
 
 # ------------------------------------------------------------------------------------------------
 class _SwiGLU(torch.autograd.Function):
-    """act_fn(gate) * up (modelling_llama.py:197) on a fused [rows, 2F] gate|up buffer."""
+    """act_fn(gate) * up (modelling_llama.py:197) on a fused [rows, 2F] gate|up buffer; optional wider output buffer
+    (see _RMSNorm)."""
 
     @staticmethod
-    def forward(ctx, gu):
+    def forward(ctx, gu, out_width):
         _chk(gu, torch.bfloat16, "gu")
         F2 = gu.shape[-1]
         rows = gu.numel() // F2
-        out = torch.empty(*gu.shape[:-1], F2 // 2, dtype=torch.bfloat16, device=gu.device)
-        call("halva_swiglu_fwd", ptr(gu), ptr(out), rows, F2 // 2, stream_ptr())
+        width = out_width or F2 // 2
+        out = torch.empty(*gu.shape[:-1], width, dtype=torch.bfloat16, device=gu.device)
+        call("halva_swiglu_fwd_ld", ptr(gu), ptr(out), width, rows, F2 // 2, stream_ptr())
         ctx.save_for_backward(gu)
+        ctx.width = width
         return out
 
     @staticmethod
@@ -154,12 +166,12 @@ class _SwiGLU(torch.autograd.Function):
         dout = _chk(dout.contiguous(), torch.bfloat16, "dout")
         dgu = torch.empty_like(gu)
         F2 = gu.shape[-1]
-        call("halva_swiglu_bwd", ptr(dout), ptr(gu), ptr(dgu), gu.numel() // F2, F2 // 2, stream_ptr())
-        return dgu
+        call("halva_swiglu_bwd_ld", ptr(dout), ctx.width, ptr(gu), ptr(dgu), gu.numel() // F2, F2 // 2, stream_ptr())
+        return dgu, None
 
 
-def swiglu(gu):
-    return _SwiGLU.apply(gu)
+def swiglu(gu, out_width=None):
+    return _SwiGLU.apply(gu, out_width)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -67,69 +67,75 @@ LORA_TARGETS = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", 
 
 
 class _LoraGroupFn(torch.autograd.Function):
-    """y = [residual +] x W^T + scale * concat_g( (x A_g^T) B_g^T )  for G LoRA targets sharing one fused base weight.
+    """y = [residual +] x W^T + scale * concat_g( (x A_g^T) B_g^T )  for G LoRA targets sharing one fused base weight -
+    peft 0.4.0 Linear.forward (result += lora_B(lora_A(dropout(x))) * scaling; dropout forced to 0 by the reference,
+    llava/train/halva_trainer.py:35-38,184-187) - computed as ONE GEMM over a K-concatenated operand:
 
-    peft 0.4.0 Linear.forward semantics (result += lora_B(lora_A(dropout(x))) * scaling; dropout forced to 0 by the
-    reference, llava/train/halva_trainer.py:35-38,184-187).  Base weight frozen: backward yields dx, dA, dB only.
-    With `sink` set the LoRA grads are added into the parameters' fp32 `main_grad` views and None is returned."""
+        xa = [ x | x A_cat^T ]  (rows x (K + G r));   Wc = [ W | blockdiag(scale * B_g) ]  (N x (K + G r));   y = xa Wc^T
+
+    so the low-rank update rides in the big GEMM instead of a read-modify-write pass over y (measured 0.19-0.38 ms per
+    projection at 16k tokens, ~25 % on top of the base GEMMs).  The producer kernel (RMSNorm / attention / SwiGLU) wrote x
+    straight into the left K columns of xa.  Backward: dxa = dy Wc gives [dx_base | scale * dy_g B_g] in one GEMM.
+    Base weight frozen: gradients for x, A, B only; with `sink` they are added into the fp32 `main_grad` views."""
 
     @staticmethod
-    def forward(ctx, x, residual, W, A, scale, sink, *Bs):
-        d_in = x.shape[-1]
-        x2 = x.reshape(-1, d_in)
-        N = W.shape[0]
-        out = torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)   # returned as-is (not a view): later
-        y = out.view(-1, N)                                                     # in-place kernels (RoPE) may dirty it
-        if residual is None:
-            torch.mm(x2, W.t(), out=y)
+    def forward(ctx, xa, residual, Wc, A, scale, sink, K, *Bs):
+        width = xa.shape[-1]
+        xa2 = xa.view(-1, width)
+        N = Wc.shape[0]
+        out = torch.empty(*xa.shape[:-1], N, dtype=xa.dtype, device=xa.device)   # returned as-is (not a view): later
+        y = out.view(-1, N)                                                        # in-place kernels (RoPE) may dirty it
+        lora = A is not None
+        if lora:
+            Gr = A.shape[0]
+            xa2[:, K:K + Gr].copy_(torch.mm(xa2[:, :K], A.t()))
+            if K + Gr < width:
+                xa2[:, K + Gr:].zero_()          # padding columns (rank not a multiple of 8) must not hold NaN garbage
+            lhs, rhs = xa2, Wc
         else:
-            torch.addmm(residual.reshape(-1, N), x2, W.t(), out=y)
-        a = None
-        if A is not None:
-            r = A.shape[0] // len(Bs)
-            a = torch.mm(x2, A.t())
-            off = 0
-            for g, B in enumerate(Bs):
-                n = B.shape[0]
-                y[:, off:off + n].addmm_(a[:, g * r:(g + 1) * r], B.t(), alpha=scale)
-                off += n
-        ctx.save_for_backward(x2, a)
-        ctx.params = (W, A, Bs)            # long-lived parameters: kept as objects so `.main_grad` stays reachable
-        ctx.scale, ctx.sink, ctx.has_res = scale, sink, residual is not None
-        ctx.x_shape = x.shape
+            lhs, rhs = xa2[:, :K], Wc[:, :K]
+        if residual is None:
+            torch.mm(lhs, rhs.t(), out=y)
+        else:
+            torch.addmm(residual.reshape(-1, N), lhs, rhs.t(), out=y)
+        ctx.save_for_backward(xa)          # the input itself (its right columns were filled above), not the internal view
+        ctx.params = (Wc, A, Bs)           # long-lived parameters: kept as objects so `.main_grad` stays reachable
+        ctx.meta = (scale, sink, residual is not None, K, xa.shape)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x2, a = ctx.saved_tensors
-        W, A, Bs = ctx.params
-        N = W.shape[0]
+        (xa,) = ctx.saved_tensors
+        Wc, A, Bs = ctx.params
+        scale, sink, has_res, K, xa_shape = ctx.meta
+        xa2 = xa.view(-1, xa.shape[-1])
+        N = Wc.shape[0]
         dy2 = dy.reshape(-1, N)
-        dx = torch.mm(dy2, W)
         dA = None
         dBs = [None] * len(Bs)
         if A is not None:
             r = A.shape[0] // len(Bs)
-            da = torch.empty(dy2.shape[0], A.shape[0], dtype=dy2.dtype, device=dy2.device)
+            dxa = torch.mm(dy2, Wc)                         # [rows, K + G r] = [dx through W | scale * dy_g B_g]
+            da = dxa[:, K:K + A.shape[0]]
+            gA = torch.mm(da.t(), xa2[:, :K])
             off = 0
             for g, B in enumerate(Bs):
                 n = B.shape[0]
-                dyg = dy2[:, off:off + n]
-                torch.mm(dyg, B, out=da[:, g * r:(g + 1) * r])
-                gB = torch.mm(dyg.t(), a[:, g * r:(g + 1) * r])
-                if ctx.sink:
-                    B.main_grad.add_(gB, alpha=ctx.scale)
+                gB = torch.mm(dy2[:, off:off + n].t(), xa2[:, K + g * r:K + (g + 1) * r])
+                if sink:
+                    B.main_grad.add_(gB, alpha=scale)
                 else:
-                    dBs[g] = gB * ctx.scale
+                    dBs[g] = gB * scale
                 off += n
-            da.mul_(ctx.scale)
-            dx.addmm_(da, A)
-            gA = torch.mm(da.t(), x2)
-            if ctx.sink:
+            if sink:
                 A.main_grad.add_(gA)
             else:
                 dA = gA
-        return (dx.view(ctx.x_shape), dy if ctx.has_res else None, None, dA, None, None, *dBs)
+            dxa[:, :K].addmm_(da, A)                        # + the LoRA path's contribution to dx, in place
+        else:
+            dxa = torch.zeros(dy2.shape[0], xa2.shape[1], dtype=dy2.dtype, device=dy2.device)
+            dxa[:, :K].copy_(torch.mm(dy2, Wc[:, :K]))
+        return (dxa.view(xa_shape), dy if has_res else None, None, dA, None, None, None, *dBs)
 
 
 class LoraTarget(nn.Module):
@@ -154,40 +160,71 @@ class RMSNormW(nn.Module):
         self.weight = nn.Parameter(torch.ones(d, dtype=dtype, device=device), requires_grad=False)
         self.variance_epsilon = eps
 
-    def forward(self, x):
-        return K.rmsnorm(x, self.weight, self.variance_epsilon)
+    def forward(self, x, out_width=None):
+        return K.rmsnorm(x, self.weight, self.variance_epsilon, out_width)
 
 
 class LoraGroup(nn.Module):
-    """A fused frozen weight [sum(out_g), in] plus the LoRA factors of its G targets."""
+    """A fused frozen weight [sum(out_g), in] plus the LoRA factors of its G targets.
+
+    Storage: `weight_cat` is [N, in + G*r]: columns [0, in) hold the frozen base weight (`.weight` is that strided view),
+    the tail holds blockdiag(scale * B_g) - refreshed from the trainable B parameters whenever they changed (their tensor
+    version counter moves on every optimizer step)."""
 
     def __init__(self, names, in_features, outs, dtype, device):
         super().__init__()
         self.names, self.outs, self.in_features = tuple(names), tuple(outs), in_features
-        self.weight = nn.Parameter(torch.empty(sum(outs), in_features, dtype=dtype, device=device), requires_grad=False)
+        self.weight_cat = nn.Parameter(torch.empty(sum(outs), in_features, dtype=dtype, device=device), requires_grad=False)
         for n, o in zip(names, outs):
             setattr(self, n, LoraTarget(in_features, o))
-        self.A_cat = None          # [G*r, in] view-concatenation target (rebuilt by attach_lora)
+        self.A_cat = None          # [G*r, in]: the A factors of the G targets, one GEMM for all of them
         self.scale = 0.0
+        self.r = 0
         self.grad_sink = False
+        self._tail_versions = None
+
+    @property
+    def weight(self):
+        return self.weight_cat[:, :self.in_features]
+
+    @property
+    def in_width(self):
+        """Width of the operand buffer the producer kernel must allocate (in + G*r once LoRA is attached)."""
+        return self.weight_cat.shape[1]
 
     def targets(self):
         return [getattr(self, n) for n in self.names]
 
+    def _Bs(self):
+        return [getattr(self, n).lora_B["default"].weight for n in self.names]
+
     def attach_lora(self, r, alpha, dtype, device, generator=None):
-        """peft 0.4.0 init: A ~ kaiming_uniform(a=sqrt(5)), B = 0, scaling = alpha / r.  The G A-factors live in one
-        [G*r, in] parameter-backed buffer so the A-side GEMM is a single launch; each target's lora_A.default.weight
-        is a row-slice view of it."""
+        """peft 0.4.0 init: A ~ kaiming_uniform(a=sqrt(5)) = U(-1/sqrt(in), 1/sqrt(in)), B = 0, scaling = alpha / r."""
         G = len(self.names)
         A_all = torch.empty(G * r, self.in_features, dtype=torch.float32, device=device)
-        bound = 1.0 / math.sqrt(self.in_features)          # kaiming_uniform_(a=sqrt(5)) on [r, in] == U(-1/sqrt(in), 1/sqrt(in))
+        bound = 1.0 / math.sqrt(self.in_features)
         A_all.uniform_(-bound, bound, generator=generator)
         self.A_cat = nn.Parameter(A_all.to(dtype))
-        for g, (n, o) in enumerate(zip(self.names, self.outs)):
-            t = getattr(self, n)
-            t.lora_B["default"] = _W(torch.zeros(o, r, dtype=dtype, device=device))
+        for n, o in zip(self.names, self.outs):
+            getattr(self, n).lora_B["default"] = _W(torch.zeros(o, r, dtype=dtype, device=device))
         self.scale = float(alpha) / float(r)
         self.r = r
+        base = self.weight_cat.data
+        tail = (G * r + 7) // 8 * 8          # 16-byte rows for the producer kernels (r = 128 needs no padding)
+        wc = torch.zeros(base.shape[0], self.in_features + tail, dtype=base.dtype, device=base.device)
+        wc[:, :self.in_features].copy_(base[:, :self.in_features])
+        self.weight_cat = nn.Parameter(wc, requires_grad=False)
+        self._tail_versions = None
+
+    def refresh_tail(self):
+        """weight_cat[:, in:] = blockdiag(scale * B_g) (bf16; scale = alpha / r is a power of two in the reference recipe)."""
+        K, r = self.in_features, self.r
+        off = 0
+        with torch.no_grad():
+            for g, (B, n) in enumerate(zip(self._Bs(), self.outs)):
+                self.weight_cat[off:off + n, K + g * r:K + (g + 1) * r].copy_(B * self.scale)
+                off += n
+        self._tail_versions = tuple(B._version for B in self._Bs())
 
     def lora_state(self):
         """{peft-style name: tensor} for this group's targets."""
@@ -200,11 +237,17 @@ class LoraGroup(nn.Module):
             out[n + ".lora_B.default.weight"] = getattr(self, n).lora_B["default"].weight.data
         return out
 
-    def forward(self, x, residual=None, use_lora=True):
+    def forward(self, xa, residual=None, use_lora=True):
+        """xa: [.., in_width] operand buffer whose left `in` columns hold the input (right columns: scratch)."""
+        if xa.shape[-1] != self.in_width:
+            raise ValueError("LoraGroup expects an operand buffer of width %d, got %d" % (self.in_width, xa.shape[-1]))
         if self.A_cat is not None and use_lora:
-            Bs = [getattr(self, n).lora_B["default"].weight for n in self.names]
-            return _LoraGroupFn.apply(x, residual, self.weight, self.A_cat, self.scale, self.grad_sink, *Bs)
-        return _LoraGroupFn.apply(x, residual, self.weight, None, 0.0, False)
+            Bs = self._Bs()
+            if self._tail_versions != tuple(B._version for B in Bs):
+                self.refresh_tail()
+            return _LoraGroupFn.apply(xa, residual, self.weight_cat, self.A_cat, self.scale, self.grad_sink,
+                                      self.in_features, *Bs)
+        return _LoraGroupFn.apply(xa, residual, self.weight_cat, None, 0.0, False, self.in_features)
 
 
 class SeqInfo:
@@ -235,12 +278,13 @@ class DecoderLayer(nn.Module):
         return (("self_attn", self.qkv), ("self_attn", self.o), ("mlp", self.gate_up), ("mlp", self.down))
 
     def forward(self, x, info, use_lora=True):
-        h = self.input_layernorm(x)
+        # every producer kernel writes straight into the (wider) operand buffer of the projection that follows it
+        h = self.input_layernorm(x, self.qkv.in_width)
         qkv = self.qkv(h, None, use_lora)
-        a = K.attention(qkv, info.cos, info.sin, info.seq_start, info.seq_len, self.H, self.D)
+        a = K.attention(qkv, info.cos, info.sin, info.seq_start, info.seq_len, self.H, self.D, self.o.in_width)
         x = self.o(a, x, use_lora)
-        h = self.post_attention_layernorm(x)
-        act = K.swiglu(self.gate_up(h, None, use_lora))
+        h = self.post_attention_layernorm(x, self.gate_up.in_width)
+        act = K.swiglu(self.gate_up(h, None, use_lora), self.down.in_width)
         return self.down(act, x, use_lora)
 
 
@@ -287,8 +331,17 @@ def add_lora(model, r, alpha, generator=None):
         p.requires_grad_(False)
     for layer in model.model.layers:
         for _, grp in layer.groups():
-            grp.attach_lora(r, alpha, grp.weight.dtype, grp.weight.device, generator)
+            grp.attach_lora(r, alpha, grp.weight_cat.dtype, grp.weight_cat.device, generator)
     return model
+
+
+def refresh_lora(model):
+    """Re-materialise blockdiag(scale * B) in every group's fused weight (call after the B factors were updated)."""
+    for layer in model.model.layers:
+        if hasattr(layer, "groups"):
+            for _, grp in layer.groups():
+                if grp.A_cat is not None:
+                    grp.refresh_tail()
 
 
 def lora_named_parameters(model):

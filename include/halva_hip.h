@@ -41,6 +41,12 @@ const char* halva_last_error(void);
 int halva_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int d, float eps, void* stream);
 int halva_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, int64_t rows, int d,
                       void* stream);
+/* same with an explicit row stride (elements) for y / dy: lets the normalised rows land directly in the left columns of the
+ * [rows, d + G*r] LoRA operand buffer of the next projection (no concat copy). */
+int halva_rmsnorm_fwd_ld(const void* x, const void* w, void* y, int64_t ldy, float* rstd, int64_t rows, int d, float eps,
+                         void* stream);
+int halva_rmsnorm_bwd_ld(const void* dy, int64_t lddy, const void* x, const void* w, const float* rstd, void* dx, int64_t rows,
+                         int d, void* stream);
 
 /* ---- RoPE, in place on the q and k thirds of a packed qkv buffer [rows, 3, H, D] (bf16).
  * replaces apply_rotary_pos_emb (modelling_llama.py:154-169) as called from
@@ -53,6 +59,8 @@ int halva_rope_qk(void* qkv, const void* cos, const void* sin, const int32_t* po
 /* ---- SwiGLU.  replaces act_fn(gate_proj(x)) * up_proj(x) (modelling_llama.py:197).  gu = [rows, 2F] (gate | up). */
 int halva_swiglu_fwd(const void* gu, void* out, int64_t rows, int F, void* stream);
 int halva_swiglu_bwd(const void* dout, const void* gu, void* dgu, int64_t rows, int F, void* stream);
+int halva_swiglu_fwd_ld(const void* gu, void* out, int64_t ldo, int64_t rows, int F, void* stream);
+int halva_swiglu_bwd_ld(const void* dout, int64_t lddo, const void* gu, void* dgu, int64_t rows, int F, void* stream);
 
 /* ---- causal self-attention on right/left padded rows, bf16, head_dim 128 (Llama) - THE headline kernel.
  * replaces flash_attn_varlen_qkvpacked_func(qkv, cu_q_lens, max_s, 0.0, softmax_scale=None, causal=True)
@@ -66,6 +74,12 @@ int halva_sdpa_causal_fwd(const void* qkv, void* out, float* lse, const int32_t*
 int halva_sdpa_causal_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                           float* delta_ws, float* dq_ws, const int32_t* seq_start, const int32_t* seq_len, int S, int T,
                           int H, int D, float scale, void* stream);
+/* same with explicit row strides (elements) of out / dout */
+int halva_sdpa_causal_fwd_ld(const void* qkv, void* out, int64_t ld_out, float* lse, const int32_t* seq_start,
+                             const int32_t* seq_len, int S, int T, int H, int D, float scale, void* stream);
+int halva_sdpa_causal_bwd_ld(const void* qkv, const void* out, int64_t ld_out, const void* dout, int64_t ld_dout,
+                             const float* lse, void* dqkv, float* delta_ws, float* dq_ws, const int32_t* seq_start,
+                             const int32_t* seq_len, int S, int T, int H, int D, float scale, void* stream);
 
 /* ---- non-causal self-attention, bf16, head_dim 64, forward only (the CLIP tower runs under no_grad:
  * llava/model/multimodal_encoder/clip_encoder.py:37-49; replaces HF CLIPAttention's softmax(QK^T*scale)V).

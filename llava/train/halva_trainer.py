@@ -222,6 +222,7 @@ class HalvaTrainer:
             return
         a = self.args
         self._flat = dpa.FlatTrainables(dpa.trainable_named_parameters(self.model))
+        dpa.bind_model(self._flat, self.model)
         dpa.set_grad_sink(self.model, True)
         self._engine = dpa.DPAEngine(self.model, self.ref_model, self.loss_alpha,
                                      pairs_per_group=int(os.environ.get("HALVA_PAIRS_PER_GROUP", "4")),

@@ -16,6 +16,7 @@ def _engine(z, pairs_per_group, ref_rows_per_group):
     from halva_amd import dpa
     pol, ref, lora = build_product_models(z)
     flat = dpa.FlatTrainables(dpa.trainable_named_parameters(pol))
+    dpa.bind_model(flat, pol)
     dpa.set_grad_sink(pol, True)
     eng = dpa.DPAEngine(pol, ref, float(z["alpha"]), pairs_per_group, ref_rows_per_group)
     return eng, pol, ref, flat, lora
@@ -109,6 +110,7 @@ def test_identity_policy_has_zero_divergence():
     for p in pol.model.mm_projector.parameters():
         p.requires_grad_(True)
     flat = dpa.FlatTrainables(dpa.trainable_named_parameters(pol))
+    dpa.bind_model(flat, pol)
     dpa.set_grad_sink(pol, True)
     eng = dpa.DPAEngine(pol, ref, 0.4, 8, 8)
     eng.loss(batch_of(z), backward=True)
