@@ -100,8 +100,16 @@ def sdpa_roofline(dev, S=8, T=2048, H=32, D=128, iters=10):
     tf, tb = tf / iters * 1e-3, tb / iters * 1e-3
     fwd_flop = 2.0 * T * T * D * H * S
     bwd_flop = 2.5 * fwd_flop
+    traffic = None          # HBM bytes per launch from the committed PMC passes of the same kernels at the same shape
+    pmc = os.path.join(ROOT, "profiles", "r01_sdpa_pmc.json")
+    if os.path.exists(pmc):
+        with open(pmc) as f:
+            j = json.load(f)
+        if j.get("shape") == {"S": S, "T": T, "H": H, "D": D}:
+            traffic = j.get("sdpa_causal_bwd_hbm_bytes_per_launch")
     return {"bound": "mfma", "kernel": "sdpa_causal_bwd (delta + dQ + dK/dV launches, D=128)", "achieved": round(bwd_flop / tb / 1e12, 2),
-            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(bwd_flop / tb / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(bwd_flop / tb / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "traffic_source": "profiles/r01_sdpa_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bytes = (2*FETCH+WRITE)*1024)",
             "launch_ms": round(tb * 1e3, 3), "shape": {"S": S, "T": T, "H": H, "D": D},
             "fwd": {"achieved": round(fwd_flop / tf / 1e12, 2), "frac": round(fwd_flop / tf / 1e12 / PEAK_BF16_TFLOPS, 4),
                     "launch_ms": round(tf * 1e3, 3)}}

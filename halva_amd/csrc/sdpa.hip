@@ -30,6 +30,28 @@ constexpr float kLn2 = 0.6931471805599453f;
 #define DKV_BQ 64       // query rows staged per barrier in the dK/dV kernel
 #endif
 
+#ifdef HALVA_STAMP
+#define STAMP(i)                                                                                   \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        unsigned long long t_;                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        stamp_acc[i] += t_ - stamp_prev;                                                           \
+        stamp_prev = t_;                                                                           \
+    } while (0)
+unsigned long long* g_dbg = nullptr;
+extern "C" unsigned long long* halva_dbg_buffer() {
+    if (!g_dbg) {
+        (void)hipMalloc(&g_dbg, 4096 * 8);
+        (void)hipMemset(g_dbg, 0, 4096 * 8);
+    }
+    return g_dbg;
+}
+#else
+#define STAMP(i)
+#endif
+
 struct SdpaParams {
     const bf16_t* q;      // [S, T, ...] row stride ld_qkv, head offset hd * D
     const bf16_t* k;
@@ -49,6 +71,7 @@ struct SdpaParams {
     int64_t ld_do;        // elements between consecutive tokens in dout
     int T, H;
     int nblk, npairs;     // row blocks per (sequence, head) pair; number of pairs (S * H)
+    unsigned long long* dbg;   // diagnostic builds only
     float scale;          // softmax scale
 };
 
@@ -292,6 +315,18 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
                 for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) st[t] = mfma32(frag_rows<D>(kt, 32 * t, ks, lane), qf[ks], st[t]);
+            }
+            // fragment reads run PREFETCH MFMAs ahead of their consumer (hipcc otherwise issues each ds_read right before
+            // the MFMA that needs it and exposes the LDS latency 2*KS times per tile)
+            {
+                constexpr int PREFETCH = 4, NM = 2 * KS;
+                __builtin_amdgcn_sched_group_barrier(0x100, PREFETCH, 0);
+#pragma unroll
+                for (int i = 0; i < NM - PREFETCH; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, PREFETCH, 0);
             }
             // ---- online softmax over the key axis (registers), log2 domain; the softmax scale rides in the exp2 FMA
             if ((kv0 + BN > len) || (CAUSAL && kv0 + BN - 1 > wq_min)) {      // wave-uniform: boundary tiles only
@@ -598,40 +633,48 @@ __device__ __forceinline__ void sdpa_bwd_dkv_block(const SdpaParams& p, char* sm
     const int64_t qrow0 = seq_row0 + start;
     const float* lse_g = p.lse + ((int64_t)s * p.H + hd) * p.T + start;
     const float* dlt_g = p.delta + ((int64_t)s * p.H + hd) * p.T + start;
+    // row statistics of the next tile: the RAW values are fetched (clamped index, no arithmetic on them until the LDS store
+    // after the compute phase - vmcnt retires in order, so touching them early would also wait for the tile loads)
     float st_lse = 0.f, st_dlt = 0.f;
     auto load_stats = [&](int q0) {
         if (threadIdx.x < BQ) {
-            const int ql = q0 + threadIdx.x;
-            st_lse = ql < len ? lse_g[ql] * kLog2e : 0.f;
-            st_dlt = ql < len ? dlt_g[ql] : 0.f;
+            const int ql = min(q0 + (int)threadIdx.x, len - 1);
+            st_lse = lse_g[ql];
+            st_dlt = dlt_g[ql];
         }
     };
     auto store_stats = [&](int buf) {
         if (threadIdx.x < BQ) {
-            lse_lds[buf * BQ + threadIdx.x] = st_lse;
+            lse_lds[buf * BQ + threadIdx.x] = st_lse * kLog2e;
             dlt_lds[buf * BQ + threadIdx.x] = st_dlt;
         }
     };
     __syncthreads();      // the previous key block of this workgroup may still be reading its last tile
+    load_stats(q_begin);
     qst.load_clamped(qp, p.ld_qkv, qrow0, q_begin, len);
     dst.load_clamped(dop, p.ld_do, qrow0, q_begin, len);
-    load_stats(q_begin);
     qst.store(q_lds);
     dst.store(do_lds);
     store_stats(0);
     __syncthreads();
 
+#ifdef HALVA_STAMP
+    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
     for (int it = 0; it < ntiles; ++it) {
+        STAMP(5);
         const int qt0 = q_begin + it * BQ;
         const char* qt = q_lds + (it & 1) * TILE_BYTES;
         const char* dot = do_lds + (it & 1) * TILE_BYTES;
         const float* lse_t = lse_lds + (it & 1) * BQ;
         const float* dlt_t = dlt_lds + (it & 1) * BQ;
         if (it + 1 < ntiles) {
+            load_stats(qt0 + BQ);
             qst.load_clamped(qp, p.ld_qkv, qrow0, qt0 + BQ, len);
             dst.load_clamped(dop, p.ld_do, qrow0, qt0 + BQ, len);
-            load_stats(qt0 + BQ);
         }
+        STAMP(0);
 #pragma unroll
         for (int sub = 0; sub < SUB; ++sub) {
             const int q0 = qt0 + 32 * sub;
@@ -649,6 +692,10 @@ __device__ __forceinline__ void sdpa_bwd_dkv_block(const SdpaParams& p, char* sm
                 sa = mfma32(frag_rows<D>(qt, 32 * sub, ks, lane), kf[ks], sa);
                 dpa = mfma32(frag_rows<D>(dot, 32 * sub, ks, lane), vf[ks], dpa);
             }
+#ifdef HALVA_STAMP
+            asm volatile("" : "+v"(sa[15]), "+v"(dpa[15]));
+#endif
+            STAMP(1);
             if ((q0 + 32 > len) || (CAUSAL && q0 < wk_min + 31) || wave_has_pad_keys) {      // wave-uniform
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -668,6 +715,7 @@ __device__ __forceinline__ void sdpa_bwd_dkv_block(const SdpaParams& p, char* sm
                     dpa[r] = pr * (dpa[r] - d4[j]);      // dZ
                 }
             }
+            STAMP(2);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const s16x8 pb = acc_to_frag(sa, ks);
@@ -679,13 +727,24 @@ __device__ __forceinline__ void sdpa_bwd_dkv_block(const SdpaParams& p, char* sm
                 }
             }
         }
+#ifdef HALVA_STAMP
+        asm volatile("" : "+v"(dkacc[0][15]), "+v"(dvacc[DT - 1][15]));
+#endif
+        STAMP(3);
         if (it + 1 < ntiles) {
             qst.store(q_lds + ((it + 1) & 1) * TILE_BYTES);
             dst.store(do_lds + ((it + 1) & 1) * TILE_BYTES);
             store_stats((it + 1) & 1);
         }
+        STAMP(4);
         __syncthreads();
     }
+#ifdef HALVA_STAMP
+    if (p.dbg && lane == 0 && kb == 0 && s == 0 && hd < 4) {
+        for (int i = 0; i < 6; ++i) p.dbg[(hd * 4 + wave) * 8 + i] = stamp_acc[i];
+        p.dbg[(hd * 4 + wave) * 8 + 6] = ntiles;
+    }
+#endif
     if (k_in_T) {
         store_rows_T<D>(dkrow, dkacc, k_valid ? p.scale : 0.f, true, lane);
         store_rows_T<D>(dvrow, dvacc, k_valid ? 1.f : 0.f, true, lane);
@@ -735,7 +794,11 @@ int launch_fwd(const SdpaParams& p, int S, hipStream_t st) {
 }
 
 template <int D, bool CAUSAL>
-int launch_bwd(const SdpaParams& p, int S, hipStream_t st) {
+int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st) {
+    SdpaParams p = p_in;
+#ifdef HALVA_STAMP
+    p.dbg = halva_dbg_buffer();
+#endif
     {
         const int64_t total = (int64_t)S * p.T * p.H;
         const int64_t threads = total * (D / 8);
