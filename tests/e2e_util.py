@@ -1,0 +1,84 @@
+"""Builds a tiny on-disk LLaVA checkpoint + dataset for end-to-end tests of the train() entry point."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from fake_tokenizer import FakeLlamaTokenizer
+from golden_util import load_npz, meta_of, tensors
+
+SAMPLES = [
+    ("closed", "What is in the picture?", "There is a <MASK> dog </MASK> sitting on <MASK> the grass </MASK>.",
+     "There is a <MASK> cat </MASK> sitting on <MASK> the sand </MASK>."),
+    ("open", "Describe the scene.", "A man rides a <MASK> brown horse </MASK> near <MASK> two </MASK> trees.",
+     "A man rides a <MASK> white horse </MASK> near <MASK> three </MASK> trees."),
+    ("qa", "Is there a cat?", "<MASK> Yes </MASK>, there is a cat.", "<MASK> No </MASK>, there is a cat."),
+    ("qa", "Is the door open?", "<MASK> No </MASK>, the door is closed.", "<MASK> Yes </MASK>, the door is closed."),
+    ("closed", "What colour is the bus?", "The bus is <MASK> blue </MASK>.", "The bus is <MASK> green </MASK>."),
+    ("open", "What is he doing?", "He is <MASK> surfing </MASK> on a <MASK> big wave </MASK>.",
+     "He is <MASK> skiing </MASK> on a <MASK> big hill </MASK>."),
+]
+REF = [("What is shown here?", "A plate of food with rice."), ("Is it raining?", "No"), ("Describe the image.", "Two children play football."),
+       ("What is this?", "A red car on a road."), ("Who is there?", "A man and a dog."), ("What colour?", "Blue and green."),
+       ("Anything else?", "Nothing else."), ("Where?", "On the left side.")]
+
+
+def plain(masked):
+    s = masked.replace(" </MASK> ", " ").replace(" </MASK>", "").replace(" <MASK> ", " ")
+    return s[len("<MASK> "):] if s.startswith("<MASK> ") else s
+
+
+def build(root):
+    from PIL import Image
+    from safetensors.torch import save_file
+    z = load_npz("dpa_step_d64_init.npz")
+    cfg, ccfg = meta_of(z, "llama_cfg"), meta_of(z, "clip_cfg")
+    ck, vt, data, img = (os.path.join(root, d) for d in ("ckpt", "vision", "data", "images/"))
+    for d in (ck, vt, data, os.path.join(img, "coco")):
+        os.makedirs(d, exist_ok=True)
+    conf = dict(cfg, model_type="llava", mm_vision_tower=vt, mm_projector_type="mlp2x_gelu", mm_hidden_size=ccfg["hidden_size"],
+                mm_vision_select_layer=-2, mm_vision_select_feature="patch")
+    json.dump(conf, open(os.path.join(ck, "config.json"), "w"))
+    save_file({k: v.to(torch.bfloat16).contiguous() for k, v in tensors(z, "base.").items()}, os.path.join(ck, "model.safetensors"))
+    json.dump({"vision_config": ccfg}, open(os.path.join(vt, "config.json"), "w"))
+    save_file({"vision_model." + k: v.to(torch.bfloat16).contiguous() for k, v in tensors(z, "clip.").items()},
+              os.path.join(vt, "model.safetensors"))
+    json.dump({"image_processor_type": "CLIPImageProcessor", "do_resize": True, "size": {"shortest_edge": ccfg["image_size"]},
+               "do_center_crop": True, "crop_size": {"height": ccfg["image_size"], "width": ccfg["image_size"]}, "do_normalize": True,
+               "do_rescale": True, "do_convert_rgb": True, "image_mean": [0.48145466, 0.4578275, 0.40821073],
+               "image_std": [0.26862954, 0.26130258, 0.27577711], "resample": 3},
+              open(os.path.join(vt, "preprocessor_config.json"), "w"))
+    rng = np.random.RandomState(0)
+    rows, refs = [], []
+    for i, (tag, q, pos, neg) in enumerate(SAMPLES):
+        name = "coco/im%d.png" % i
+        Image.fromarray(rng.randint(0, 255, (24 + 3 * i, 30, 3), dtype=np.uint8)).save(os.path.join(img, name))
+        rows.append({"id": i, "image": name, "tag": tag, "raw_answer": "yes" if "Yes" in pos else "no", "question": "<image>\n" + q,
+                     "correct_answer": plain(pos), "correct_answer_masked": pos, "hallucinated_answer": plain(neg),
+                     "hallucinated_answer_masked": neg})
+    for i, (q, a) in enumerate(REF):
+        refs.append({"id": "r%d" % i, "image": "coco/im%d.png" % (i % len(SAMPLES)),
+                     "conversations": [{"from": "human", "value": "<image>\n" + q}, {"from": "gpt", "value": a}]})
+    json.dump(rows, open(os.path.join(data, "data.json"), "w"))
+    json.dump(refs, open(os.path.join(data, "ref_data.json"), "w"))
+    return dict(ckpt=ck, vision=vt, data=os.path.join(data, "data.json"), ref=os.path.join(data, "ref_data.json"), images=img,
+                vocab_size=cfg["vocab_size"])
+
+
+class _Tok(FakeLlamaTokenizer):
+    unk_token = "<unk>"
+    pad_token = None
+
+
+def patch_tokenizer(monkeypatch, max_vocab):
+    """transformers 5.x no longer ships the legacy slow Llama tokenizer the reference's span walk relies on: use the
+    deterministic stand-in (tests/golden/fake_tokenizer.py) for the end-to-end tests."""
+    import transformers
+
+    def from_pretrained(path, cache_dir=None, model_max_length=2048, padding_side="right", use_fast=False, **kw):
+        t = _Tok(model_max_length=model_max_length)
+        t.padding_side = padding_side
+        t.max_vocab = max_vocab
+        return t
+    monkeypatch.setattr(transformers.AutoTokenizer, "from_pretrained", staticmethod(from_pretrained))

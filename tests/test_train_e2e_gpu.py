@@ -1,0 +1,45 @@
+"""End-to-end on the GPU: the reference's entry point (`train_halva.train` with the flag set of src/hallava_7b.sh) on a tiny
+on-disk checkpoint + JSON dataset + PNG images: model / tokenizer / dataset construction, sampler, engine steps with gradient
+accumulation, AdamW + cosine schedule, PEFT-format outputs."""
+import json
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import e2e_util  # noqa: E402
+
+
+def test_train_entry_point(tmp_path, monkeypatch):
+    import llava.train.train_halva as TH
+    paths = e2e_util.build(str(tmp_path))
+    e2e_util.patch_tokenizer(monkeypatch, paths["vocab_size"])
+    out = os.path.join(str(tmp_path), "out")
+    argv = ("--lora_enable True --lora_r 8 --lora_alpha 16 --mm_projector_lr 0 --deepspeed src/json/zero3.json --loss_alpha 0.4 "
+            "--model_name_or_path %s --version v1 --data_path %s --ref_data_path %s --image_folder %s --vision_tower %s "
+            "--mm_projector_type mlp2x_gelu --mm_vision_select_layer -2 --mm_use_im_start_end False --mm_use_im_patch_token False "
+            "--image_aspect_ratio pad --group_by_modality_length True --bf16 True --output_dir %s --num_train_epochs 2 "
+            "--per_device_train_batch_size 2 --per_device_eval_batch_size 4 --gradient_accumulation_steps 2 --evaluation_strategy no "
+            "--save_strategy steps --save_steps 50000 --learning_rate 1e-3 --weight_decay 0. --warmup_ratio 0.03 "
+            "--lr_scheduler_type cosine --logging_steps 1 --tf32 True --model_max_length 64 --gradient_checkpointing True "
+            "--dataloader_num_workers 0 --lazy_preprocess True --report_to wandb --save_total_limit 1 --run_name e2e"
+            % (paths["ckpt"], paths["data"], paths["ref"], paths["images"], paths["vision"], out)).split()
+    TH.train(argv)
+    state = json.load(open(os.path.join(out, "trainer_state.json")))
+    losses = [r["loss"] for r in state["log_history"]]
+    assert state["global_step"] == len(losses) >= 2 and all(math.isfinite(l) for l in losses)
+    assert losses[-1] < losses[0], losses            # lr 1e-3 on 6 samples: the DPA loss must go down
+    adapter = torch.load(os.path.join(out, "adapter_model.bin"))
+    k = "base_model.model.model.layers.0.self_attn.q_proj.lora_A.weight"
+    assert k in adapter and adapter[k].shape == (8, 128)
+    assert adapter["base_model.model.model.layers.1.mlp.down_proj.lora_B.weight"].shape == (128, 8)
+    assert float(adapter["base_model.model.model.layers.0.self_attn.q_proj.lora_B.weight"].abs().sum()) > 0   # B moved off zero
+    nl = torch.load(os.path.join(out, "non_lora_trainables.bin"))
+    assert "base_model.model.model.mm_projector.0.weight" in nl
+    cfg = json.load(open(os.path.join(out, "adapter_config.json")))
+    assert cfg["r"] == 8 and cfg["lora_alpha"] == 16 and set(cfg["target_modules"]) == {"q_proj", "k_proj", "v_proj", "o_proj",
+                                                                                           "gate_proj", "up_proj", "down_proj"}
+    assert os.path.exists(os.path.join(out, "config.json"))
