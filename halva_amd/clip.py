@@ -4,8 +4,8 @@ Stand-in for reference llava/model/multimodal_encoder/clip_encoder.py (CLIPVisio
 llava/model/multimodal_projector/builder.py (mlp2x_gelu).  The tower runs under no_grad exactly like the reference
 (clip_encoder.py:37); only the layers that feed `hidden_states[select_layer]` are executed (HF computes all 24 and
 the post-LN and throws them away).  Hand-written kernels: patch-embed (im2col + MFMA GEMM), attention (MFMA,
-head_dim 64), projector MLP (MFMA GEMM, fused bias+GELU epilogue, fwd + bwd).  LayerNorm / the four biased
-linears / quick_gelu go through PyTorch-ROCm.
+head_dim 64), LayerNorm (wave-per-row kernel), projector MLP (MFMA GEMM, fused bias+GELU epilogue, fwd + bwd).
+The four biased linears / quick_gelu of the frozen blocks go through PyTorch-ROCm (hipBLASLt).
 """
 import json
 import os
@@ -138,14 +138,14 @@ class CLIPVisionTower(nn.Module):
         N = x.shape[0]
         x = K.clip_patch_embed(x, self.patch_w, cfg.patch_size, d)
         x = torch.cat([self.class_embedding.expand(N, 1, d), x], 1) + self.position_embedding[None]
-        x = F.layer_norm(x, (d,), self.pre_ln_w, self.pre_ln_b, eps)
+        x = K.layernorm(x.contiguous(), self.pre_ln_w, self.pre_ln_b, eps)
         n_run = cfg.num_hidden_layers + 1 + self.select_layer if self.select_layer < 0 else self.select_layer
         for L in list(self.layers)[:n_run]:
-            h = F.layer_norm(x, (d,), L.ln1_w, L.ln1_b, eps)
+            h = K.layernorm(x, L.ln1_w, L.ln1_b, eps)
             qkv = F.linear(h, L.qkv_w, L.qkv_b)
             a = K.sdpa_full(qkv, H, d // H)
             x = x + F.linear(a, L.out_w, L.out_b)
-            h = F.layer_norm(x, (d,), L.ln2_w, L.ln2_b, eps)
+            h = K.layernorm(x, L.ln2_w, L.ln2_b, eps)
             h = F.linear(h, L.fc1_w, L.fc1_b)
             h = h * torch.sigmoid(1.702 * h)
             x = x + F.linear(h, L.fc2_w, L.fc2_b)
@@ -211,6 +211,7 @@ class Projector(nn.Sequential):
 
     def forward(self, x):
         if len(self) == 3 and isinstance(self[0], nn.Linear) and isinstance(self[2], nn.Linear):
+            x = x.to(self[0].weight.dtype)             # the tower hands features back in the images' dtype
             return K.projector_mlp(x, self[0].weight, self[0].bias, self[2].weight, self[2].bias)
         raise NotImplementedError("only mlp2x_gelu is on the DPA hot path")
 

@@ -247,19 +247,25 @@ extern "C" int halva_gemm_bf16(const void* A, const void* B, const void* bias, v
     return launch_gemm<true, true>(p, (hipStream_t)stream);
 }
 
-extern "C" int halva_clip_patch_embed(const void* images, const void* weight_kp, void* col_ws, void* out, int n, int hw, int p,
-                                      int d, int Kp, void* stream) {
-    HALVA_CHECK_ARG(images && weight_kp && col_ws && out, "clip_patch_embed: null pointer");
-    HALVA_CHECK_ARG(n > 0 && p > 0 && hw % p == 0, "clip_patch_embed: bad image/patch size");
-    HALVA_CHECK_ARG(Kp % 8 == 0 && Kp >= 3 * p * p, "clip_patch_embed: Kp=%d must be a multiple of 8 and >= 3*p*p", Kp);
-    const int np = (hw / p) * (hw / p);
+extern "C" int halva_vit_patch_embed(const void* images, const void* weight_kp, const void* bias, void* col_ws, void* out, int n,
+                                     int hw, int p, int d, int Kp, void* stream) {
+    HALVA_CHECK_ARG(images && weight_kp && col_ws && out, "vit_patch_embed: null pointer");
+    HALVA_CHECK_ARG(n > 0 && p > 0 && hw >= p, "vit_patch_embed: bad image/patch size");
+    HALVA_CHECK_ARG(Kp % 8 == 0 && Kp >= 3 * p * p, "vit_patch_embed: Kp=%d must be a multiple of 8 and >= 3*p*p", Kp);
+    const int np = (hw / p) * (hw / p);   // 'valid' convolution: a trailing partial patch is dropped (384 = 27*14 + 6)
     const int64_t total = (int64_t)n * np * Kp;
     int64_t grid = (total + 255) / 256;
     if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)images,
                        (bf16_t*)col_ws, n, hw, p, Kp, total);
     HALVA_CHECK_LAUNCH("im2col");
-    return halva_gemm_bf16(col_ws, weight_kp, nullptr, out, nullptr, n * np, d, Kp, 0, 0, 0, HALVA_BF16, 0, stream);
+    return halva_gemm_bf16(col_ws, weight_kp, bias, out, nullptr, n * np, d, Kp, 0, 0, 0, HALVA_BF16, 0, stream);
+}
+
+extern "C" int halva_clip_patch_embed(const void* images, const void* weight_kp, void* col_ws, void* out, int n, int hw, int p,
+                                      int d, int Kp, void* stream) {
+    HALVA_CHECK_ARG(p > 0 && hw % p == 0, "clip_patch_embed: bad image/patch size");
+    return halva_vit_patch_embed(images, weight_kp, nullptr, col_ws, out, n, hw, p, d, Kp, stream);
 }
 
 extern "C" int halva_gelu_bwd(const void* dy, const void* h, void* dh, int64_t M, int N, void* stream) {

@@ -17,6 +17,8 @@ for one MI355X without changing its arithmetic:
 import math
 import warnings
 
+from types import SimpleNamespace
+
 import numpy as np
 import torch
 
@@ -134,16 +136,28 @@ def phrase_slots(signs_shifted_half):
 
 
 class DPAStepPlan:
-    """Everything about one micro-batch that is decidable from its integer tensors (host only)."""
+    """Everything about one micro-batch that is decidable from its integer tensors (host only).
 
-    def __init__(self, batch, n_patch, max_len, padding_side="right"):
+    Images: the reference feeds `cat([images, images])` and lets the splice loop walk a running image index over the
+    flattened list (llava_arch.py:277-330, vila/model/llava_arch.py:650-653,700-745); row r of the concatenated batch
+    therefore reads slots that map back (mod n_images) onto the un-duplicated images, which is what lets each image be
+    encoded once per pair.  n_images = B * images-per-sample."""
+
+    def __init__(self, batch, n_patch, max_len, padding_side="right", n_images=None, imageless_consumes=True):
         c_ids, c_lab, c_att, c_sig = concat_pos_neg(batch)
         self.B = c_ids.shape[0] // 2
         self.cat = (c_ids, c_lab, c_att, c_sig)
         self.n_patch, self.max_len, self.side = n_patch, max_len, padding_side
+        self.consumes = imageless_consumes
         B = self.B
+        self.n_images = B if n_images is None else int(n_images)
+        self.row_slots, used = SP.image_slots(c_ids, c_att, imageless_consumes)
+        if used > 2 * self.n_images:
+            raise IndexError("the batch has %d image tokens/slots but only %d images (x2 for pos/neg): index %d is out of "
+                             "bounds" % (used, self.n_images, 2 * self.n_images))
         full = SP.plan_splice(c_ids, c_att, c_lab, c_sig, n_patch, max_len, padding_side,
-                              image_map=list(range(B)) + list(range(B)))
+                              image_map=[s % self.n_images for s in range(max(used, 1))],
+                              imageless_consumes=imageless_consumes)
         sg = full.signs.numpy()[:, 1:]
         self.pos_slots = phrase_slots(sg[:B])
         self.neg_slots = phrase_slots(sg[B:])
@@ -154,19 +168,39 @@ class DPAStepPlan:
         self.P = len(self.pos_slots)
         self.T_full = full.T
         self.ref = tuple(_np(batch[k]) for k in ("ref_input_ids", "ref_labels", "ref_attention_mask"))
+        self.ref_slots, used_ref = SP.image_slots(self.ref[0], self.ref[2], imageless_consumes)
+        self.n_ref_images = used_ref
+
+    def _local_map(self, slots_per_row, modulo):
+        """(image_map for plan_splice's local running index, sorted unique image ids to encode)."""
+        ids = sorted({s % modulo for sl in slots_per_row for s in sl})
+        pos = {v: i for i, v in enumerate(ids)}
+        local = []
+        for sl in slots_per_row:
+            if sl:
+                local += [pos[s % modulo] for s in sl]
+            elif self.consumes:
+                local.append(0)
+        return local or [0], ids
 
     def pair_group(self, idx):
-        """Splice plan of the 2*len(idx) rows [pos(idx) ; neg(idx)]; both rows of a pair read image slot of the pair."""
+        """Splice plan of the 2*len(idx) rows [pos(idx) ; neg(idx)] + the (un-duplicated) images those rows read."""
         c_ids, c_lab, c_att, c_sig = self.cat
         rows = list(idx) + [self.B + b for b in idx]
-        g = len(idx)
-        return SP.plan_splice(c_ids[rows], c_att[rows], c_lab[rows], c_sig[rows], self.n_patch, self.max_len, self.side,
-                              image_map=list(range(g)) + list(range(g)))
+        local, images = self._local_map([self.row_slots[r] for r in rows], self.n_images)
+        gp = SP.plan_splice(c_ids[rows], c_att[rows], c_lab[rows], c_sig[rows], self.n_patch, self.max_len, self.side,
+                            image_map=local, imageless_consumes=self.consumes)
+        gp.images = images
+        return gp
 
     def ref_group(self, idx):
         ids, lab, att = self.ref
         idx = list(idx)
-        return SP.plan_splice(ids[idx], att[idx], lab[idx], None, self.n_patch, self.max_len, self.side)
+        local, images = self._local_map([self.ref_slots[r] for r in idx], max(self.n_ref_images, 1))
+        gp = SP.plan_splice(ids[idx], att[idx], lab[idx], None, self.n_patch, self.max_len, self.side, image_map=local,
+                            imageless_consumes=self.consumes)
+        gp.images = images
+        return gp
 
 
 def _kept_rows(labels):
@@ -181,6 +215,18 @@ def _kept_rows(labels):
     return hid, dense, target
 
 
+def model_spec(model):
+    """What the step planner needs to know about a model wrapper: image tokens per image after the projector, the
+    post-splice truncation length and padding side, and whether an image-less row advances the image index.
+    LlavaLlamaForCausalLM (llava path) is described here; the VILA wrapper supplies its own `dpa_spec()`."""
+    if hasattr(model, "dpa_spec"):
+        return model.dpa_spec()
+    cfg = model.config
+    return SimpleNamespace(n_patch=model.get_vision_tower().num_patches,
+                           max_len=getattr(cfg, "tokenizer_model_max_length", None),
+                           padding_side=getattr(cfg, "tokenizer_padding_side", "right"), imageless_consumes=True)
+
+
 class DPAEngine:
     """Forward/backward of the DPA loss on one GPU.  `policy` / `ref_model` are LlavaLlamaForCausalLM instances."""
 
@@ -188,14 +234,27 @@ class DPAEngine:
         self.policy, self.ref_model, self.alpha = policy, ref_model, float(loss_alpha)
         self.pairs_per_group, self.ref_rows_per_group = pairs_per_group, ref_rows_per_group
 
+    @property
+    def spec(self):
+        return model_spec(self.policy)
+
     # -- pieces ------------------------------------------------------------------------------------
     def _images(self, batch, key, idx, dev):
+        """Flat images `idx` of batch[key]: [B,3,H,W], [B,n,3,H,W] (VILA, flattened like llava_arch.py:650-653) or a list."""
         im = batch[key]
         if isinstance(im, (list, tuple)):
-            im = torch.stack([im[i] for i in idx])
+            flat = [x for t in im for x in (t if t.ndim == 4 else t[None])]
+            im = torch.stack([flat[i] for i in idx])
         else:
+            if im.ndim == 5:
+                im = im.flatten(0, 1)
             im = im[list(idx)]
         return im.to(dev, torch.bfloat16, non_blocking=True)
+
+    def _encode(self, model, batch, key, gp, dev):
+        if not gp.images:                       # text-only group: a zero-row feature tensor keeps the gather well-formed
+            return torch.zeros(0, self.spec.n_patch, model.lm_head.weight.shape[1], dtype=torch.bfloat16, device=dev)
+        return model.encode_images(self._images(batch, key, gp.images, dev))
 
     def _hidden(self, model, plan, feats):
         m = model.get_model()
@@ -209,7 +268,7 @@ class DPAEngine:
         dev = pol.device
         gp = plan.pair_group(idx)
         g = len(idx)
-        feats = pol.encode_images(self._images(batch, "images", idx, dev))               # [g, n_patch, d]; grads -> projector
+        feats = self._encode(pol, batch, "images", gp, dev)                              # [g, n_patch, d]; grads -> projector
         h = self._hidden(pol, gp, feats)
         hid, dense, target = _kept_rows(gp.labels)
         T1 = gp.T - 1
@@ -236,10 +295,9 @@ class DPAEngine:
         pol, ref = self.policy, self.ref_model
         dev = pol.device
         gp = plan.ref_group(idx)
-        images = self._images(batch, "ref_images", idx, dev)
-        h_pol = self._hidden(pol, gp, pol.encode_images(images))
+        h_pol = self._hidden(pol, gp, self._encode(pol, batch, "ref_images", gp, dev))
         with torch.no_grad():
-            h_ref = self._hidden(ref, gp, ref.encode_images(images))
+            h_ref = self._hidden(ref, gp, self._encode(ref, batch, "ref_images", gp, dev))
         hid, _, _ = _kept_rows(gp.labels)
         if hid.numel() == 0:
             return h_pol.sum() * 0.0, gp
@@ -251,10 +309,13 @@ class DPAEngine:
 
     # -- whole micro-batch -------------------------------------------------------------------------
     def make_plan(self, batch):
-        pol = self.policy
-        vt = pol.get_vision_tower()
-        return DPAStepPlan(batch, vt.num_patches, getattr(pol.config, "tokenizer_model_max_length", None),
-                           getattr(pol.config, "tokenizer_padding_side", "right"))
+        sp = self.spec
+        im = batch["images"]
+        if isinstance(im, (list, tuple)):
+            n_images = sum(1 if t.ndim == 3 else t.shape[0] for t in im)
+        else:
+            n_images = im.shape[0] * (im.shape[1] if im.ndim == 5 else 1)
+        return DPAStepPlan(batch, sp.n_patch, sp.max_len, sp.padding_side, n_images, sp.imageless_consumes)
 
     def _groups(self, n, per):
         return [list(range(i, min(n, i + per))) for i in range(0, n, per)]
@@ -298,6 +359,7 @@ class FlatTrainables:
         dev = named_params[0][1].device
         self.names = [n for n, _ in named_params]
         self.params = [p for _, p in named_params]
+        self.no_decay = {n for n, p in named_params if getattr(p, "no_decay", "bias" in n)}
         sizes = [p.numel() for p in self.params]
         self.offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         total = int(self.offsets[-1])
@@ -329,11 +391,23 @@ class FlatTrainables:
             fn()
 
 
+def _llm_of(model):
+    """(causal LM holding `.model.layers`, name prefix): the LLaVA wrapper IS the LM, VILA keeps it under `.llm`."""
+    return (model.get_llm(), "llm.") if hasattr(model, "get_llm") else (model, "")
+
+
+def _projector_of(model):
+    if hasattr(model, "get_mm_projector"):
+        return model.get_mm_projector(), "mm_projector."
+    return getattr(model.get_model(), "mm_projector", None), "model.mm_projector."
+
+
 def bind_model(flat, model):
     """After every optimizer step the fused LoRA weights of `model` must pick up the new B factors."""
     from .llama import refresh_lora
-    flat.post_sync.append(lambda: refresh_lora(model))
-    refresh_lora(model)
+    lm, _ = _llm_of(model)
+    flat.post_sync.append(lambda: refresh_lora(lm))
+    refresh_lora(lm)
 
 
 def set_grad_sink(model, on=True):
@@ -342,35 +416,41 @@ def set_grad_sink(model, on=True):
         if hasattr(layer, "groups"):
             for _, grp in layer.groups():
                 grp.grad_sink = on
-    proj = getattr(model.get_model(), "mm_projector", None)
+    proj, _ = _projector_of(model)
     if proj is not None:
         for p in proj.parameters():
             p.grad_sink = on
 
 
 def trainable_named_parameters(model):
-    """Trainable tensors in flat-buffer order: LoRA factors, then projector weights, then projector biases."""
+    """Trainable tensors in flat-buffer order: LoRA factors, then the projector's decayed tensors (Linear weights), then
+    its un-decayed ones (biases and LayerNorm weights - HF's get_parameter_names(model, ALL_LAYERNORM_LAYERS) split)."""
     from .llama import lora_named_parameters
-    out = list(lora_named_parameters(model))
-    proj = getattr(model.get_model(), "mm_projector", None)
+    lm, pre = _llm_of(model)
+    out = [(pre + n, p) for n, p in lora_named_parameters(lm)]
+    proj, ppre = _projector_of(model)
     if proj is not None:
-        named = [("model.mm_projector." + n, p) for n, p in proj.named_parameters() if p.requires_grad]
-        out += [x for x in named if "bias" not in x[0]] + [x for x in named if "bias" in x[0]]
+        ln = {id(p) for m in proj.modules() if isinstance(m, torch.nn.LayerNorm) for p in m.parameters()}
+        named = [(ppre + n, p) for n, p in proj.named_parameters() if p.requires_grad]
+        for n, p in named:
+            p.no_decay = ("bias" in n) or (id(p) in ln)
+        out += [x for x in named if not x[1].no_decay] + [x for x in named if x[1].no_decay]
     return out
 
 
 class AdamWFlat:
     """torch.optim.AdamW (reference optim="adamw_torch", llava/train/train_halva.py:70) on the fp32 master slices,
     with the reference's parameter groups: {decay, no-decay} x {projector (lr = mm_projector_lr), rest}
-    (halva_trainer.py:291-337).  "decay" = not a bias (no LayerNorm weight is trainable on this path)."""
+    (halva_trainer.py:291-337).  "decay" = neither a bias nor a LayerNorm weight (the latter only exists in VILA's mlp_downsample)."""
 
     def __init__(self, flat, lr, weight_decay=0.0, mm_projector_lr=None, betas=(0.9, 0.999), eps=1e-8):
         self.flat = flat
         groups = []
         segs = [("lora", lambda n: "mm_projector" not in n, lr, weight_decay),
-                ("proj_w", lambda n: "mm_projector" in n and "bias" not in n, lr if mm_projector_lr is None else mm_projector_lr,
-                 weight_decay),
-                ("proj_b", lambda n: "mm_projector" in n and "bias" in n, lr if mm_projector_lr is None else mm_projector_lr, 0.0)]
+                ("proj_w", lambda n: "mm_projector" in n and n not in flat.no_decay,
+                 lr if mm_projector_lr is None else mm_projector_lr, weight_decay),
+                ("proj_b", lambda n: "mm_projector" in n and n in flat.no_decay,
+                 lr if mm_projector_lr is None else mm_projector_lr, 0.0)]
         self._views = []
         for name, pred, g_lr, wd in segs:
             s = flat.segment(pred)

@@ -32,6 +32,10 @@ SIGNATURES = {
     "halva_sdpa_full_fwd": [_P, _P, _I, _I, _I, _I, _F, _P],
     "halva_gemm_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "halva_clip_patch_embed": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "halva_vit_patch_embed": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "halva_layernorm_fwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
+    "halva_layernorm_bwd_params": [_P, _P, _P, _P, _P, _L, _I, _P],
+    "halva_downsample2x2": [_P, _P, _I, _I, _I, _P],
     "halva_gelu_bwd": [_P, _P, _P, _L, _I, _P],
     "halva_colsum": [_P, _P, _L, _I, _P],
     "halva_splice_rows": [_P, _P, _P, _P, _L, _I, _P],

@@ -57,10 +57,12 @@ def rmsnorm(x, w, eps, out_width=None):
 
 
 # ------------------------------------------------------------------------------------------------
-def rope_tables(head_dim, max_pos, base=10000.0, device="cuda"):
-    """cos/sin tables [max_pos, D/2] in bf16 (modelling_llama.py:79-106: computed in fp32, cast to the compute dtype)."""
+def rope_tables(head_dim, max_pos, base=10000.0, device="cuda", linear_factor=1.0):
+    """cos/sin tables [max_pos, D/2] in bf16 (modelling_llama.py:79-106: computed in fp32, cast to the compute dtype).
+    linear_factor: LlamaLinearScalingRotaryEmbedding (t / factor), what vila/model/language_model/builder.py:43-50
+    turns on when model_max_length exceeds the checkpoint's max_position_embeddings."""
     inv = 1.0 / (base ** (torch.arange(0, head_dim, 2, dtype=torch.float32, device=device) / head_dim))
-    freqs = torch.outer(torch.arange(max_pos, dtype=torch.float32, device=device), inv)
+    freqs = torch.outer(torch.arange(max_pos, dtype=torch.float32, device=device) / float(linear_factor), inv)
     return freqs.cos().to(torch.bfloat16).contiguous(), freqs.sin().to(torch.bfloat16).contiguous()
 
 
@@ -134,12 +136,13 @@ def sdpa_causal(qkv, seq_start, seq_len, H, D):
     return _SdpaCausal.apply(qkv, seq_start, seq_len, H, D, None, None)
 
 
-def sdpa_full(qkv, H, D):
-    """Non-causal attention of the frozen CLIP tower (forward only).  qkv [N, S, 3*H*D] -> [N, S, H*D]."""
+def sdpa_full(qkv, H, D, scale=0.0):
+    """Non-causal attention of the frozen CLIP / SigLIP tower (forward only).  qkv [N, S, 3*H*D] -> [N, S, H*D].
+    scale 0 = 1/sqrt(D); SigLIP's 72-wide heads run zero-padded to D=128 with scale = 72**-0.5."""
     _chk(qkv, torch.bfloat16, "qkv")
     N, S = qkv.shape[0], qkv.shape[1]
     out = torch.empty(N, S, H * D, dtype=torch.bfloat16, device=qkv.device)
-    call("halva_sdpa_full_fwd", ptr(qkv), ptr(out), N, S, H, D, 0.0, stream_ptr())
+    call("halva_sdpa_full_fwd", ptr(qkv), ptr(out), N, S, H, D, float(scale), stream_ptr())
     return out
 
 
@@ -261,6 +264,102 @@ class _ProjectorMLP(torch.autograd.Function):
 
 def projector_mlp(x, w1, b1, w2, b2):
     return _ProjectorMLP.apply(x, w1, b1, w2, b2)
+
+
+def _sink_or_return(pairs):
+    """Gradient hand-off shared by the projector Functions: fp32 accumulation straight into `.main_grad` (the flat
+    DP / optimizer buffer) when the parameter is bound to one, else a plain autograd gradient."""
+    grads = []
+    for prm, gr in pairs:
+        if getattr(prm, "main_grad", None) is not None and getattr(prm, "grad_sink", False):
+            prm.main_grad.add_(gr)
+            grads.append(None)
+        else:
+            grads.append(gr.to(prm.dtype))
+    return grads
+
+
+def layernorm(x, w, b, eps, want_stats=False):
+    """nn.LayerNorm forward over the last dim (no autograd: frozen towers).  Returns y or (y, stats[rows, 2])."""
+    _chk(x, torch.bfloat16, "x"), _chk(w, torch.bfloat16, "w"), _chk(b, torch.bfloat16, "b")
+    d = x.shape[-1]
+    rows = x.numel() // d
+    y = torch.empty_like(x)
+    stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device) if want_stats else None
+    call("halva_layernorm_fwd", ptr(x), ptr(w), ptr(b), ptr(y), ptr(stats), rows, d, float(eps), stream_ptr())
+    return (y, stats) if want_stats else y
+
+
+def downsample2x2(x):
+    """DownSampleBlock of VILA's mlp_downsample (vila base_projector.py:33-54): [n, g*g, c] -> [n, ceil(g/2)^2, 4c]."""
+    _chk(x, torch.bfloat16, "x")
+    n, s, c = x.shape
+    g = int(s ** 0.5)
+    if g * g != s:
+        raise ValueError("downsample2x2 needs a square token grid, got %d tokens" % s)
+    G = (g + 1) // 2
+    out = torch.empty(n, G * G, 4 * c, dtype=x.dtype, device=x.device)
+    call("halva_downsample2x2", ptr(x), ptr(out), n, g, c, stream_ptr())
+    return out
+
+
+class _DownsampleMLP(torch.autograd.Function):
+    """mlp_downsample projector (vila/model/multimodal_projector/base_projector.py:76-83): DownSampleBlock ->
+    LayerNorm(4c) -> Linear -> GELU -> Linear.  The input (SigLIP features) carries no gradient (tower frozen,
+    src_vila/halva_vila_13b.sh:44), so the backward stops at the LayerNorm parameters."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, eps, w1, b1, w2, b2):
+        xd = downsample2x2(x.contiguous())
+        x2 = xd.view(-1, xd.shape[-1])
+        xn, stats = layernorm(x2, ln_w, ln_b, eps, want_stats=True)
+        h_pre = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.bfloat16, device=x.device)
+        g = gemm(xn, w1, b1, epilogue=1, pre_act=h_pre)
+        y = gemm(g, w2, b2)
+        ctx.save_for_backward(x2, stats, xn, h_pre, g)
+        ctx.params = (ln_w, ln_b, w1, b1, w2, b2)
+        return y.view(xd.shape[0], xd.shape[1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, stats, xn, h_pre, g = ctx.saved_tensors
+        ln_w, ln_b, w1, b1, w2, b2 = ctx.params
+        dy2 = _chk(dy.reshape(-1, dy.shape[-1]).contiguous(), torch.bfloat16, "dy")
+        M = dy2.shape[0]
+        st = stream_ptr()
+        dev = dy.device
+        dw2 = gemm(dy2, g, trans_a=True, trans_b=True, out_dtype=torch.float32)
+        db2 = torch.zeros(w2.shape[0], dtype=torch.float32, device=dev)
+        call("halva_colsum", ptr(dy2), ptr(db2), M, w2.shape[0], st)
+        dg = gemm(dy2, w2, trans_b=True)
+        dh = torch.empty_like(dg)
+        call("halva_gelu_bwd", ptr(dg), ptr(h_pre), ptr(dh), M, dg.shape[1], st)
+        dw1 = gemm(dh, xn, trans_a=True, trans_b=True, out_dtype=torch.float32)
+        db1 = torch.zeros(w1.shape[0], dtype=torch.float32, device=dev)
+        call("halva_colsum", ptr(dh), ptr(db1), M, w1.shape[0], st)
+        dxn = gemm(dh, w1, trans_b=True)                                                  # [M, 4c]
+        d = x2.shape[1]
+        dlw = torch.zeros(d, dtype=torch.float32, device=dev)
+        dlb = torch.zeros(d, dtype=torch.float32, device=dev)
+        call("halva_layernorm_bwd_params", ptr(dxn), ptr(x2), ptr(stats), ptr(dlw), ptr(dlb), M, d, st)
+        gr = _sink_or_return(((ln_w, dlw), (ln_b, dlb), (w1, dw1), (b1, db1), (w2, dw2), (b2, db2)))
+        return (None, gr[0], gr[1], None, *gr[2:])
+
+
+def downsample_mlp(x, ln_w, ln_b, eps, w1, b1, w2, b2):
+    return _DownsampleMLP.apply(x, ln_w, ln_b, eps, w1, b1, w2, b2)
+
+
+def vit_patch_embed(images, weight_kp, bias, patch, d):
+    """Conv2d(3, d, k=p, s=p, padding='valid', bias) of SiglipVisionEmbeddings as im2col + MFMA GEMM."""
+    _chk(images, torch.bfloat16, "images"), _chk(weight_kp, torch.bfloat16, "weight")
+    n, hw = images.shape[0], images.shape[-1]
+    np_ = (hw // patch) ** 2
+    Kp = weight_kp.shape[1]
+    ws = torch.empty(n * np_, Kp, dtype=torch.bfloat16, device=images.device)
+    out = torch.empty(n, np_, d, dtype=torch.bfloat16, device=images.device)
+    call("halva_vit_patch_embed", ptr(images), ptr(weight_kp), ptr(bias), ptr(ws), ptr(out), n, hw, patch, d, Kp, stream_ptr())
+    return out
 
 
 def clip_patch_embed(images, weight_kp, patch, d):

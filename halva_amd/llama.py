@@ -303,8 +303,12 @@ class LlamaModel(nn.Module):
         key = (str(device), max(T, 1))
         if key not in self._rope:
             n = max(T, getattr(self.config, "tokenizer_model_max_length", 0) or 0, 16)
+            sc = getattr(self.config, "rope_scaling", None) or {}
+            if sc and sc.get("type", sc.get("rope_type", "linear")) not in ("linear", "default"):
+                raise NotImplementedError("rope_scaling %r (only linear scaling is on the HALVA path)" % (sc,))
             self._rope = {key: K.rope_tables(self.config.hidden_size // self.config.num_attention_heads, n,
-                                             getattr(self.config, "rope_theta", 10000.0), device)}
+                                             getattr(self.config, "rope_theta", 10000.0), device,
+                                             float(sc.get("factor", 1.0)) if sc.get("type", sc.get("rope_type")) == "linear" else 1.0)}
             self._rope[(str(device), n)] = self._rope[key]
         return self._rope[key]
 

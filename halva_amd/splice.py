@@ -36,9 +36,25 @@ class SplicePlan:
     n_images: int                     # image slots consumed (running index of the reference)
 
 
-def plan_splice(input_ids, attention_mask, labels, signs, n_patch, max_len=None, padding_side="right", image_map=None):
+def image_slots(input_ids, attention_mask, imageless_consumes=True):
+    """Running image index of the reference's splice loop: for every row, the list of image slots its image tokens
+    read, plus the total number of slots consumed.  LLaVA advances the index for an image-less row too
+    (llava_arch.py:287-294); VILA does not (vila/model/llava_arch.py:716-718)."""
+    ids = np.asarray(input_ids)
+    att = np.ones(ids.shape, dtype=bool) if attention_mask is None else np.asarray(attention_mask).astype(bool)
+    out, slot = [], 0
+    for b in range(ids.shape[0]):
+        n_img = int(((ids[b] == IMAGE_TOKEN_INDEX) & att[b]).sum())
+        out.append(list(range(slot, slot + n_img)))
+        slot += n_img if n_img else (1 if imageless_consumes else 0)
+    return out, slot
+
+
+def plan_splice(input_ids, attention_mask, labels, signs, n_patch, max_len=None, padding_side="right", image_map=None,
+                imageless_consumes=True):
     """input_ids/labels/signs: int64 [S, L] (CPU), attention_mask bool [S, L] or None.  image_map (optional) maps the
-    running image-slot index of the reference to a row of the feature tensor (lets pos/neg rows share one encode)."""
+    running image-slot index of the reference to a row of the feature tensor (lets pos/neg rows share one encode).
+    imageless_consumes: see image_slots()."""
     ids = np.asarray(input_ids)
     S, L = ids.shape
     att = np.ones((S, L), dtype=bool) if attention_mask is None else np.asarray(attention_mask).astype(bool)
@@ -65,8 +81,8 @@ def plan_splice(input_ids, attention_mask, labels, signs, n_patch, max_len=None,
                 if s is not None:
                     s[o:o + n_patch] = IGNORE_INDEX
             slot += n_img
-        else:
-            slot += 1                                             # an image-less sample still consumes one image
+        elif imageless_consumes:
+            slot += 1                                             # an image-less sample still consumes one image (LLaVA)
         if max_len is not None:
             src, l = src[:max_len], l[:max_len]
             if s is not None:

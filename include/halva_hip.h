@@ -98,9 +98,28 @@ int halva_gemm_bf16(const void* A, const void* B, const void* bias, void* C, voi
  * Kp (multiple of 8); col_ws: caller scratch [n * (hw/p)^2, Kp] bf16 -> out [n, (hw/p)^2, d] bf16 */
 int halva_clip_patch_embed(const void* images, const void* weight_kp, void* col_ws, void* out, int n, int hw, int p, int d,
                            int Kp, void* stream);
+/* Same with a bias and a 'valid' grid of floor(hw/p)^2 patches: SigLIP's Conv2d(3, d, k=14, s=14, padding="valid") of
+ * the VILA path (vila/model/multimodal_encoder/siglip/modeling_siglip.py SiglipVisionEmbeddings, reached through
+ * vila/model/multimodal_encoder/vision_encoder.py:136-140).  bias [d] bf16 or NULL. */
+int halva_vit_patch_embed(const void* images, const void* weight_kp, const void* bias, void* col_ws, void* out, int n, int hw,
+                          int p, int d, int Kp, void* stream);
 /* dh[M,N] = dy[M,N] * gelu'(h[M,N]) (h = pre-activation), and column sums for the bias grads. */
 int halva_gelu_bwd(const void* dy, const void* h, void* dh, int64_t M, int N, void* stream);
 int halva_colsum(const void* x, float* out, int64_t M, int N, void* stream);
+
+/* ---- vision-side row kernels (VILA path).
+ * LayerNorm over rows of [rows, d] bf16 (d % 8 == 0, d <= 8192): the nn.LayerNorm of mlp_downsample
+ * (vila/model/multimodal_projector/base_projector.py:78) and of the CLIP / SigLIP encoder blocks.
+ * stats (optional) receives (mean, rstd) per row as f32 [rows, 2] for the parameter gradients:
+ * dw[j] += sum_r dy[r,j] * xhat[r,j], db[j] += sum_r dy[r,j] (f32 accumulators; the input carries no gradient
+ * because the vision tower is frozen, src_vila/halva_vila_13b.sh:44).
+ * downsample2x2: DownSampleBlock.flat_square (base_projector.py:33-54): x [n, g*g, c] -> out [n, G*G, 4c], G = ceil(g/2),
+ * odd grids zero padded, token order and channel order exactly as the reference's view/permute chain. */
+int halva_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* stats, int64_t rows, int d, float eps,
+                        void* stream);
+int halva_layernorm_bwd_params(const void* dy, const void* x, const float* stats, float* dw, float* db, int64_t rows, int d,
+                               void* stream);
+int halva_downsample2x2(const void* x, void* out, int n, int g, int c, void* stream);
 
 /* ---- splice gather.  replaces the per-sample python loop of prepare_inputs_labels_for_multimodal[_signed]
  * (llava/model/llava_arch.py:285-374): out[r] = embed[src[r]] if src[r] >= 0, feats[-src[r]-2] if src[r] <= -2,

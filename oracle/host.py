@@ -215,12 +215,14 @@ def modality_length_grouped_indices(lengths, batch_size, world_size, generator=N
 # ------------------------------------------------------------------------------------------------
 # splice - reference llava/model/llava_arch.py:85-226 (unsigned) / :229-394 (signed)
 # ------------------------------------------------------------------------------------------------
-def splice(input_ids, attention_mask, labels, signs, image_features, embed_tokens, max_len, padding_side="right"):
+def splice(input_ids, attention_mask, labels, signs, image_features, embed_tokens, max_len, padding_side="right",
+           imageless_consumes=True):
     """Per-sample loop exactly as the reference: drop pads by mask, cut at IMAGE_TOKEN_INDEX, embed text,
     insert the image's feature rows (labels/signs := IGNORE_INDEX there), truncate to max_len, pad with
     ZERO vectors / IGNORE_INDEX.  numpy in, numpy out.  signs may be None (un-signed twin).
     image_features: [n_images, n_patch, d]; one image is consumed per sample, also by image-less samples
-    (llava_arch.py:287-294).
+    (llava_arch.py:287-294).  imageless_consumes=False is the VILA twin (vila/model/llava_arch.py:708-718:
+    "we do not have placeholdr image for text-only data now", the index is not advanced).
     """
     B = input_ids.shape[0]
     d = embed_tokens.shape[1]
@@ -239,7 +241,8 @@ def splice(input_ids, attention_mask, labels, signs, image_features, embed_token
             l_parts.append(lab)
             if sg is not None:
                 s_parts.append(sg)
-            img += 1
+            if imageless_consumes:
+                img += 1
         else:
             for i in range(n_img + 1):
                 sl = slice(cuts[i] + 1, cuts[i + 1])

@@ -50,3 +50,47 @@ def build_product_models(z, device="cuda", lora=True):
 
 def batch_of(z):
     return {k[len("batch."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("batch.")}
+
+
+def build_product_vila(z, device="cuda", lora=True, max_len=None, padding_side="right"):
+    """(policy, reference, (r, alpha, factors)) VILA wrappers from a vila_* fixture (llm.* / vis.* / proj.* tensors)."""
+    from halva_amd.llama import LlamaConfig, add_lora, load_hf_llama_weights
+    from halva_amd.siglip import SiglipVisionConfig, SiglipVisionTower
+    from halva_amd.vila_model import LlamaForCausalLM, MultimodalProjector, VilaConfig, VilaLlavaLlamaModel
+    cfg_d, vis_d = meta_of(z, "llama_cfg"), meta_of(z, "vis_cfg")
+    llmW, visW, projW, fac = tensors(z, "llm."), tensors(z, "vis."), tensors(z, "proj."), tensors(z, "lora.")
+    r, alpha = (int(z["lora_cfg"][0]), float(z["lora_cfg"][1])) if "lora_cfg" in z.files else (0, 0.0)
+    if max_len is None:
+        max_len = int(z["max_len"])
+
+    def make(with_lora):
+        cfg = VilaConfig(mm_hidden_size=vis_d["hidden_size"], hidden_size=cfg_d["hidden_size"])
+        llm = LlamaForCausalLM(LlamaConfig(**cfg_d), torch.bfloat16, device)
+        load_hf_llama_weights(llm, llmW)
+        llm.config.tokenizer_model_max_length, llm.config.tokenizer_padding_side = max_len, padding_side
+        vt = SiglipVisionTower("fixture", args=cfg, delay_load=True, config=SiglipVisionConfig(**vis_d), device=device)
+        vt._alloc()
+        vt.load_hf_state_dict(visW)
+        vt.requires_grad_(False)
+        vt.is_loaded = True
+        proj = MultimodalProjector("mlp_downsample", cfg, device=device)
+        proj.load_state_dict(projW)
+        m = VilaLlavaLlamaModel(cfg, llm=llm, vision_tower=vt, mm_projector=proj, device=device)
+        for p in m.parameters():
+            p.requires_grad_(False)
+        if with_lora and fac:
+            add_lora(m.llm, r, alpha)
+            with torch.no_grad():
+                for i, layer in enumerate(m.llm.model.layers):
+                    for sub, grp in layer.groups():
+                        for g, n in enumerate(grp.names):
+                            key = "model.layers.%d.%s.%s" % (i, sub, n)
+                            grp.A_cat[g * r:(g + 1) * r].copy_(fac[key + ".A"])
+                            getattr(grp, n).lora_B["default"].weight.copy_(fac[key + ".B"])
+            for p in m.mm_projector.parameters():
+                p.requires_grad_(True)
+        else:
+            m._use_lora = False
+        return m
+
+    return make(lora), make(False), (r, alpha, fac)
