@@ -31,11 +31,13 @@ LLAMA_13B = dict(vocab_size=32000, hidden_size=5120, intermediate_size=13824, nu
                  num_key_value_heads=40, rms_norm_eps=1e-5, max_position_embeddings=4096)
 CLIP_L_336 = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=336,
                   patch_size=14)
+SIGLIP_SO400M_384 = dict(hidden_size=1152, intermediate_size=4304, num_hidden_layers=27, num_attention_heads=16, image_size=384,
+                         patch_size=14)
 TFLOP_PER_PAIR = 214.7            # BASELINE.md section 2 (7B, T = 2048, LoRA r = 128, no recompute)
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def synthetic_batch(B, seed, resp_len=1419, vocab=32000, image=336):
+def synthetic_batch(B, seed, resp_len=1419, vocab=32000, image=336, images_per_sample=None):
     """BASELINE.md section 3 layout: [BOS, 34 prompt, <image>, 12 question, 5 'ASSISTANT:', R response, EOS]."""
     g = torch.Generator().manual_seed(seed)
     pre = 1 + 34
@@ -65,10 +67,11 @@ def synthetic_batch(B, seed, resp_len=1419, vocab=32000, image=336):
     ref_labels = ref.clone()
     ref_labels[:, :off] = -100
     ones = torch.ones(B, L, dtype=torch.bool)
+    ishape = (B, 3, image, image) if images_per_sample is None else (B, images_per_sample, 3, image, image)   # VILA: [B,n,3,H,W]
     return dict(input_ids=pos, labels=labels, attention_mask=ones, neg_input_ids=neg, neg_labels=neg_labels,
                 neg_attention_mask=ones.clone(), pos_signs=signs, neg_signs=signs.clone(), ref_input_ids=ref,
                 ref_labels=ref_labels, ref_attention_mask=ones.clone(),
-                images=torch.randn(B, 3, image, image, generator=g), ref_images=torch.randn(B, 3, image, image, generator=g))
+                images=torch.randn(*ishape, generator=g), ref_images=torch.randn(*ishape, generator=g))
 
 
 def sdpa_roofline(dev, S=8, T=2048, H=32, D=128, iters=10):
@@ -172,10 +175,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs-per-gpu", type=int, default=16)
-    ap.add_argument("--model", default="7b", choices=["7b", "13b"])
+    ap.add_argument("--pairs-per-gpu", type=int, default=0, help="default 16 (7b, 13b) / 8 (vila13b)")
+    ap.add_argument("--model", default="7b", choices=["7b", "13b", "vila13b"],
+                    help="7b = BASELINE configs[1] (the metric); 13b / vila13b = configs[3] / configs[4] geometry (extra workloads)")
     ap.add_argument("--layers", type=int, default=0, help="debug: override the layer count (result is then marked invalid)")
-    ap.add_argument("--pairs-per-group", type=int, default=int(os.environ.get("HALVA_PAIRS_PER_GROUP", "8")))
+    ap.add_argument("--pairs-per-group", type=int, default=int(os.environ.get("HALVA_PAIRS_PER_GROUP", "0")),
+                    help="default 8 (7b) / 4 (13b) / 2 (vila13b)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -196,21 +201,37 @@ def main():
     geo = dict(LLAMA_7B if args.model == "7b" else LLAMA_13B)
     if args.layers:
         geo["num_hidden_layers"] = args.layers
-    policy = build_random_llava(geo, CLIP_L_336, lora_r=128, lora_alpha=256, seed=1234, device=dev, max_len=2048)
+    vila = args.model == "vila13b"
+    seq = 4096 if vila else 2048
+    if not args.pairs_per_gpu:
+        args.pairs_per_gpu = 8 if vila else 16
+    if not args.pairs_per_group:
+        args.pairs_per_group = {"7b": 8, "13b": 4, "vila13b": 2}[args.model]
+    if vila:
+        from halva_amd.vila_model import build_random_vila
+        policy = build_random_vila(geo, SIGLIP_SO400M_384, lora_r=128, lora_alpha=256, seed=1234, device=dev, max_len=seq)
+        ref = build_random_vila(geo, SIGLIP_SO400M_384, seed=1234, device=dev, max_len=seq, share_base_from=policy)
+        layers = policy.llm.model.layers
+    else:
+        policy = build_random_llava(geo, CLIP_L_336, lora_r=128, lora_alpha=256, seed=1234, device=dev, max_len=seq)
+        ref = build_random_llava(geo, CLIP_L_336, seed=1234, device=dev, max_len=seq, share_base_from=policy)
+        layers = policy.model.layers
     with torch.no_grad():                       # LoRA B ~ N(0, 0.01) so that KL != 0
         gB = torch.Generator(device=dev).manual_seed(99)
-        for layer in policy.model.layers:
+        for layer in layers:
             for _, grp in layer.groups():
                 for n in grp.names:
                     getattr(grp, n).lora_B["default"].weight.normal_(0.0, 0.01, generator=gB)
-    ref = build_random_llava(geo, CLIP_L_336, seed=1234, device=dev, max_len=2048, share_base_from=policy)
     flat = dpa.FlatTrainables(dpa.trainable_named_parameters(policy))
     dpa.bind_model(flat, policy)
     dpa.set_grad_sink(policy, True)
-    opt = dpa.AdamWFlat(flat, lr=5e-6, weight_decay=0.0, mm_projector_lr=0.0)
-    eng = dpa.DPAEngine(policy, ref, 0.4, pairs_per_group=args.pairs_per_group, ref_rows_per_group=2 * args.pairs_per_group)
+    opt = dpa.AdamWFlat(flat, lr=2.5e-5 if vila else 5e-6, weight_decay=0.0, mm_projector_lr=0.0)
+    eng = dpa.DPAEngine(policy, ref, 0.2 if vila else 0.4, pairs_per_group=args.pairs_per_group,
+                        ref_rows_per_group=2 * args.pairs_per_group)
     B = args.pairs_per_gpu
-    batch = synthetic_batch(B, 1234 + ctx.rank)
+    n_patch = dpa.model_spec(policy).n_patch                     # 576 (CLIP-L/336) or 196 (SigLIP-384 + mlp_downsample)
+    batch = synthetic_batch(B, 1234 + ctx.rank, resp_len=seq - n_patch - 53, image=384 if vila else 336,
+                            images_per_sample=1 if vila else None)
     batch["images"] = batch["images"].to(dev, torch.bfloat16)          # inputs resident in HBM before the timed region
     batch["ref_images"] = batch["ref_images"].to(dev, torch.bfloat16)
 
@@ -248,11 +269,14 @@ def main():
                "unit": "paired-samples/sec", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16", "data": "synthetic (BASELINE.md section 3), random-init weights",
-               "config": {"workload": "configs[1]: LLaVA-1.5-%s LoRA(r=128) DPA step, 336px, T=2048 post-splice, %d pairs per GPU per "
-                                      "step (fwd+bwd+loss+grad all-reduce+AdamW)" % (args.model.upper(), B),
-                          "pairs_per_gpu": B, "global_pairs": B * ctx.world, "seq_len": 2048, "parallelism": "dp%d" % ctx.world,
+               "config": {"workload": ("configs[4]: VILA-13B geometry (Llama-13B + SigLIP-so400m-384 + mlp_downsample, 196 image tokens) "
+                                       "LoRA(r=128) DPA step, T=%d post-splice, %d pairs per GPU per step (EXTRA workload, not the "
+                                       "BASELINE metric)" % (seq, B)) if vila else
+                                      ("configs[%d]: LLaVA-1.5-%s LoRA(r=128) DPA step, 336px, T=2048 post-splice, %d pairs per GPU per "
+                                       "step (fwd+bwd+loss+grad all-reduce+AdamW)" % (1 if args.model == "7b" else 3, args.model.upper(), B)),
+                          "pairs_per_gpu": B, "global_pairs": B * ctx.world, "seq_len": seq, "parallelism": "dp%d" % ctx.world,
                           "pairs_per_group": args.pairs_per_group, "recompute": "none",
-                          "valid": not bool(args.layers)},
+                          "valid": not bool(args.layers) and args.model == "7b"},
                "loss": round(loss_val, 5),
                "step_tflops_per_gpu": None if tf_pair is None else round(pairs_per_s / ctx.world * tf_pair, 1),
                "step_mfma_frac": None if tf_pair is None else round(pairs_per_s / ctx.world * tf_pair / PEAK_BF16_TFLOPS, 4),

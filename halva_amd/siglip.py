@@ -106,7 +106,7 @@ class SiglipVisionTower(CLIPVisionTower):
     def load_hf_state_dict(self, sd):
         """HF / vendored SiglipVisionModel names, with or without the `vision_model.` prefix.  The pooling head and
         post_layernorm are not on the path (`hidden_states[-2]` is taken before them) and are ignored."""
-        sd = {re.sub(r"^(vision_tower\.)*(vision_model\.)?", "", k): v for k, v in sd.items()}
+        sd = {re.sub(r"^(vision_tower\.)*(vision_model\.)*", "", k): v for k, v in sd.items()}
         cfg = self._cfg
         d, H, D, Dp = cfg.hidden_size, cfg.num_attention_heads, self.head_dim, self.head_pad
         with torch.no_grad():

@@ -446,7 +446,7 @@ class _FrozenProjectorView(nn.Module):
     def __init__(self, proj):
         super().__init__()
         self._p = [proj]
-        self.kind = proj.kind
+        self.kind, self.config = proj.kind, proj.config
 
     def tokens_per_image(self, n):
         return self._p[0].tokens_per_image(n)

@@ -251,14 +251,16 @@ def _render(conv, roles, source):
     return conv.get_prompt()
 
 
-def _mask_targets(targets, conversations, conv, tokenizer, has_image):
-    """labels := ids with BOS and every round's instruction part set to IGNORE_INDEX (reference :432-473)."""
+def _mask_targets(targets, conversations, conv, tokenizer, has_image, later_round_shrink=0):
+    """labels := ids with BOS and every round's instruction part set to IGNORE_INDEX (reference :432-473).
+    later_round_shrink: VILA's twin takes 1 token off the round / instruction length of every round after the first
+    for non-gemma tokenizers (vila/train/train_halva.py:717-726)."""
     sep = conv.sep + conv.roles[1] + ": "
     for conversation, target in zip(conversations, targets):
         total_len = int(target.ne(tokenizer.pad_token_id).sum())
         cur = 1
         target[:cur] = IGNORE_INDEX
-        for rou in conversation.split(conv.sep2):
+        for i_round, rou in enumerate(conversation.split(conv.sep2)):
             if rou == "":
                 break
             parts = rou.split(sep)
@@ -271,6 +273,8 @@ def _mask_targets(targets, conversations, conv, tokenizer, has_image):
             else:
                 round_len = len(tokenizer(rou).input_ids)
                 instr_len = len(tokenizer(instr).input_ids) - 2
+            if i_round > 0:
+                round_len, instr_len = round_len - later_round_shrink, instr_len - later_round_shrink
             target[cur:cur + instr_len] = IGNORE_INDEX
             cur += round_len
         target[cur:] = IGNORE_INDEX
@@ -279,11 +283,14 @@ def _mask_targets(targets, conversations, conv, tokenizer, has_image):
             print(f"WARNING: tokenization mismatch: {cur} vs. {total_len}. (ignored)")
 
 
-def preprocess_v1(sources, tokenizer, has_image: bool = False) -> Dict:
+def preprocess_v1(sources, tokenizer, has_image: bool = False, no_system_prompt: bool = False, later_round_shrink: int = 0) -> Dict:
     """sources[0] = [human, gpt (masked answer), gpt-ref (plain answer)].  Returns input_ids / labels / signs [1, L],
-    or None when the masked tokenisation differs from the plain one (the caller then fails, as in the reference)."""
+    or None when the masked tokenisation differs from the plain one (the caller then fails, as in the reference).
+    no_system_prompt / later_round_shrink: the VILA twin's extras (vila/train/train_halva.py:623-634,717-726)."""
     assert has_image, "this code may not be ready to handle non image setup"
     conv = conversation_lib.default_conversation.copy()
+    if no_system_prompt:
+        conv.system = ""
     roles = {"human": conv.roles[0], "gpt": conv.roles[1]}
     turns = copy.deepcopy(sources[0])
     assert turns[2]["from"] == "gpt-ref"
@@ -301,12 +308,15 @@ def preprocess_v1(sources, tokenizer, has_image: bool = False) -> Dict:
         return None
     targets = ids.clone()
     assert conv.sep_style == conversation_lib.SeparatorStyle.TWO
-    _mask_targets(targets, [plain_prompt], conv, tokenizer, has_image)
+    _mask_targets(targets, [plain_prompt], conv, tokenizer, has_image, later_round_shrink)
     return dict(input_ids=ids, labels=targets, signs=signs)
 
 
-def preprocess_v1_ref(sources, tokenizer, has_image: bool = False) -> Dict:
+def preprocess_v1_ref(sources, tokenizer, has_image: bool = False, no_system_prompt: bool = False,
+                      later_round_shrink: int = 0) -> Dict:
     conv = conversation_lib.default_conversation.copy()
+    if no_system_prompt:
+        conv.system = ""
     roles = {"human": conv.roles[0], "gpt": conv.roles[1]}
     prompts = [_render(conv, roles, s) for s in sources]
     if has_image:
@@ -316,7 +326,7 @@ def preprocess_v1_ref(sources, tokenizer, has_image: bool = False) -> Dict:
                         truncation=True).input_ids
     targets = ids.clone()
     assert conv.sep_style == conversation_lib.SeparatorStyle.TWO
-    _mask_targets(targets, prompts, conv, tokenizer, has_image)
+    _mask_targets(targets, prompts, conv, tokenizer, has_image, later_round_shrink)
     return dict(input_ids=ids, labels=targets)
 
 

@@ -82,3 +82,50 @@ def patch_tokenizer(monkeypatch, max_vocab):
         t.max_vocab = max_vocab
         return t
     monkeypatch.setattr(transformers.AutoTokenizer, "from_pretrained", staticmethod(from_pretrained))
+
+
+def build_vila(root, multi_image=False):
+    """A VILA-layout checkpoint (root/{config.json, llm/, vision_tower/, mm_projector/}) from the vila_step_init fixture
+    + the same JSON dataset / PNG images as build()."""
+    from PIL import Image
+    from safetensors.torch import save_file
+    z = load_npz("vila_step_init.npz")
+    cfg, vcfg = meta_of(z, "llama_cfg"), meta_of(z, "vis_cfg")
+    ck, data, img = (os.path.join(root, d) for d in ("vila_ckpt", "data", "images/"))
+    llm, vt, mp = (os.path.join(ck, d) for d in ("llm", "vision_tower", "mm_projector"))
+    for d in (llm, vt, mp, data, os.path.join(img, "coco")):
+        os.makedirs(d, exist_ok=True)
+    bf = lambda d: {k: v.to(torch.bfloat16).contiguous() for k, v in d.items()}
+    json.dump(dict(cfg, model_type="llama", architectures=["LlamaForCausalLM"]), open(os.path.join(llm, "config.json"), "w"))
+    save_file(bf(tensors(z, "llm.")), os.path.join(llm, "model.safetensors"))
+    json.dump(dict(vcfg, model_type="siglip_vision_model", architectures=["SiglipVisionModel"]),
+              open(os.path.join(vt, "config.json"), "w"))
+    save_file(bf(tensors(z, "vis.")), os.path.join(vt, "model.safetensors"))          # keys already carry `vision_model.`
+    json.dump({"image_processor_type": "SiglipImageProcessor", "do_resize": True,
+               "size": {"height": vcfg["image_size"], "width": vcfg["image_size"]}, "do_normalize": True, "do_rescale": True,
+               "rescale_factor": 1 / 255, "image_mean": [0.5, 0.5, 0.5], "image_std": [0.5, 0.5, 0.5], "resample": 3},
+              open(os.path.join(vt, "preprocessor_config.json"), "w"))
+    json.dump({"mm_projector_type": "mlp_downsample", "model_type": "v2l_projector", "architectures": ["MultimodalProjector"]},
+              open(os.path.join(mp, "config.json"), "w"))
+    save_file(bf(tensors(z, "proj.")), os.path.join(mp, "model.safetensors"))
+    json.dump({"model_type": "llava_llama", "architectures": ["LlavaLlamaModel"], "llm_cfg": dict(cfg, model_type="llama"),
+               "vision_tower_cfg": dict(vcfg, model_type="siglip_vision_model"),
+               "mm_projector_cfg": {"mm_projector_type": "mlp_downsample"}, "hidden_size": cfg["hidden_size"],
+               "mm_hidden_size": vcfg["hidden_size"], "model_dtype": "torch.bfloat16", "resume_path": ck},
+              open(os.path.join(ck, "config.json"), "w"))
+    rng = np.random.RandomState(0)
+    rows, refs = [], []
+    for i, (tag, q, pos, neg) in enumerate(SAMPLES):
+        name = "coco/im%d.png" % i
+        shape = (24 + 3 * i, 30, 3) if i != 2 else (26, 26)              # one single-channel image: patched_normalize path
+        Image.fromarray(rng.randint(0, 255, shape, dtype=np.uint8)).save(os.path.join(img, name))
+        rows.append({"id": i, "image": name, "tag": tag, "raw_answer": "yes" if "Yes" in pos else "no", "question": "<image>\n" + q,
+                     "correct_answer": plain(pos), "correct_answer_masked": pos, "hallucinated_answer": plain(neg),
+                     "hallucinated_answer_masked": neg})
+    for i, (q, a) in enumerate(REF):
+        refs.append({"id": "r%d" % i, "image": "coco/im%d.png" % (i % len(SAMPLES)),
+                     "conversations": [{"from": "human", "value": "<image>\n" + q}, {"from": "gpt", "value": a}]})
+    json.dump(rows, open(os.path.join(data, "data.json"), "w"))
+    json.dump(refs, open(os.path.join(data, "ref_data.json"), "w"))
+    return dict(ckpt=ck, data=os.path.join(data, "data.json"), ref=os.path.join(data, "ref_data.json"), images=img,
+                vocab_size=cfg["vocab_size"], image_size=vcfg["image_size"])

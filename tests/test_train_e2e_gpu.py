@@ -43,3 +43,42 @@ def test_train_entry_point(tmp_path, monkeypatch):
     assert cfg["r"] == 8 and cfg["lora_alpha"] == 16 and set(cfg["target_modules"]) == {"q_proj", "k_proj", "v_proj", "o_proj",
                                                                                            "gate_proj", "up_proj", "down_proj"}
     assert os.path.exists(os.path.join(out, "config.json"))
+
+
+def test_vila_train_entry_point(tmp_path, monkeypatch):
+    """vila.train.train_halva.train with the flag set of src_vila/halva_vila_13b.sh on a VILA-layout tiny checkpoint."""
+    import vila.train.train_halva as TV
+    paths = e2e_util.build_vila(str(tmp_path))
+    e2e_util.patch_tokenizer(monkeypatch, paths["vocab_size"])
+    out = os.path.join(str(tmp_path), "out_vila")
+    argv = ("--lora_enable True --lora_r 8 --lora_alpha 16 --mm_projector_lr 0 --deepspeed src/json/zero3.json --loss_alpha 0.2 "
+            "--model_name_or_path %s --version v1 --data_path %s --ref_data_path %s --image_folder %s "
+            "--vision_tower google/siglip-so400m-patch14-384 --mm_vision_select_feature cls_patch --mm_projector mlp_downsample "
+            "--tune_vision_tower False --tune_mm_projector True --tune_language_model False --mm_vision_select_layer -2 "
+            "--mm_use_im_start_end False --mm_use_im_patch_token False --image_aspect_ratio resize --bf16 True --output_dir %s "
+            "--num_train_epochs 2 --per_device_train_batch_size 2 --per_device_eval_batch_size 4 --gradient_accumulation_steps 2 "
+            "--evaluation_strategy no --save_strategy steps --save_steps 50000 --learning_rate 1e-3 --weight_decay 0. "
+            "--warmup_ratio 0.03 --lr_scheduler_type cosine --logging_steps 1 --tf32 True --model_max_length 64 "
+            "--gradient_checkpointing True --dataloader_num_workers 0 --lazy_preprocess True --report_to wandb "
+            "--save_total_limit 1 --vflan_no_system_prompt True --run_name e2e-vila"
+            % (paths["ckpt"], paths["data"], paths["ref"], paths["images"], out)).split()
+    from unittest import mock
+    from vila.train.transformer_normalize_monkey_patch import patched_normalize
+    with mock.patch("transformers.image_transforms.normalize", new=patched_normalize):
+        TV.train(argv)
+    state = json.load(open(os.path.join(out, "trainer_state.json")))
+    losses = [r["loss"] for r in state["log_history"]]
+    assert state["global_step"] == len(losses) >= 2 and all(math.isfinite(l) for l in losses)
+    assert losses[-1] < losses[0], losses
+    adapter = torch.load(os.path.join(out, "adapter_model.bin"))
+    k = "llm.base_model.model.model.layers.0.self_attn.q_proj.lora_A.weight"
+    assert k in adapter and adapter[k].shape == (8, 128)
+    assert float(adapter["llm.base_model.model.model.layers.0.self_attn.q_proj.lora_B.weight"].abs().sum()) > 0
+    nl = torch.load(os.path.join(out, "non_lora_trainables.bin"))
+    assert set(nl) == {"mm_projector.layers.%s" % s for s in ("1.weight", "1.bias", "2.weight", "2.bias", "4.weight", "4.bias")}
+    # --mm_projector_lr 0: the projector receives gradients but must not move (reference optimizer groups)
+    from safetensors.torch import load_file
+    before = load_file(os.path.join(paths["ckpt"], "mm_projector", "model.safetensors"))
+    for kk, v in nl.items():
+        assert torch.equal(v, before[kk[len("mm_projector."):]]), kk
+    assert os.path.exists(os.path.join(out, "config.json"))
