@@ -174,6 +174,42 @@ struct Stage {
             r[i] = *reinterpret_cast<const u32x4*>(base + (grow_local0 + loc) * ld + ch * 8);
         }
     }
+    // the same three operations for a sub-group of the workgroup whose threads are numbered tid = 0..NT-1
+    __device__ __forceinline__ void load_clamped_t(int tid, const bf16_t* base, int64_t ld, int64_t grow_local0, int local0, int limit) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int cid = tid + NT * i;
+            const int row = cid / NCH, ch = cid % NCH;
+            const int loc = min(max(local0 + row, 0), limit - 1);
+            r[i] = *reinterpret_cast<const u32x4*>(base + (grow_local0 + loc) * ld + ch * 8);
+        }
+    }
+    __device__ __forceinline__ void store_t(int tid, char* tile) const {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int cid = tid + NT * i;
+            const int row = cid / NCH, ch = cid % NCH;
+            *reinterpret_cast<u32x4*>(tile + tile_off<D>(row, ch)) = r[i];
+        }
+    }
+    // pointer-bumping variant for full tiles: ptr[i] addresses this thread's chunk i of the NEXT tile to fetch
+    __device__ __forceinline__ void init_ptrs(const bf16_t* (&ptr)[PER_THREAD], const bf16_t* base, int64_t ld, int64_t grow_local0,
+                                              int local0, int tid = -1) const {
+        if (tid < 0) tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int cid = tid + NT * i;
+            const int row = cid / NCH, ch = cid % NCH;
+            ptr[i] = base + (grow_local0 + local0 + row) * ld + ch * 8;
+        }
+    }
+    __device__ __forceinline__ void load_bump(const bf16_t* (&ptr)[PER_THREAD], int64_t stride_elems) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            r[i] = *reinterpret_cast<const u32x4*>(ptr[i]);
+            ptr[i] += stride_elems;
+        }
+    }
     __device__ __forceinline__ void store(char* tile) const {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
@@ -231,12 +267,159 @@ __device__ __forceinline__ void map_block(int L, int nblk, int H, int npairs, bo
 // ===================================================================================================
 // forward
 // ===================================================================================================
-// Forward: 8 waves x 32 query rows (two waves per SIMD), 64-key K/V tiles double-buffered in LDS, register staged
-// (the loads of tile t+1 are issued before the MFMAs of tile t and written to LDS after them; one barrier per tile).
-// Variants that were built and measured slower on MI355X at S=8,T=2048,H=32 (kept out of the tree, numbers in DESIGN.md):
-// 4 waves x 64 rows at one wave per SIMD, a half-tile stagger between the two halves of the workgroup, and an
-// in-wave S(t+1) || softmax(t) software pipeline (hipcc either keeps the streams in separate blocks or over-hoists
-// and spills).
+// 8 waves x 32 query rows (two waves per SIMD), 64-key K/V tiles double-buffered in LDS, register staged (the loads of
+// tile t+1 are issued before the MFMAs of tile t and written to LDS after them; one barrier per tile).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float xhalf_max(float v) {   // max with the lane 32 away (v_permlane32_swap: no LDS round trip)
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// The tile body is two straight-line blocks in which the wave's own vector work rides in the shadow of its own MFMAs
+// (the interleave is written out in the source and pinned with scheduling fences):
+//   A:  S0 = K[0:32] Q^T ; S1 = K[32:64] Q^T  ||  max(S0), P0 = exp2(S0*sc - m_ref), sum      then max(S1)
+//   B:  O^T += V^T[:, 0:32] P0^T              ||  P1 = exp2(S1*sc - m_ref), sum ;  O^T += V^T[:, 32:64] P1^T
+// The exponent reference m_ref is only moved when a row's maximum exceeds it by more than 2^RESCALE_AT (the first tile
+// always does): that rare path sits between A and B, rescales O / l and recomputes P0 from the untouched S0; O is not
+// multiplied every tile.  Cross-half reductions use v_permlane32_swap (no LDS round trip), the exp2 argument / row sums use
+// packed fp32 ops, full tiles are fetched by pointer bumps (no per-tile 64-bit address arithmetic).
+// Variants built and measured on MI355X at S=8,T=2048,H=32 (numbers and PMC breakdown in DESIGN.md), none faster: 4 waves x
+// 64 rows at one wave per SIMD; a ping-pong of GEMM-only / softmax-only phases between the two waves of a SIMD (two barriers
+// per tile; the later-dispatched wave of each SIMD is starved whatever s_setprio says); the same with the two blocks in
+// rotated order and one barrier; 4-wave workgroups at two per CU.
+// ---------------------------------------------------------------------------------------------------
+template <bool MASK, bool CAUSAL>
+__device__ __forceinline__ void mask_half(f32x16& st, int kbase, int h, int len, int ql) {
+    if (!MASK) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int kl = kbase + acc_row(r, h);
+        if (kl >= len || (CAUSAL && kl > ql)) st[r] = -INFINITY;
+    }
+}
+__device__ __forceinline__ float half_max(const f32x16& st) {
+    float a = fmaxf(st[0], st[1]), b = fmaxf(st[2], st[3]);
+#pragma unroll
+    for (int r = 4; r < 16; r += 4) {
+        a = fmaxf(fmaxf(a, st[r]), st[r + 1]);
+        b = fmaxf(fmaxf(b, st[r + 2]), st[r + 3]);
+    }
+    return fmaxf(a, b);
+}
+// One 2-element slice of P = exp2(S * sc - m): elements r, r+1 of the accumulator -> bf16 pair in the B-operand fragment
+__device__ __forceinline__ void exp_pair(const f32x16& st, int r, f32x2 sc2, f32x2 ms2, f32x2& ps, s16x8& p_lo, s16x8& p_hi) {
+    f32x2 x = {st[r], st[r + 1]};
+    x = x * sc2 + ms2;
+    const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+    ps = ps + e;
+    const unsigned w = pack_bf16x2(e[0], e[1]);
+    if (r < 8) {
+        p_lo[r] = (short)(w & 0xffffu);
+        p_lo[r + 1] = (short)(w >> 16);
+    } else {
+        p_hi[r - 8] = (short)(w & 0xffffu);
+        p_hi[r - 7] = (short)(w >> 16);
+    }
+}
+__device__ __forceinline__ float half_exp(const f32x16& st, float sc, float m_sub, s16x8& p_lo, s16x8& p_hi) {
+    const f32x2 sc2 = {sc, sc}, ms2 = {-m_sub, -m_sub};
+    f32x2 ps = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) exp_pair(st, r, sc2, ms2, ps, p_lo, p_hi);
+    return ps[0] + ps[1];
+}
+
+// scheduling fence that only LDS reads and scalar ops may cross: pins the MFMA / VALU interleave written in the source
+#define FENCE() __builtin_amdgcn_sched_barrier(0x100 | 0x004)
+
+#ifdef HALVA_STAMP
+#define STAMP_ARGS , unsigned long long (&stamp_acc)[6], unsigned long long& stamp_prev
+#define STAMP_PASS , stamp_acc, stamp_prev
+#else
+#define STAMP_ARGS
+#define STAMP_PASS
+#endif
+template <int D, bool CAUSAL, bool MASK, bool SLOW_TR>
+__device__ __forceinline__ void fwd_tile(const char* kt, const char* vt, const s16x8 (&qf)[D / 16], f32x16 (&oacc)[D / 32],
+                                          float& m_ref, float& l_run, float sc, int kv0, int len, int ql, int lane STAMP_ARGS) {
+    constexpr int KS = D / 16, DT = D / 32;
+    constexpr float RESCALE_AT = 64.f;     // log2 units: P stays below 2^64, far inside fp32 / bf16 range
+    static_assert(KS == 8 || KS == 4, "head_dim 128 or 64");
+    constexpr int PPS = 8 / KS;            // exp pairs handled per S1 MFMA (1 for D=128, 2 for D=64)
+    const int h = lane >> 5;
+    f32x16 s0, s1;
+    s16x8 p0a, p0b, p1a, p1b;
+    const f32x2 sc2 = {sc, sc};
+    // ---------------- block A: S0 bare, then S1 with softmax(S0) in its shadow ----------------
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s0[r] = 0.f, s1[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) s0 = mfma32(frag_rows<D>(kt, 0, ks, lane), qf[ks], s0);
+    mask_half<MASK, CAUSAL>(s0, kv0, h, len, ql);
+    STAMP(1);
+    const float msub_a = (m_ref == -INFINITY) ? 0.f : m_ref;
+    const f32x2 ms2a = {-msub_a, -msub_a};
+    f32x2 ps0 = {0.f, 0.f};
+    float mx0a = -INFINITY, mx0b = -INFINITY;
+    FENCE();
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        s1 = mfma32(frag_rows<D>(kt, 32, ks, lane), qf[ks], s1);
+        FENCE();
+#pragma unroll
+        for (int q = 0; q < PPS; ++q) {
+            const int r = 2 * (ks * PPS + q);
+            exp_pair(s0, r, sc2, ms2a, ps0, p0a, p0b);
+            if (q & 1 || PPS == 1 ? (ks & 1) : false) mx0b = fmaxf(fmaxf(mx0b, s0[r]), s0[r + 1]);
+            else mx0a = fmaxf(fmaxf(mx0a, s0[r]), s0[r + 1]);
+        }
+        FENCE();
+    }
+    mask_half<MASK, CAUSAL>(s1, kv0 + 32, h, len, ql);
+    float sum0 = ps0[0] + ps0[1];
+    const float tmax = xhalf_max(fmaxf(fmaxf(mx0a, mx0b), half_max(s1))) * sc;
+    STAMP(2);
+    // ---------------- rare: move the exponent reference ----------------
+    if (__any(tmax > m_ref + RESCALE_AT)) {
+        const float m_next = fmaxf(m_ref, tmax);
+        const float alpha = (m_next == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_ref - m_next);
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        m_ref = m_next;
+        sum0 = half_exp(s0, sc, (m_ref == -INFINITY) ? 0.f : m_ref, p0a, p0b);
+    }
+    STAMP(3);
+    // ---------------- block B: PV(P0) with softmax(S1) in its shadow, then PV(P1) bare ----------------
+    const float msub_b = (m_ref == -INFINITY) ? 0.f : m_ref;
+    const f32x2 ms2b = {-msub_b, -msub_b};
+    f32x2 ps1 = {0.f, 0.f};
+    FENCE();
+#pragma unroll
+    for (int i = 0; i < 2 * DT; ++i) {
+        const int ks = i / DT, dt = i % DT;
+        oacc[dt] = mfma32(frag_cols<D, SLOW_TR>(vt, 16 * ks, 32 * dt, lane), ks ? p0b : p0a, oacc[dt]);
+        FENCE();
+#pragma unroll
+        for (int q = 0; q < 8 / (2 * DT); ++q) exp_pair(s1, 2 * (i * (8 / (2 * DT)) + q), sc2, ms2b, ps1, p1a, p1b);
+        FENCE();
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * DT; ++i) {
+        const int ks = i / DT, dt = i % DT;
+        oacc[dt] = mfma32(frag_cols<D, SLOW_TR>(vt, 32 + 16 * ks, 32 * dt, lane), ks ? p1b : p1a, oacc[dt]);
+    }
+    l_run += sum0 + ps1[0] + ps1[1];
+    STAMP(4);
+}
+
 template <int D, bool CAUSAL, bool SLOW_TR>
 __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, int s, int hd, int qb) {
     constexpr int NW = 8, BN = 64, KS = D / 16, DT = D / 32, BM = 32 * NW, NT = 64 * NW;
@@ -247,14 +430,14 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     const int start = p.seq_start ? p.seq_start[s] : 0;
     const int len = p.seq_len ? p.seq_len[s] : p.T;
-    const int g0 = qb * BM;                          // first padded-row index of this block
+    const int g0 = qb * BM;
     const int64_t seq_row0 = (int64_t)s * p.T;
-    const int gq = g0 + 32 * wave + (lane & 31);     // this lane's query row (padded index)
-    const int ql = gq - start;                       // local (un-padded) query index
+    const int gq = g0 + 32 * wave + (lane & 31);
+    const int ql = gq - start;
     const bool q_in_T = gq < p.T;
     const bool q_valid = q_in_T && ql >= 0 && ql < len;
 
-    int kv_end = len;                                // key range this block needs (local indices)
+    int kv_end = len;
     if (CAUSAL) kv_end = min(len, g0 + BM - start);
     const int ntiles = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
 
@@ -262,7 +445,7 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
     const bf16_t* vp = p.v + hd * D;
     bf16_t* orow = p.o + (seq_row0 + gq) * p.ld_o + hd * D;
 
-    if (ntiles == 0) {   // every row of the block is padding
+    if (ntiles == 0) {
         if (q_in_T) {
             store_rows_zero<D>(orow, lane);
             if (h == 0 && p.lse) p.lse[((int64_t)s * p.H + hd) * p.T + gq] = 0.f;
@@ -270,7 +453,6 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
         return;
     }
 
-    // Q fragments (B operand of S^T = K Q^T): lane (q, h) holds Q[q][16*ks + 8*h .. +7]
     s16x8 qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -285,102 +467,66 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_ref = -INFINITY, l_run = 0.f;
     const float sc = p.scale * kLog2e;
-    const int wq_min = g0 + 32 * wave - start, wq_max = wq_min + 31;      // wave-level causal bounds (local indices)
+    const int wq_min = g0 + 32 * wave - start, wq_max = wq_min + 31;
 
     Stage<D, BN, NT> kst, vst;
     const int64_t krow0 = seq_row0 + start;
-    __syncthreads();      // the previous row block of this workgroup may still be reading its last tile
+    const int nfull = len / BN;
+    const int64_t tile_stride = (int64_t)BN * p.ld_qkv;
+    const bf16_t* kptr[Stage<D, BN, NT>::PER_THREAD];
+    const bf16_t* vptr[Stage<D, BN, NT>::PER_THREAD];
+    kst.init_ptrs(kptr, kp, p.ld_qkv, krow0, BN);
+    vst.init_ptrs(vptr, vp, p.ld_qkv, krow0, BN);
+    __syncthreads();
     kst.load_clamped(kp, p.ld_qkv, krow0, 0, len);
     vst.load_clamped(vp, p.ld_qkv, krow0, 0, len);
     kst.store(k_lds);
     vst.store(v_lds);
     __syncthreads();
+#ifdef HALVA_STAMP
+    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
 
     for (int it = 0; it < ntiles; ++it) {
         const int kv0 = it * BN;
         const char* kt = k_lds + (it & 1) * TILE_BYTES;
         const char* vt = v_lds + (it & 1) * TILE_BYTES;
-        if (it + 1 < ntiles) {
+        if (it + 1 < nfull) {
+            kst.load_bump(kptr, tile_stride);
+            vst.load_bump(vptr, tile_stride);
+        } else if (it + 1 < ntiles) {
             kst.load_clamped(kp, p.ld_qkv, krow0, kv0 + BN, len);
             vst.load_clamped(vp, p.ld_qkv, krow0, kv0 + BN, len);
         }
+        STAMP(0);
         if (!CAUSAL || kv0 <= wq_max) {
-            // ---- S^T[key][q] for the 64 keys of the tile
-            f32x16 st[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) st[t] = mfma32(frag_rows<D>(kt, 32 * t, ks, lane), qf[ks], st[t]);
-            }
-            // fragment reads run PREFETCH MFMAs ahead of their consumer (hipcc otherwise issues each ds_read right before
-            // the MFMA that needs it and exposes the LDS latency 2*KS times per tile)
-            {
-                constexpr int PREFETCH = 4, NM = 2 * KS;
-                __builtin_amdgcn_sched_group_barrier(0x100, PREFETCH, 0);
-#pragma unroll
-                for (int i = 0; i < NM - PREFETCH; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, PREFETCH, 0);
-            }
-            // ---- online softmax over the key axis (registers), log2 domain; the softmax scale rides in the exp2 FMA
-            if ((kv0 + BN > len) || (CAUSAL && kv0 + BN - 1 > wq_min)) {      // wave-uniform: boundary tiles only
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int kl = kv0 + 32 * t + acc_row(r, h);
-                        if (kl >= len || (CAUSAL && kl > ql)) st[t][r] = -INFINITY;
-                    }
-            }
-            float tmax = fmaxf(st[0][0], st[1][0]);
-#pragma unroll
-            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(st[0][r], st[1][r]));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run, tmax * sc);
-            const float m_sub = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_sub);
-            float psum = 0.f;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][r], sc, -m_sub));
-                    st[t][r] = e;
-                    psum += e;
-                }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
-            // ---- O^T[d][q] += V^T[d][key] P^T[key][q]
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const s16x8 pb = acc_to_frag(st[ks >> 1], ks & 1);
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-                    oacc[dt] = mfma32(frag_cols<D, SLOW_TR>(vt, 16 * ks, 32 * dt, lane), pb, oacc[dt]);
-            }
+            if ((kv0 + BN > len) || (CAUSAL && kv0 + BN - 1 > wq_min))      // wave-uniform: boundary tiles only
+                fwd_tile<D, CAUSAL, true, SLOW_TR>(kt, vt, qf, oacc, m_ref, l_run, sc, kv0, len, ql, lane STAMP_PASS);
+            else
+                fwd_tile<D, CAUSAL, false, SLOW_TR>(kt, vt, qf, oacc, m_ref, l_run, sc, kv0, len, ql, lane STAMP_PASS);
         }
         if (it + 1 < ntiles) {
             kst.store(k_lds + ((it + 1) & 1) * TILE_BYTES);
             vst.store(v_lds + ((it + 1) & 1) * TILE_BYTES);
         }
         __syncthreads();
+        STAMP(5);
     }
+#ifdef HALVA_STAMP
+    if (p.dbg && lane == 0 && s == 0 && hd == 0 && qb == p.nblk - 1) {
+        for (int i = 0; i < 6; ++i) p.dbg[wave * 8 + i] = stamp_acc[i];
+        p.dbg[wave * 8 + 6] = ntiles;
+    }
+#endif
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = xhalf_sum(l_run);
     const float inv = (q_valid && l_tot > 0.f) ? 1.f / l_tot : 0.f;
     if (q_in_T) {
         store_rows_T<D>(orow, oacc, inv, true, lane);
-        if (h == 0 && p.lse) p.lse[((int64_t)s * p.H + hd) * p.T + gq] = q_valid ? (m_run + log2f(l_tot)) * kLn2 : 0.f;
+        if (h == 0 && p.lse) p.lse[((int64_t)s * p.H + hd) * p.T + gq] = q_valid ? (m_ref + log2f(l_tot)) * kLn2 : 0.f;
     }
 }
 
@@ -787,8 +933,12 @@ int launch_one(KernelT kern, SdpaParams p, bool causal, int rows_per_block, int 
 }
 
 template <int D, bool CAUSAL>
-int launch_fwd(const SdpaParams& p, int S, hipStream_t st) {
+int launch_fwd(const SdpaParams& p_in, int S, hipStream_t st) {
     const size_t lds = 4 * 64 * D * 2;
+    SdpaParams p = p_in;
+#ifdef HALVA_STAMP
+    p.dbg = halva_dbg_buffer();
+#endif
     return slow_tr_requested() ? launch_one(sdpa_fwd_kernel<D, CAUSAL, true>, p, CAUSAL, 256, 512, lds, S, st, "sdpa_fwd")
                                : launch_one(sdpa_fwd_kernel<D, CAUSAL, false>, p, CAUSAL, 256, 512, lds, S, st, "sdpa_fwd");
 }
