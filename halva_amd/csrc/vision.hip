@@ -157,3 +157,132 @@ extern "C" int halva_downsample2x2(const void* x, void* out, int n, int g, int c
     HALVA_CHECK_LAUNCH("downsample2x2");
     return HALVA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Image preprocessing: Pillow's 8-bit bicubic resample + the HF processor's crop / rescale / normalise, for
+// a batch of decoded uint8 images.  Two passes like ImagingResample: horizontal into a uint8 scratch (only the rows the
+// vertical pass reads), vertical fused with the centre crop and the per-channel 256-entry normalise table.  The
+// expand2square canvas is virtual (pixels outside the pasted image read the fill colour).  Integer arithmetic is Pillow's
+// (22-bit fixed-point weights from the host, int32 accumulate with +2^21, shift, clip) so the uint8 results are bit-exact.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ int clip8(int v) {
+    v >>= 22;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+__global__ __launch_bounds__(256) void image_resample_h_kernel(const uint8_t* __restrict__ src, const HalvaImageDesc* __restrict__ descs,
+                                                               const int32_t* __restrict__ coef, const int32_t* __restrict__ bounds,
+                                                               uint8_t* __restrict__ tmp) {
+    const HalvaImageDesc d = descs[blockIdx.y];
+    const int64_t total = (int64_t)d.tmp_rows * d.out_w;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int xx = (int)(i % d.out_w), row = (int)(i / d.out_w);
+        const int cy = d.row0 + row - d.pad_y;                 // row inside the decoded image (may fall in the padding)
+        const bool row_in = cy >= 0 && cy < d.src_h;
+        const uint8_t* srow = src + d.src_off + (int64_t)(row_in ? cy : 0) * d.src_w * 3;
+        int o0, o1, o2;
+        if (d.need_h) {
+            const int xmin = bounds[d.bh_off + 2 * xx], n = bounds[d.bh_off + 2 * xx + 1];
+            const int32_t* k = coef + d.kh_off + (int64_t)xx * d.ksize_h;
+            int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+            for (int j = 0; j < n; ++j) {
+                const int cx = xmin + j - d.pad_x;
+                int p0 = d.bg[0], p1 = d.bg[1], p2 = d.bg[2];
+                if (row_in && cx >= 0 && cx < d.src_w) {
+                    p0 = srow[3 * cx];
+                    p1 = srow[3 * cx + 1];
+                    p2 = srow[3 * cx + 2];
+                }
+                a0 += p0 * k[j];
+                a1 += p1 * k[j];
+                a2 += p2 * k[j];
+            }
+            o0 = clip8(a0), o1 = clip8(a1), o2 = clip8(a2);
+        } else {
+            const int cx = xx - d.pad_x;
+            o0 = d.bg[0], o1 = d.bg[1], o2 = d.bg[2];
+            if (row_in && cx >= 0 && cx < d.src_w) {
+                o0 = srow[3 * cx];
+                o1 = srow[3 * cx + 1];
+                o2 = srow[3 * cx + 2];
+            }
+        }
+        uint8_t* t = tmp + d.tmp_off + ((int64_t)row * d.out_w + xx) * 3;
+        t[0] = (uint8_t)o0;
+        t[1] = (uint8_t)o1;
+        t[2] = (uint8_t)o2;
+    }
+}
+
+template <bool BF16OUT>
+__global__ __launch_bounds__(256) void image_resample_v_kernel(const uint8_t* __restrict__ tmp, const HalvaImageDesc* __restrict__ descs,
+                                                               const int32_t* __restrict__ coef, const int32_t* __restrict__ bounds,
+                                                               const float* __restrict__ lut, void* __restrict__ out, int crop_h,
+                                                               int crop_w) {
+    __shared__ float s_lut[3 * 256];
+    for (int i = threadIdx.x; i < 3 * 256; i += 256) s_lut[i] = lut[i];
+    __syncthreads();
+    const HalvaImageDesc d = descs[blockIdx.y];
+    const int64_t plane = (int64_t)crop_h * crop_w;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < plane; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % crop_w), y = (int)(i / crop_w);
+        const int rx = x + d.crop_x, ry = y + d.crop_y;
+        const uint8_t* t = tmp + d.tmp_off;
+        int o0, o1, o2;
+        if (d.need_v) {
+            const int ymin = bounds[d.bv_off + 2 * ry], n = bounds[d.bv_off + 2 * ry + 1];
+            const int32_t* k = coef + d.kv_off + (int64_t)ry * d.ksize_v;
+            int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+            for (int j = 0; j < n; ++j) {
+                const uint8_t* px = t + ((int64_t)(ymin + j) * d.out_w + rx) * 3;
+                a0 += px[0] * k[j];
+                a1 += px[1] * k[j];
+                a2 += px[2] * k[j];
+            }
+            o0 = clip8(a0), o1 = clip8(a1), o2 = clip8(a2);
+        } else {
+            const uint8_t* px = t + ((int64_t)ry * d.out_w + rx) * 3;
+            o0 = px[0], o1 = px[1], o2 = px[2];
+        }
+        const int64_t base = (int64_t)blockIdx.y * 3 * plane + i;
+        const float f0 = s_lut[o0], f1 = s_lut[256 + o1], f2 = s_lut[512 + o2];
+        if (BF16OUT) {
+            bf16_t* o = (bf16_t*)out;
+            o[base] = f32_to_bf16(f0);
+            o[base + plane] = f32_to_bf16(f1);
+            o[base + 2 * plane] = f32_to_bf16(f2);
+        } else {
+            float* o = (float*)out;
+            o[base] = f0;
+            o[base + plane] = f1;
+            o[base + 2 * plane] = f2;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int halva_image_preprocess(const void* src_pack, const HalvaImageDesc* descs, const int32_t* coef, const int32_t* bounds,
+                                      const float* lut, void* tmp, void* out, int n_images, int max_tmp_pixels, int crop_h,
+                                      int crop_w, halva_dtype out_dtype, void* stream) {
+    HALVA_CHECK_ARG(src_pack && descs && coef && bounds && lut && tmp && out, "image_preprocess: null pointer");
+    HALVA_CHECK_ARG(n_images > 0 && crop_h > 0 && crop_w > 0 && max_tmp_pixels > 0, "image_preprocess: bad sizes");
+    HALVA_CHECK_ARG(out_dtype == HALVA_BF16 || out_dtype == HALVA_F32, "image_preprocess: bad output dtype");
+    int gx = (max_tmp_pixels + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(image_resample_h_kernel, dim3(gx, n_images), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src_pack, descs,
+                       coef, bounds, (uint8_t*)tmp);
+    HALVA_CHECK_LAUNCH("image_resample_h");
+    int gy = (crop_h * crop_w + 255) / 256;
+    if (gy > 4096) gy = 4096;
+    if (out_dtype == HALVA_BF16)
+        hipLaunchKernelGGL(image_resample_v_kernel<true>, dim3(gy, n_images), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)tmp, descs,
+                           coef, bounds, lut, out, crop_h, crop_w);
+    else
+        hipLaunchKernelGGL(image_resample_v_kernel<false>, dim3(gy, n_images), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)tmp, descs,
+                           coef, bounds, lut, out, crop_h, crop_w);
+    HALVA_CHECK_LAUNCH("image_resample_v");
+    return HALVA_OK;
+}

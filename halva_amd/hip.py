@@ -36,6 +36,7 @@ SIGNATURES = {
     "halva_layernorm_fwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
     "halva_layernorm_bwd_params": [_P, _P, _P, _P, _P, _L, _I, _P],
     "halva_downsample2x2": [_P, _P, _I, _I, _I, _P],
+    "halva_image_preprocess": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "halva_gelu_bwd": [_P, _P, _P, _L, _I, _P],
     "halva_colsum": [_P, _P, _L, _I, _P],
     "halva_splice_rows": [_P, _P, _P, _P, _L, _I, _P],

@@ -121,6 +121,31 @@ int halva_layernorm_bwd_params(const void* dy, const void* x, const float* stats
                                void* stream);
 int halva_downsample2x2(const void* x, void* out, int n, int g, int c, void* stream);
 
+/* ---- image preprocessing on the GPU.  replaces, for a batch of DECODED uint8 RGB images, the per-sample
+ * expand2square + processor.preprocess of HallDataset.__getitem__ (llava/train/train_halva.py:735-751: PIL paste on a
+ * mean-coloured square, CLIPImageProcessor resize(shortest_edge, BICUBIC) / center_crop / rescale / normalize) and the
+ * VILA twin's `image.resize((S, S))` + SiglipImageProcessor (vila/mm_utils.py:150-193).  Pillow's 8-bit resample arithmetic
+ * is reproduced exactly (uint8 results bit-exact; the float output is a per-channel 256-entry table built by the host from
+ * rescale_factor / mean / std, so it is bit-exact too).  One descriptor per image; coefficient / bounds tables are the
+ * host's precompute_coeffs (22-bit fixed point), shared between images of equal geometry.
+ * tmp: uint8 scratch for the horizontal pass, out: [n_images, 3, crop_h, crop_w] bf16 or f32. */
+typedef struct {
+    int64_t src_off;              /* byte offset of the [src_h, src_w, 3] image in src_pack */
+    int64_t tmp_off;              /* byte offset of the [tmp_rows, out_w, 3] horizontal-pass result in tmp */
+    int32_t src_h, src_w;
+    int32_t pad_x, pad_y;         /* position of the image on the (virtual) expand2square canvas */
+    int32_t bg[3];                /* canvas fill colour */
+    int32_t out_h, out_w;         /* size after the resize, before the crop */
+    int32_t row0, tmp_rows;       /* canvas rows [row0, row0 + tmp_rows) feed the vertical pass */
+    int32_t kh_off, ksize_h, bh_off;
+    int32_t kv_off, ksize_v, bv_off;   /* vertical bounds are relative to row0 */
+    int32_t crop_y, crop_x;
+    int32_t need_h, need_v;
+} HalvaImageDesc;
+int halva_image_preprocess(const void* src_pack, const HalvaImageDesc* descs, const int32_t* coef, const int32_t* bounds,
+                           const float* lut, void* tmp, void* out, int n_images, int max_tmp_pixels, int crop_h, int crop_w,
+                           halva_dtype out_dtype, void* stream);
+
 /* ---- splice gather.  replaces the per-sample python loop of prepare_inputs_labels_for_multimodal[_signed]
  * (llava/model/llava_arch.py:285-374): out[r] = embed[src[r]] if src[r] >= 0, feats[-src[r]-2] if src[r] <= -2,
  * zeros if src[r] == -1 (padding).  src is the host-computed index plan, rows = S*T. */

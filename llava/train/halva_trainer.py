@@ -316,12 +316,28 @@ class HalvaTrainer:
                 cb.on_train_end(a, self.state, None, model=self.model)
         return self.state
 
+    def _image_pipeline(self):
+        """GPU preprocessing of decoded uint8 images (data_args.gpu_image_pipeline); built from the tower's processor."""
+        if getattr(self, "_pipe", None) is None:
+            from halva_amd.image_pipeline import GpuImagePipeline
+            da = self.train_dataset.data_args
+            self._pipe = GpuImagePipeline.from_processor(da.image_processor, da.image_aspect_ratio, device=self.model.device)
+        return self._pipe
+
+    @staticmethod
+    def _is_raw(v):
+        return isinstance(v, (list, tuple)) and len(v) > 0 and all(t.dtype == torch.uint8 and t.ndim == 3 and t.shape[-1] == 3 for t in v) \
+            or (isinstance(v, torch.Tensor) and v.dtype == torch.uint8 and v.ndim == 4 and v.shape[-1] == 3)
+
     def _to_device(self, batch):
         dev = self.model.device
         out = dict(batch)
         for k in ("images", "ref_images"):
             v = out[k]
-            out[k] = (torch.stack(v) if isinstance(v, (list, tuple)) else v).to(dev, torch.bfloat16, non_blocking=True)
+            if self._is_raw(v):
+                out[k] = self._image_pipeline()(list(v))
+            else:
+                out[k] = (torch.stack(v) if isinstance(v, (list, tuple)) else v).to(dev, torch.bfloat16, non_blocking=True)
         return out          # integer tensors stay on the host: the splice plan is computed there
 
     def save_state(self):

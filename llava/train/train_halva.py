@@ -63,6 +63,9 @@ class DataArguments:
     is_multimodal: bool = False
     image_folder: Optional[str] = field(default=None)
     image_aspect_ratio: str = "square"
+    # MI355X addition (default off = the reference's CPU preprocessing): the dataset hands over DECODED uint8 images and the
+    # trainer runs expand2square / bicubic resize / crop / normalise on the GPU (halva_amd/image_pipeline.py, bit-exact)
+    gpu_image_pipeline: bool = field(default_factory=lambda: os.environ.get("HALVA_GPU_IMAGE_PIPELINE", "0") == "1")
 
 
 @dataclass
@@ -144,6 +147,8 @@ def parse_args_into_dataclasses(classes, argv=None):
     for cls in classes:
         for f in dataclasses.fields(cls):
             default = None if f.default is dataclasses.MISSING else f.default
+            if f.default is dataclasses.MISSING and f.default_factory is not dataclasses.MISSING:
+                default = f.default_factory()
             base = f.type
             if getattr(base, "__origin__", None) is not None:               # Optional[X]
                 base = [a for a in base.__args__ if a is not type(None)][0]
@@ -425,6 +430,9 @@ class HallDataset(Dataset):
         from PIL import Image
         proc = self.data_args.image_processor
         img = Image.open(self.get_image_file_path(rel)).convert("RGB")
+        if getattr(self.data_args, "gpu_image_pipeline", False):
+            import numpy as np
+            return torch.from_numpy(np.asarray(img).copy())           # [H, W, 3] uint8; preprocessed on the GPU by the trainer
         if self.data_args.image_aspect_ratio == "pad":
             img = _expand2square(img, tuple(int(x * 255) for x in proc.image_mean))
         return proc.preprocess(img, return_tensors="pt")["pixel_values"][0]

@@ -82,3 +82,45 @@ def test_vila_train_entry_point(tmp_path, monkeypatch):
     for kk, v in nl.items():
         assert torch.equal(v, before[kk[len("mm_projector."):]]), kk
     assert os.path.exists(os.path.join(out, "config.json"))
+
+
+def test_gpu_image_pipeline_matches_cpu_dataset(tmp_path, monkeypatch):
+    """--gpu_image_pipeline True: the dataset hands over decoded uint8 images and the trainer's GPU preprocessing yields exactly
+    the tensors the reference's CPU path (expand2square + CLIPImageProcessor) produces, bf16-rounded; then a full train() run."""
+    import types
+    from transformers import CLIPImageProcessor
+    import llava.train.train_halva as TH
+    from llava import conversation as conv_lib
+    from llava.train.halva_trainer import HalvaTrainer
+    paths = e2e_util.build(str(tmp_path))
+    tok = e2e_util._Tok(model_max_length=64)
+    tok.pad_token = tok.unk_token
+    conv_lib.default_conversation = conv_lib.conv_templates["v1"]
+    proc = CLIPImageProcessor.from_pretrained(paths["vision"])
+    batches = {}
+    for flag in (False, True):
+        args = types.SimpleNamespace(data_path=paths["data"], ref_data_path=paths["ref"], image_folder=paths["images"],
+                                     image_aspect_ratio="pad", image_processor=proc, is_multimodal=True, mm_use_im_start_end=False,
+                                     gpu_image_pipeline=flag)
+        mod = TH.make_supervised_data_module(tok, args)
+        ds = mod["train_dataset"]
+        batch = mod["data_collator"]([ds[i] for i in range(4)])
+        stub = types.SimpleNamespace(model=types.SimpleNamespace(device=torch.device("cuda")), train_dataset=ds, _pipe=None)
+        stub._image_pipeline = types.MethodType(HalvaTrainer._image_pipeline, stub)
+        stub._is_raw = HalvaTrainer._is_raw
+        batches[flag] = HalvaTrainer._to_device(stub, batch)
+    for k in ("images", "ref_images"):
+        assert batches[True][k].dtype == torch.bfloat16 and batches[True][k].shape == batches[False][k].shape
+        assert torch.equal(batches[True][k].cpu(), batches[False][k].cpu()), k
+    e2e_util.patch_tokenizer(monkeypatch, paths["vocab_size"])
+    out = os.path.join(str(tmp_path), "out_gpu_pipe")
+    argv = ("--lora_enable True --lora_r 8 --lora_alpha 16 --mm_projector_lr 0 --loss_alpha 0.4 --model_name_or_path %s --version v1 "
+            "--data_path %s --ref_data_path %s --image_folder %s --vision_tower %s --mm_projector_type mlp2x_gelu "
+            "--mm_vision_select_layer -2 --mm_use_im_start_end False --mm_use_im_patch_token False --image_aspect_ratio pad "
+            "--group_by_modality_length True --bf16 True --output_dir %s "
+            "--num_train_epochs 1 --per_device_train_batch_size 2 --gradient_accumulation_steps 1 --learning_rate 1e-3 "
+            "--logging_steps 1 --model_max_length 64 --gpu_image_pipeline True"
+            % (paths["ckpt"], paths["data"], paths["ref"], paths["images"], paths["vision"], out)).split()
+    TH.train(argv)
+    state = json.load(open(os.path.join(out, "trainer_state.json")))
+    assert state["global_step"] == 3 and all(math.isfinite(r["loss"]) for r in state["log_history"])

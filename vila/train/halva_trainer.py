@@ -131,6 +131,9 @@ class HalvaTrainer(_Base):
         out = dict(batch)
         for k in ("images", "ref_images"):
             v = out[k]
+            if self._is_raw(v):
+                out[k] = self._image_pipeline()(list(v)).unsqueeze(1)          # [B, 1, 3, S, S] like the CPU path
+                continue
             if isinstance(v, (list, tuple)):
                 v = torch.stack([t if t.ndim == 4 else t[None] for t in v])
             out[k] = v.to(dev, torch.bfloat16, non_blocking=True)

@@ -44,6 +44,7 @@ class DataArguments:
     vflan_no_system_prompt: bool = False
     downsample_video: bool = False
     num_video_frames: int = 8
+    gpu_image_pipeline: bool = field(default_factory=lambda: os.environ.get("HALVA_GPU_IMAGE_PIPELINE", "0") == "1")   # see llava twin
 
 
 @dataclass
@@ -101,6 +102,13 @@ class HallDataset(_L.HallDataset):
     image is read from the TRAINING sample of the same index (:1111, `self.list_data_dict[i]["image"]`)."""
 
     def _images(self, image_file):
+        if getattr(self.data_args, "gpu_image_pipeline", False):
+            import numpy as np
+            from PIL import Image
+            if isinstance(image_file, list):
+                raise NotImplementedError("gpu_image_pipeline with several images per sample")
+            img = Image.open(self.get_image_file_path(image_file)).convert("RGB")
+            return torch.from_numpy(np.asarray(img).copy())               # [H, W, 3] uint8 -> GPU pipeline in the trainer
         if isinstance(image_file, list):
             return torch.stack([process_image(self.get_image_file_path(f), self.data_args, self.data_args.image_folder)
                                 for f in image_file])
@@ -130,7 +138,8 @@ class HallDataset(_L.HallDataset):
         n = preprocess_v1(n_src, self.tokenizer, has_image=("image" in neg))
         item = dict(input_ids=p["input_ids"][0], labels=p["labels"][0], neg_input_ids=n["input_ids"][0], neg_labels=n["labels"][0],
                     pos_signs=p["signs"][0], neg_signs=n["signs"][0])
-        item["image"] = (image if image.ndim == 4 else image.unsqueeze(0)) if has_image else self._blank()
+        raw = getattr(self.data_args, "gpu_image_pipeline", False)
+        item["image"] = (image if (raw or image.ndim == 4) else image.unsqueeze(0)) if has_image else self._blank()
         if self.ref_data_dict is not None:
             r = self.ref_getitem(i)
             item["ref_input_ids"], item["ref_labels"], item["ref_image"] = r["input_ids"], r["labels"], r["image"]
@@ -148,7 +157,8 @@ class HallDataset(_L.HallDataset):
             src = copy.deepcopy([s["conversations"]])
         d = preprocess_v1_ref_vila(src, self.tokenizer, has_image=has_image)
         out = dict(input_ids=d["input_ids"][0], labels=d["labels"][0])
-        out["image"] = (image if image.ndim == 4 else image.unsqueeze(0)) if has_image else self._blank()
+        raw = getattr(self.data_args, "gpu_image_pipeline", False)
+        out["image"] = (image if (raw or image.ndim == 4) else image.unsqueeze(0)) if has_image else self._blank()
         return out
 
 
