@@ -1,11 +1,10 @@
 #!/bin/bash
-# usage: tools/pmc_sdpa.sh <variant>   (run on the GPU box; writes gpurun_out/pmc_v<variant>/)
+# SQ counters of the SDPA kernels at the 7B per-layer shape (run on the GPU box: `gpurun -- bash tools/pmc_sdpa.sh`).
+# Two passes of 8 SQ counters each (PMC runs carry --kernel-trace only); writes gpurun_out/pmc_sdpa/{a,b}/*_counter_collection.csv.
 cd /tmp && export TMPDIR=/tmp
-V=$1
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_v$V
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_sdpa
 mkdir -p $OUT
-export HALVA_SDPA_FWD_PP=$V
 cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU -d $OUT/a -o a --output-format csv -- python3 tools/bench_sdpa.py > $OUT/a.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU GRBM_GUI_ACTIVE SQ_VALU_MFMA_COEXEC_CYCLES -d $OUT/b -o b --output-format csv -- python3 tools/bench_sdpa.py > $OUT/b.log 2>&1
-find $OUT -name "*counter_collection.csv" | head
+find $OUT -name "*counter_collection.csv"
