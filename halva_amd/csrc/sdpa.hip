@@ -66,6 +66,8 @@ struct SdpaParams {
     float* delta;         // [S, H, T]
     const int32_t* seq_start;
     const int32_t* seq_len;
+    const int32_t* br_a;  // optional per-sequence branch points (local indices; br_b a multiple of 64), include/halva_hip.h:
+    const int32_t* br_b;  // rows [br_b, len) do not attend to rows [br_a, br_b)
     int64_t ld_qkv;       // elements between consecutive tokens in q/k/v
     int64_t ld_o;         // elements between consecutive tokens in out
     int64_t ld_do;        // elements between consecutive tokens in dout
@@ -74,6 +76,20 @@ struct SdpaParams {
     unsigned long long* dbg;   // diagnostic builds only
     float scale;          // softmax scale
 };
+
+// Two responses sharing one prefix are packed as [prefix | A | pad | B] in one sequence: B (rows >= b, b a multiple of 64 so
+// that no 32-row strip and no 64-key tile straddles it) must not see [a, b) = A and the padding.  For a strip of B rows a
+// key tile is therefore either untouched, wholly hidden (dropped), or cut at `a` - which is the ordinary "sequence ends at a"
+// mask.  Without branch points a = b = INT_MAX and nothing changes.
+struct Branch {
+    int a, b;
+};
+__device__ __forceinline__ Branch load_branch(const SdpaParams& p, int s) {
+    Branch br;
+    br.a = p.br_a ? p.br_a[s] : 0x7fffffff;
+    br.b = p.br_b ? p.br_b[s] : 0x7fffffff;
+    return br;
+}
 
 // Byte offset of 16-byte chunk `ch` of row `row` in a [rows][D] bf16 LDS tile.  The tile is cut into 8-row x 32-column
 // subtiles of 512 B; inside a subtile the four chunks of a row are XOR-ed with (row >> 2) & 3.  Conflict-free for the
@@ -490,6 +506,8 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
 
+    const Branch br = load_branch(p, s);
+    const bool wave_in_b = wq_min >= br.b;             // wave-uniform (br.b is a multiple of 64, strips are 32 rows)
     for (int it = 0; it < ntiles; ++it) {
         const int kv0 = it * BN;
         const char* kt = k_lds + (it & 1) * TILE_BYTES;
@@ -502,11 +520,13 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
             vst.load_clamped(vp, p.ld_qkv, krow0, kv0 + BN, len);
         }
         STAMP(0);
-        if (!CAUSAL || kv0 <= wq_max) {
-            if ((kv0 + BN > len) || (CAUSAL && kv0 + BN - 1 > wq_min))      // wave-uniform: boundary tiles only
-                fwd_tile<D, CAUSAL, true, SLOW_TR>(kt, vt, qf, oacc, m_ref, l_run, sc, kv0, len, ql, lane STAMP_PASS);
+        const bool hidden = wave_in_b && kv0 >= br.a && kv0 < br.b;                       // tile wholly inside [a, b)
+        const int len_t = (wave_in_b && kv0 < br.a && kv0 + BN > br.a) ? br.a : len;       // tile cut at a
+        if ((!CAUSAL || kv0 <= wq_max) && !hidden) {
+            if ((kv0 + BN > len_t) || (CAUSAL && kv0 + BN - 1 > wq_min))      // wave-uniform: boundary tiles only
+                fwd_tile<D, CAUSAL, true, SLOW_TR>(kt, vt, qf, oacc, m_ref, l_run, sc, kv0, len_t, ql, lane STAMP_PASS);
             else
-                fwd_tile<D, CAUSAL, false, SLOW_TR>(kt, vt, qf, oacc, m_ref, l_run, sc, kv0, len, ql, lane STAMP_PASS);
+                fwd_tile<D, CAUSAL, false, SLOW_TR>(kt, vt, qf, oacc, m_ref, l_run, sc, kv0, len_t, ql, lane STAMP_PASS);
         }
         if (it + 1 < ntiles) {
             kst.store(k_lds + ((it + 1) & 1) * TILE_BYTES);
@@ -630,6 +650,8 @@ __device__ __forceinline__ void sdpa_bwd_dq_block(const SdpaParams& p, char* sme
         for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.f;
 
     const int wq_min = g0 + 32 * wave - start, wq_max = wq_min + 31;
+    const Branch br = load_branch(p, s);
+    const bool wave_in_b = wq_min >= br.b;             // wave-uniform (br.b is a multiple of 64, strips are 32 rows)
     Stage<D, BN, NT> kst, vst;
     const int64_t krow0 = seq_row0 + start;
     __syncthreads();      // the previous row block of this workgroup may still be reading its last tile
@@ -647,7 +669,9 @@ __device__ __forceinline__ void sdpa_bwd_dq_block(const SdpaParams& p, char* sme
             kst.load_clamped(kp, p.ld_qkv, krow0, kv0 + BN, len);
             vst.load_clamped(vp, p.ld_qkv, krow0, kv0 + BN, len);
         }
-        const bool active = !CAUSAL || kv0 <= wq_max;
+        const bool hidden = wave_in_b && kv0 >= br.a && kv0 < br.b;                       // tile wholly inside [a, b)
+        const int len_t = (wave_in_b && kv0 < br.a && kv0 + BN > br.a) ? br.a : len;       // tile cut at a
+        const bool active = (!CAUSAL || kv0 <= wq_max) && !hidden;
         if (active) {
             f32x16 st[2], dp[2];
 #pragma unroll
@@ -663,13 +687,13 @@ __device__ __forceinline__ void sdpa_bwd_dq_block(const SdpaParams& p, char* sme
                     dp[t] = mfma32(frag_rows<D>(vt, 32 * t, ks, lane), dof[ks], dp[t]);
                 }
             }
-            if ((kv0 + BN > len) || (CAUSAL && kv0 + BN - 1 > wq_min)) {      // wave-uniform: boundary tiles only
+            if ((kv0 + BN > len_t) || (CAUSAL && kv0 + BN - 1 > wq_min)) {      // wave-uniform: boundary tiles only
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int kl = kv0 + 32 * t + acc_row(r, h);
-                        if (kl >= len || (CAUSAL && kl > ql)) st[t][r] = -INFINITY;      // -> P = 0
+                        if (kl >= len_t || (CAUSAL && kl > ql)) st[t][r] = -INFINITY;      // -> P = 0
                     }
             }
 #pragma unroll
@@ -741,7 +765,11 @@ __device__ __forceinline__ void sdpa_bwd_dkv_block(const SdpaParams& p, char* sm
     int q_begin = 0;
     if (CAUSAL) q_begin = max(0, kblk_min) / BQ * BQ;
     const bool block_has_keys = (kblk_min < len) && (kblk_min + 128 > 0);
-    const int ntiles = (block_has_keys && len > q_begin) ? (len - q_begin + BQ - 1) / BQ : 0;
+    // branch points: queries >= br.b never look at keys in [br.a, br.b); a key block wholly inside that range stops at br.b
+    const Branch br = load_branch(p, s);
+    const int q_stop = (kblk_min >= br.a && kblk_min + 127 < br.b) ? min(len, br.b) : len;
+    const int ntiles = (block_has_keys && q_stop > q_begin) ? (q_stop - q_begin + BQ - 1) / BQ : 0;
+    const bool key_hidden = kl >= br.a && kl < br.b;       // per lane: this key is invisible to branch-B queries
     if (ntiles == 0) {
         if (k_in_T) {
             store_rows_zero<D>(dkrow, lane);
@@ -824,7 +852,9 @@ __device__ __forceinline__ void sdpa_bwd_dkv_block(const SdpaParams& p, char* sm
 #pragma unroll
         for (int sub = 0; sub < SUB; ++sub) {
             const int q0 = qt0 + 32 * sub;
-            const bool active = (q0 < len) && (!CAUSAL || (q0 + 31 >= wk_min));
+            const bool q_in_b = q0 >= br.b;                 // uniform: br.b is a multiple of 64, sub-tiles are 32 rows
+            const bool wave_hidden = q_in_b && wk_min >= br.a && wk_min + 31 < br.b;
+            const bool active = (q0 < len) && (!CAUSAL || (q0 + 31 >= wk_min)) && !wave_hidden;
             if (!active) continue;
             // S[q][key] and dP[q][key]: key on the lane, q on the accumulator rows
             f32x16 sa, dpa;
@@ -842,11 +872,13 @@ __device__ __forceinline__ void sdpa_bwd_dkv_block(const SdpaParams& p, char* sm
             asm volatile("" : "+v"(sa[15]), "+v"(dpa[15]));
 #endif
             STAMP(1);
-            if ((q0 + 32 > len) || (CAUSAL && q0 < wk_min + 31) || wave_has_pad_keys) {      // wave-uniform
+            if ((q0 + 32 > len) || (CAUSAL && q0 < wk_min + 31) || wave_has_pad_keys ||
+                (q_in_b && wk_min < br.b && wk_min + 31 >= br.a)) {      // wave-uniform
+                const bool lane_off = !k_valid || (q_in_b && key_hidden);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ql = q0 + acc_row(r, h);
-                    if (ql >= len || (CAUSAL && kl > ql) || !k_valid) sa[r] = -INFINITY;      // -> P = 0
+                    if (ql >= len || (CAUSAL && kl > ql) || lane_off) sa[r] = -INFINITY;      // -> P = 0
                 }
             }
 #pragma unroll
@@ -974,6 +1006,13 @@ extern "C" int halva_sdpa_causal_fwd(const void* qkv, void* out, float* lse, con
 
 extern "C" int halva_sdpa_causal_fwd_ld(const void* qkv, void* out, int64_t ld_out, float* lse, const int32_t* seq_start,
                                         const int32_t* seq_len, int S, int T, int H, int D, float scale, void* stream) {
+    return halva_sdpa_branch_fwd(qkv, out, ld_out, lse, seq_start, seq_len, nullptr, nullptr, S, T, H, D, scale, stream);
+}
+
+extern "C" int halva_sdpa_branch_fwd(const void* qkv, void* out, int64_t ld_out, float* lse, const int32_t* seq_start,
+                                     const int32_t* seq_len, const int32_t* br_a, const int32_t* br_b, int S, int T, int H, int D,
+                                     float scale, void* stream) {
+    HALVA_CHECK_ARG((br_a == nullptr) == (br_b == nullptr), "sdpa_branch_fwd: br_a and br_b go together");
     HALVA_CHECK_ARG(qkv && out && lse, "sdpa_causal_fwd: null pointer");
     HALVA_CHECK_ARG(ld_out >= (int64_t)H * D && ld_out % 8 == 0, "sdpa_causal_fwd: bad output row stride %lld", (long long)ld_out);
     HALVA_CHECK_ARG(D == 128 || D == 64, "sdpa_causal_fwd: head_dim %d not supported (64 or 128)", D);
@@ -987,6 +1026,8 @@ extern "C" int halva_sdpa_causal_fwd_ld(const void* qkv, void* out, int64_t ld_o
     p.lse = lse;
     p.seq_start = seq_start;
     p.seq_len = seq_len;
+    p.br_a = br_a;
+    p.br_b = br_b;
     p.ld_qkv = 3 * (int64_t)H * D;
     p.ld_o = ld_out;
     p.T = T;
@@ -1006,6 +1047,14 @@ extern "C" int halva_sdpa_causal_bwd_ld(const void* qkv, const void* out, int64_
                                         const float* lse, void* dqkv, float* delta_ws, float* dq_ws, const int32_t* seq_start,
                                         const int32_t* seq_len, int S, int T, int H, int D, float scale, void* stream) {
     (void)dq_ws;
+    return halva_sdpa_branch_bwd(qkv, out, ld_out, dout, ld_dout, lse, dqkv, delta_ws, seq_start, seq_len, nullptr, nullptr, S, T, H, D,
+                                 scale, stream);
+}
+
+extern "C" int halva_sdpa_branch_bwd(const void* qkv, const void* out, int64_t ld_out, const void* dout, int64_t ld_dout,
+                                     const float* lse, void* dqkv, float* delta_ws, const int32_t* seq_start, const int32_t* seq_len,
+                                     const int32_t* br_a, const int32_t* br_b, int S, int T, int H, int D, float scale, void* stream) {
+    HALVA_CHECK_ARG((br_a == nullptr) == (br_b == nullptr), "sdpa_branch_bwd: br_a and br_b go together");
     HALVA_CHECK_ARG(ld_out >= (int64_t)H * D && ld_out % 8 == 0 && ld_dout >= (int64_t)H * D && ld_dout % 8 == 0,
                     "sdpa_causal_bwd: bad row strides %lld / %lld", (long long)ld_out, (long long)ld_dout);   // reserved for an atomics-based dQ variant; the shipped dQ kernel needs no scratch
     HALVA_CHECK_ARG(qkv && out && dout && lse && dqkv && delta_ws, "sdpa_causal_bwd: null pointer");
@@ -1026,6 +1075,8 @@ extern "C" int halva_sdpa_causal_bwd_ld(const void* qkv, const void* out, int64_
     p.delta = delta_ws;
     p.seq_start = seq_start;
     p.seq_len = seq_len;
+    p.br_a = br_a;
+    p.br_b = br_b;
     p.ld_qkv = 3 * (int64_t)H * D;
     p.ld_o = ld_out;
     p.ld_do = ld_dout;

@@ -66,9 +66,10 @@ def rope_tables(head_dim, max_pos, base=10000.0, device="cuda", linear_factor=1.
     return freqs.cos().to(torch.bfloat16).contiguous(), freqs.sin().to(torch.bfloat16).contiguous()
 
 
-def _rope_inplace(qkv, cos, sin, T, H, D, inverse):
+def _rope_inplace(qkv, cos, sin, T, H, D, inverse, pos=None):
+    """pos: optional int32 [rows] position of every row (branch-packed sequences); default = row index inside its sequence."""
     rows = qkv.numel() // (3 * H * D)
-    call("halva_rope_qk", ptr(qkv), ptr(cos), ptr(sin), None, rows, T, H, D, cos.shape[0], int(inverse), stream_ptr())
+    call("halva_rope_qk", ptr(qkv), ptr(cos), ptr(sin), ptr(pos), rows, T, H, D, cos.shape[0], int(inverse), stream_ptr())
 
 
 class _RopeQK(torch.autograd.Function):
@@ -77,15 +78,15 @@ class _RopeQK(torch.autograd.Function):
     buffer), so this node's backward is the identity."""
 
     @staticmethod
-    def forward(ctx, qkv, cos, sin, H, D):
+    def forward(ctx, qkv, cos, sin, H, D, pos=None):
         _chk(qkv, torch.bfloat16, "qkv")
-        _rope_inplace(qkv, cos, sin, qkv.shape[1], H, D, False)
+        _rope_inplace(qkv, cos, sin, qkv.shape[1], H, D, False, pos)
         ctx.mark_dirty(qkv)
         return qkv
 
     @staticmethod
     def backward(ctx, dqkv):
-        return dqkv, None, None, None, None
+        return dqkv, None, None, None, None, None
 
 
 class _SdpaCausal(torch.autograd.Function):
@@ -94,14 +95,18 @@ class _SdpaCausal(torch.autograd.Function):
     the inverse rotation to dq, dk (see _RopeQK)."""
 
     @staticmethod
-    def forward(ctx, qkv, seq_start, seq_len, H, D, cos, sin, out_width=None):
+    def forward(ctx, qkv, seq_start, seq_len, H, D, cos, sin, out_width=None, branch=None):
+        """branch: optional (br_a, br_b, pos) int32 device tensors - packed [prefix | A | B] rows whose B part must not see A
+        (halva_sdpa_branch_fwd) and whose RoPE positions are given explicitly."""
         _chk(qkv, torch.bfloat16, "qkv")
         S, T = qkv.shape[0], qkv.shape[1]
         width = out_width or H * D
         out = torch.empty(S, T, width, dtype=torch.bfloat16, device=qkv.device)
         lse = torch.empty(S, H, T, dtype=torch.float32, device=qkv.device)
-        call("halva_sdpa_causal_fwd_ld", ptr(qkv), ptr(out), width, ptr(lse), ptr(seq_start), ptr(seq_len), S, T, H, D, 0.0,
-             stream_ptr())
+        br_a, br_b, pos = branch if branch is not None else (None, None, None)
+        call("halva_sdpa_branch_fwd", ptr(qkv), ptr(out), width, ptr(lse), ptr(seq_start), ptr(seq_len), ptr(br_a), ptr(br_b), S, T, H,
+             D, 0.0, stream_ptr())
+        ctx.branch = branch
         ctx.save_for_backward(qkv, lse, seq_start, seq_len)
         # `out` may be the (wider) operand buffer of the next LoRA projection, which fills its right columns in place; the
         # backward only reads the left H*D columns, so keep a detached alias instead of a version-checked saved tensor
@@ -118,22 +123,23 @@ class _SdpaCausal(torch.autograd.Function):
         dout = _chk(dout.contiguous(), torch.bfloat16, "dout")
         dqkv = torch.empty_like(qkv)
         delta = torch.empty(S, H, T, dtype=torch.float32, device=qkv.device)
-        call("halva_sdpa_causal_bwd_ld", ptr(qkv), ptr(out), width, ptr(dout), dout.shape[-1], ptr(lse), ptr(dqkv), ptr(delta),
-             None, ptr(seq_start), ptr(seq_len), S, T, H, D, 0.0, stream_ptr())
+        br_a, br_b, pos = ctx.branch if ctx.branch is not None else (None, None, None)
+        call("halva_sdpa_branch_bwd", ptr(qkv), ptr(out), width, ptr(dout), dout.shape[-1], ptr(lse), ptr(dqkv), ptr(delta),
+             ptr(seq_start), ptr(seq_len), ptr(br_a), ptr(br_b), S, T, H, D, 0.0, stream_ptr())
         cos, sin = ctx.rope
         if cos is not None:
-            _rope_inplace(dqkv, cos, sin, T, H, D, True)
-        return dqkv, None, None, None, None, None, None, None
+            _rope_inplace(dqkv, cos, sin, T, H, D, True, pos)
+        return dqkv, None, None, None, None, None, None, None, None
 
 
-def attention(qkv, cos, sin, seq_start, seq_len, H, D, out_width=None):
+def attention(qkv, cos, sin, seq_start, seq_len, H, D, out_width=None, branch=None):
     """RoPE (in place) + causal attention on a packed [S, T, 3*H*D] projection output."""
-    qkv = _RopeQK.apply(qkv, cos, sin, H, D)
-    return _SdpaCausal.apply(qkv, seq_start, seq_len, H, D, cos, sin, out_width)
+    qkv = _RopeQK.apply(qkv, cos, sin, H, D, None if branch is None else branch[2])
+    return _SdpaCausal.apply(qkv, seq_start, seq_len, H, D, cos, sin, out_width, branch)
 
 
-def sdpa_causal(qkv, seq_start, seq_len, H, D):
-    return _SdpaCausal.apply(qkv, seq_start, seq_len, H, D, None, None)
+def sdpa_causal(qkv, seq_start, seq_len, H, D, br_a=None, br_b=None):
+    return _SdpaCausal.apply(qkv, seq_start, seq_len, H, D, None, None, None, None if br_a is None else (br_a, br_b, None))
 
 
 def sdpa_full(qkv, H, D, scale=0.0):

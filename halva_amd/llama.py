@@ -273,8 +273,9 @@ class LoraGroup(nn.Module):
 class SeqInfo:
     """Per-forward constants shared by all layers: RoPE tables and the valid span of every padded row."""
 
-    def __init__(self, cos, sin, seq_start, seq_len):
+    def __init__(self, cos, sin, seq_start, seq_len, branch=None):
         self.cos, self.sin, self.seq_start, self.seq_len = cos, sin, seq_start, seq_len
+        self.branch = branch       # (br_a, br_b, pos) of branch-packed rows, or None (halva_amd/kernels.py:_SdpaCausal)
 
 
 class DecoderLayer(nn.Module):
@@ -301,7 +302,7 @@ class DecoderLayer(nn.Module):
         # every producer kernel writes straight into the (wider) operand buffer of the projection that follows it
         h = self.input_layernorm(x, self.qkv.in_width)
         qkv = self.qkv(h, None, use_lora)
-        a = K.attention(qkv, info.cos, info.sin, info.seq_start, info.seq_len, self.H, self.D, self.o.in_width)
+        a = K.attention(qkv, info.cos, info.sin, info.seq_start, info.seq_len, self.H, self.D, self.o.in_width, info.branch)
         x = self.o(a, x, use_lora)
         h = self.post_attention_layernorm(x, self.gate_up.in_width)
         act = K.swiglu(self.gate_up(h, None, use_lora), self.down.in_width)
@@ -332,14 +333,15 @@ class LlamaModel(nn.Module):
             self._rope[(str(device), n)] = self._rope[key]
         return self._rope[key]
 
-    def run_layers(self, x, seq_start, seq_len, use_lora=True):
-        """x [S, T, d] bf16 -> last hidden state after the final RMSNorm (modelling_llama.py:580-705)."""
+    def run_layers(self, x, seq_start, seq_len, use_lora=True, branch=None):
+        """x [S, T, d] bf16 -> last hidden state after the final RMSNorm (modelling_llama.py:580-705).
+        branch = (br_a, br_b, pos): rows are packed [prefix | A | B] sequences (see halva_sdpa_branch_fwd)."""
         T = x.shape[1]
         cos, sin = self.rope(T, x.device)
         if cos.shape[0] < T:
             self._rope = {}
             cos, sin = self.rope(T, x.device)
-        info = SeqInfo(cos, sin, seq_start, seq_len)
+        info = SeqInfo(cos, sin, seq_start, seq_len, branch)
         for layer in self.layers:
             if self.gradient_checkpointing and torch.is_grad_enabled() and x.requires_grad:
                 x = torch.utils.checkpoint.checkpoint(layer, x, info, use_lora, use_reentrant=False)

@@ -81,6 +81,19 @@ int halva_sdpa_causal_bwd_ld(const void* qkv, const void* out, int64_t ld_out, c
                              const float* lse, void* dqkv, float* delta_ws, float* dq_ws, const int32_t* seq_start,
                              const int32_t* seq_len, int S, int T, int H, int D, float scale, void* stream);
 
+/* Branched causal attention: one packed sequence [prefix | A | pad | B] per row; rows >= br_b[s] (branch B) do not attend to
+ * rows [br_a[s], br_b[s]) (branch A and the padding); everything else is causal.  Lets the correct and the hallucinated
+ * response of a pair share ONE forward/backward over their common prefix (image + prompt + identical start of the response) -
+ * the reference runs the prefix twice, once per row of the concatenated batch (llava/train/halva_trainer.py:434-470).
+ * br_a / br_b: int32 [S] row indices, or both NULL = plain causal (the entries above).  Contract: br_b[s] is a multiple of 64
+ * (no 32-row strip / 64-key tile straddles it; rows in [br_a + len(A), br_b) are padding whose output is unspecified) and
+ * seq_start[s] == 0 for a branched sequence; br_a[s] = br_b[s] >= seq_len[s] marks a sequence without a branch.  RoPE
+ * positions of branch B restart at br_a (halva_rope_qk's `pos` argument). */
+int halva_sdpa_branch_fwd(const void* qkv, void* out, int64_t ld_out, float* lse, const int32_t* seq_start, const int32_t* seq_len,
+                          const int32_t* br_a, const int32_t* br_b, int S, int T, int H, int D, float scale, void* stream);
+int halva_sdpa_branch_bwd(const void* qkv, const void* out, int64_t ld_out, const void* dout, int64_t ld_dout, const float* lse,
+                          void* dqkv, float* delta_ws, const int32_t* seq_start, const int32_t* seq_len, const int32_t* br_a,
+                          const int32_t* br_b, int S, int T, int H, int D, float scale, void* stream);
 /* ---- non-causal self-attention, bf16, head_dim 64, forward only (the CLIP tower runs under no_grad:
  * llava/model/multimodal_encoder/clip_encoder.py:37-49; replaces HF CLIPAttention's softmax(QK^T*scale)V).
  * qkv: [N, S, 3, H, D] packed; out [N, S, H, D]. */
