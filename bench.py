@@ -276,8 +276,14 @@ def main():
                                        "step (fwd+bwd+loss+grad all-reduce+AdamW)" % (1 if args.model == "7b" else 3, args.model.upper(), B)),
                           "pairs_per_gpu": B, "global_pairs": B * ctx.world, "seq_len": seq, "parallelism": "dp%d" % ctx.world,
                           "pairs_per_group": args.pairs_per_group, "recompute": "none",
+                          "prefix_sharing": None if eng.last_packing is None else
+                          {"rows_run": eng.last_packing[0], "rows_of_the_two_separate_sequences": eng.last_packing[1],
+                           "note": "the correct and the hallucinated row of a pair share ONE pass over their common prefix "
+                                   "(image + prompt + identical start of the response: 668 of 2048 rows in this layout); results are "
+                                   "those of the reference's two separate rows (HALVA_SHARE_PREFIX=0 runs them separately)"},
                           "valid": not bool(args.layers) and args.model == "7b"},
                "loss": round(loss_val, 5),
+               # reference-algorithm FLOPs per pair x pairs/s: with prefix sharing fewer are executed
                "step_tflops_per_gpu": None if tf_pair is None else round(pairs_per_s / ctx.world * tf_pair, 1),
                "step_mfma_frac": None if tf_pair is None else round(pairs_per_s / ctx.world * tf_pair / PEAK_BF16_TFLOPS, 4),
                "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),

@@ -15,6 +15,7 @@ for one MI355X without changing its arithmetic:
     consumed in place by the token-logp / KL kernels, which also emit the gradient w.r.t. the hidden state.
 """
 import math
+import os
 import warnings
 
 from types import SimpleNamespace
@@ -203,13 +204,15 @@ class DPAStepPlan:
         return gp
 
 
-def _kept_rows(labels):
-    """Rows (flattened [S, T-1] index into the [S, T] hidden states) whose shifted label is a real token."""
+def _kept_rows(labels, row_of=None):
+    """Rows (flattened [S, T-1] index into the [S, T] hidden states) whose shifted label is a real token.
+    row_of (optional, [S, T]): flat index of the hidden state of (row, position) in another layout (packed pairs)."""
     lab = labels.numpy()
     S, T = lab.shape
     tgt = lab[:, 1:]
     s_idx, t_idx = np.nonzero(tgt != IGNORE_INDEX)
-    hid = torch.from_numpy((s_idx * T + t_idx).astype(np.int64))            # position t predicts label t+1
+    flat = (s_idx * T + t_idx) if row_of is None else row_of[s_idx, t_idx]
+    hid = torch.from_numpy(flat.astype(np.int64))                           # position t predicts label t+1
     dense = torch.from_numpy((s_idx * (T - 1) + t_idx).astype(np.int64))
     target = torch.from_numpy(tgt[s_idx, t_idx].astype(np.int32))
     return hid, dense, target
@@ -230,9 +233,15 @@ def model_spec(model):
 class DPAEngine:
     """Forward/backward of the DPA loss on one GPU.  `policy` / `ref_model` are LlavaLlamaForCausalLM instances."""
 
-    def __init__(self, policy, ref_model, loss_alpha, pairs_per_group=4, ref_rows_per_group=8):
+    def __init__(self, policy, ref_model, loss_alpha, pairs_per_group=4, ref_rows_per_group=8, share_prefix=None):
         self.policy, self.ref_model, self.alpha = policy, ref_model, float(loss_alpha)
         self.pairs_per_group, self.ref_rows_per_group = pairs_per_group, ref_rows_per_group
+        # run the common prefix of a pair (image + prompt + identical start of the response) once: the correct and the
+        # hallucinated row are packed into one branched sequence (halva_amd/splice.py:pack_pairs).  HALVA_SHARE_PREFIX=0 runs
+        # them as two rows like the reference does.
+        # share_prefix: True = when it saves rows, "always" = even when the 64-row alignment padding eats the saving (tests)
+        self.share_prefix = (os.environ.get("HALVA_SHARE_PREFIX", "1") != "0") if share_prefix is None else share_prefix
+        self.last_packing = None
 
     @property
     def spec(self):
@@ -269,8 +278,18 @@ class DPAEngine:
         gp = plan.pair_group(idx)
         g = len(idx)
         feats = self._encode(pol, batch, "images", gp, dev)                              # [g, n_patch, d]; grads -> projector
-        h = self._hidden(pol, gp, feats)
-        hid, dense, target = _kept_rows(gp.labels)
+        packed = SP.pack_pairs(gp) if (self.share_prefix and gp.seq_start.numpy().max(initial=0) == 0) else None
+        if packed is not None and (packed.rows_packed < packed.rows_unpacked or self.share_prefix == "always"):
+            # the two rows of a pair run as ONE packed row [prefix | correct rest | pad | hallucinated rest]
+            m = pol.get_model()
+            embeds = K.splice_rows(m.embed_tokens.weight, feats, packed.src.to(dev, non_blocking=True), g, packed.T)
+            branch = tuple(t.to(dev, non_blocking=True) for t in (packed.br_a, packed.br_b, packed.pos))
+            h = pol.hidden_states(embeds, None, torch.zeros(g, dtype=torch.int32), packed.seq_len, branch=branch)
+            hid, dense, target = _kept_rows(gp.labels, packed.row_of)
+            self.last_packing = (packed.rows_packed, packed.rows_unpacked)
+        else:
+            h = self._hidden(pol, gp, feats)
+            hid, dense, target = _kept_rows(gp.labels)
         T1 = gp.T - 1
         logp_dense = torch.zeros(2 * g * T1, dtype=torch.float32, device=dev)
         if hid.numel():

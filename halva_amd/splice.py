@@ -122,3 +122,69 @@ def spans_from_mask(mask):
     if not np.array_equal(m, (idx >= start[:, None]) & (idx < (start + length)[:, None])):
         raise ValueError("attention_mask must mark one contiguous run of valid tokens per sequence")
     return torch.from_numpy(start), torch.from_numpy(length)
+
+
+# ------------------------------------------------------------------------------------------------
+# prefix sharing between the two rows of a pair
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class PackedPairs:
+    """g packed rows [prefix | A | pad | B] built from the 2g spliced rows [pos(0..g-1) ; neg(0..g-1)] of a pair group.
+
+    The correct and the hallucinated sequence of a pair start with the same image, prompt and (usually) the same beginning of
+    the response; under a causal mask their hidden states are identical up to the first differing input row, so the prefix is
+    run ONCE: A = the rest of the correct row, B = the rest of the hallucinated row, B never attends to A
+    (halva_sdpa_branch_fwd) and B's RoPE positions continue from the prefix."""
+    src: torch.Tensor          # int32 [g * T]: splice source per packed row (same encoding as SplicePlan.src)
+    pos: torch.Tensor          # int32 [g * T]: RoPE position of every packed row
+    br_a: torch.Tensor         # int32 [g]: prefix length (first row of A)
+    br_b: torch.Tensor         # int32 [g]: first row of B (multiple of 64)
+    seq_len: torch.Tensor      # int32 [g]
+    T: int
+    row_of: np.ndarray         # int64 [2g, T_unpacked]: packed flat row index holding the hidden state of (row, position); -1 = none
+    rows_packed: int           # sum of packed lengths
+    rows_unpacked: int         # sum of the 2g un-packed lengths
+
+
+def pack_pairs(plan, align=64):
+    """plan: SplicePlan of 2g right-padded rows, row i and row g+i forming a pair."""
+    S, T = plan.S, plan.T
+    g = S // 2
+    src = plan.src.numpy().reshape(S, T)
+    lens = plan.seq_len.numpy().astype(np.int64)
+    if int(plan.seq_start.numpy().max(initial=0)) != 0:
+        raise ValueError("pack_pairs needs right-padded rows")
+    rows, poss, a_s, b_s, n_s = [], [], [], [], []
+    maps = []
+    for i in range(g):
+        lp, ln = int(lens[i]), int(lens[g + i])
+        m = min(lp, ln)
+        neq = np.nonzero(src[i, :m] != src[g + i, :m])[0]
+        L = int(neq[0]) if len(neq) else m                      # length of the common prefix
+        b = (lp + align - 1) // align * align                   # B starts on a tile boundary; rows [lp, b) are padding
+        nb = ln - L
+        row = np.full(b + nb, -1, dtype=np.int32)
+        row[:lp] = src[i, :lp]
+        row[b:] = src[g + i, L:ln]
+        pos = np.zeros(b + nb, dtype=np.int32)
+        pos[:lp] = np.arange(lp)
+        pos[b:] = np.arange(L, ln)
+        rows.append(row), poss.append(pos), a_s.append(L), b_s.append(b), n_s.append(b + nb)
+        mp, mn = np.full(T, -1, dtype=np.int64), np.full(T, -1, dtype=np.int64)
+        mp[:lp] = np.arange(lp)
+        mn[:L] = np.arange(L)
+        mn[L:ln] = b + np.arange(nb)
+        maps.append((mp, mn))
+    Tp = max(n_s) if n_s else 0
+    out_src = np.full((g, Tp), -1, dtype=np.int32)
+    out_pos = np.zeros((g, Tp), dtype=np.int32)
+    row_of = np.full((S, T), -1, dtype=np.int64)
+    for i in range(g):
+        out_src[i, :n_s[i]] = rows[i]
+        out_pos[i, :n_s[i]] = poss[i]
+        mp, mn = maps[i]
+        row_of[i] = np.where(mp >= 0, mp + i * Tp, -1)
+        row_of[g + i] = np.where(mn >= 0, mn + i * Tp, -1)
+    i32 = lambda v: torch.from_numpy(np.asarray(v, dtype=np.int32))
+    return PackedPairs(src=torch.from_numpy(out_src.reshape(-1)), pos=torch.from_numpy(out_pos.reshape(-1)), br_a=i32(a_s), br_b=i32(b_s),
+                       seq_len=i32(n_s), T=Tp, row_of=row_of, rows_packed=int(sum(n_s)), rows_unpacked=int(lens.sum()))

@@ -12,13 +12,13 @@ from golden_util import load_npz, tensors  # noqa: E402
 from model_util import batch_of, build_product_models  # noqa: E402
 
 
-def _engine(z, pairs_per_group, ref_rows_per_group):
+def _engine(z, pairs_per_group, ref_rows_per_group, share_prefix=None):
     from halva_amd import dpa
     pol, ref, lora = build_product_models(z)
     flat = dpa.FlatTrainables(dpa.trainable_named_parameters(pol))
     dpa.bind_model(flat, pol)
     dpa.set_grad_sink(pol, True)
-    eng = dpa.DPAEngine(pol, ref, float(z["alpha"]), pairs_per_group, ref_rows_per_group)
+    eng = dpa.DPAEngine(pol, ref, float(z["alpha"]), pairs_per_group, ref_rows_per_group, share_prefix=share_prefix)
     return eng, pol, ref, flat, lora
 
 
@@ -31,14 +31,17 @@ FIXTURES = {"dpa_step_d64_init": (1e-3, 1e-3, 1e-3), "dpa_step_d64": (8e-3, 8e-3
 
 
 @pytest.mark.parametrize("fixture", list(FIXTURES))
-@pytest.mark.parametrize("ppg,rpg", [(8, 8), (2, 1)])
-def test_step_matches_reference_golden(ppg, rpg, fixture):
+@pytest.mark.parametrize("ppg,rpg,share", [(8, 8, False), (2, 1, False), (8, 8, "always"), (1, 2, "always")])
+def test_step_matches_reference_golden(ppg, rpg, share, fixture):
+    """share = "always": the two rows of every pair run as one branched row [prefix | correct | pad | hallucinated] (prefix run
+    once) - same reference numbers, same tolerances."""
     tol_loss, tol_align, tol_div = FIXTURES[fixture]
     z = load_npz(fixture + ".npz")
-    eng, pol, ref, flat, (r, alpha, fac) = _engine(z, ppg, rpg)
+    eng, pol, ref, flat, (r, alpha, fac) = _engine(z, ppg, rpg, share)
     batch = batch_of(z)
     loss = eng.loss(batch, backward=True)
     torch.cuda.synchronize()
+    assert (eng.last_packing is not None) == (share == "always")
     got = float(loss)
     parts = {k: float(v) for k, v in eng.last_parts.items()}
     assert abs(got - float(z["out.loss"])) < tol_loss, (got, float(z["out.loss"]))

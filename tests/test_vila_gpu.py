@@ -131,20 +131,20 @@ def test_vila_signed_splice_on_gpu(case, side):
         assert _rel(o2[4], torch.from_numpy(z["unsigned.embeds"])) < 2e-2
 
 
-def _engine(z, ppg, rpg):
+def _engine(z, ppg, rpg, share=None):
     from halva_amd import dpa
     pol, ref, lora = build_product_vila(z)
     flat = dpa.FlatTrainables(dpa.trainable_named_parameters(pol))
     dpa.bind_model(flat, pol)
     dpa.set_grad_sink(pol, True)
-    return dpa.DPAEngine(pol, ref, float(z["alpha"]), ppg, rpg), pol, ref, flat, lora
+    return dpa.DPAEngine(pol, ref, float(z["alpha"]), ppg, rpg, share_prefix=share), pol, ref, flat, lora
 
 
 @pytest.mark.parametrize("fixture", ["vila_step_init", "vila_step_multi"])
-@pytest.mark.parametrize("ppg,rpg", [(8, 8), (2, 1)])
-def test_vila_step_matches_reference_golden(fixture, ppg, rpg):
+@pytest.mark.parametrize("ppg,rpg,share", [(8, 8, False), (2, 1, False), (8, 8, "always")])
+def test_vila_step_matches_reference_golden(fixture, ppg, rpg, share):
     z = load_npz(fixture + ".npz")
-    eng, pol, ref, flat, (r, alpha, fac) = _engine(z, ppg, rpg)
+    eng, pol, ref, flat, (r, alpha, fac) = _engine(z, ppg, rpg, share)
     batch = batch_of(z)
     loss = eng.loss(batch, backward=True)
     torch.cuda.synchronize()
