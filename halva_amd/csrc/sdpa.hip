@@ -487,53 +487,57 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
     const float sc = p.scale * kLog2e;
     const int wq_min = g0 + 32 * wave - start, wq_max = wq_min + 31;
 
+    const Branch br = load_branch(p, s);
+    const bool wave_in_b = wq_min >= br.b;             // wave-uniform (br.b is a multiple of 64, strips are 32 rows)
     Stage<D, BN, NT> kst, vst;
     const int64_t krow0 = seq_row0 + start;
-    const int nfull = len / BN;
-    const int64_t tile_stride = (int64_t)BN * p.ld_qkv;
-    const bf16_t* kptr[Stage<D, BN, NT>::PER_THREAD];
-    const bf16_t* vptr[Stage<D, BN, NT>::PER_THREAD];
-    kst.init_ptrs(kptr, kp, p.ld_qkv, krow0, BN);
-    vst.init_ptrs(vptr, vp, p.ld_qkv, krow0, BN);
-    __syncthreads();
-    kst.load_clamped(kp, p.ld_qkv, krow0, 0, len);
-    vst.load_clamped(vp, p.ld_qkv, krow0, 0, len);
-    kst.store(k_lds);
-    vst.store(v_lds);
-    __syncthreads();
 #ifdef HALVA_STAMP
     unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
-
-    const Branch br = load_branch(p, s);
-    const bool wave_in_b = wq_min >= br.b;             // wave-uniform (br.b is a multiple of 64, strips are 32 rows)
-    for (int it = 0; it < ntiles; ++it) {
-        const int kv0 = it * BN;
-        const char* kt = k_lds + (it & 1) * TILE_BYTES;
-        const char* vt = v_lds + (it & 1) * TILE_BYTES;
-        if (it + 1 < nfull) {
-            kst.load_bump(kptr, tile_stride);
-            vst.load_bump(vptr, tile_stride);
-        } else if (it + 1 < ntiles) {
-            kst.load_clamped(kp, p.ld_qkv, krow0, kv0 + BN, len);
-            vst.load_clamped(vp, p.ld_qkv, krow0, kv0 + BN, len);
-        }
-        STAMP(0);
-        const bool hidden = wave_in_b && kv0 >= br.a && kv0 < br.b;                       // tile wholly inside [a, b)
-        const int len_t = (wave_in_b && kv0 < br.a && kv0 + BN > br.a) ? br.a : len;       // tile cut at a
-        if ((!CAUSAL || kv0 <= wq_max) && !hidden) {
-            if ((kv0 + BN > len_t) || (CAUSAL && kv0 + BN - 1 > wq_min))      // wave-uniform: boundary tiles only
-                fwd_tile<D, CAUSAL, true, SLOW_TR>(kt, vt, qf, oacc, m_ref, l_run, sc, kv0, len_t, ql, lane STAMP_PASS);
-            else
-                fwd_tile<D, CAUSAL, false, SLOW_TR>(kt, vt, qf, oacc, m_ref, l_run, sc, kv0, len_t, ql, lane STAMP_PASS);
-        }
-        if (it + 1 < ntiles) {
-            kst.store(k_lds + ((it + 1) & 1) * TILE_BYTES);
-            vst.store(v_lds + ((it + 1) & 1) * TILE_BYTES);
-        }
+    // A row block wholly in branch B does not even stage the key tiles that lie wholly inside [a, b): the tile range is walked
+    // in (up to) two segments [0, skip_lo) and [skip_hi, ntiles), each a plain double-buffered loop (one barrier per tile).
+    int skip_lo = ntiles, skip_hi = ntiles;
+    if (g0 - start >= br.b) {
+        skip_lo = min(ntiles, (br.a + BN - 1) / BN);
+        skip_hi = max(skip_lo, min(ntiles, br.b / BN));
+    }
+#pragma unroll 1
+    for (int seg = 0; seg < 2; ++seg) {
+        const int t0 = seg ? skip_hi : 0, t1 = seg ? ntiles : skip_lo;
+        if (t0 >= t1) continue;
+        __syncthreads();      // earlier readers of the LDS slots (previous segment / previous row block) are done
+        kst.load_clamped(kp, p.ld_qkv, krow0, t0 * BN, len);
+        vst.load_clamped(vp, p.ld_qkv, krow0, t0 * BN, len);
+        kst.store(k_lds);
+        vst.store(v_lds);
         __syncthreads();
-        STAMP(5);
+#pragma unroll 1
+        for (int it = t0; it < t1; ++it) {
+            const int kv0 = it * BN;
+            const int slot = (it - t0) & 1;
+            const char* kt = k_lds + slot * TILE_BYTES;
+            const char* vt = v_lds + slot * TILE_BYTES;
+            if (it + 1 < t1) {
+                kst.load_clamped(kp, p.ld_qkv, krow0, kv0 + BN, len);
+                vst.load_clamped(vp, p.ld_qkv, krow0, kv0 + BN, len);
+            }
+            STAMP(0);
+            const bool hidden = wave_in_b && kv0 >= br.a && kv0 < br.b;                       // tile wholly inside [a, b)
+            const int len_t = (wave_in_b && kv0 < br.a && kv0 + BN > br.a) ? br.a : len;       // tile cut at a
+            if ((!CAUSAL || kv0 <= wq_max) && !hidden) {
+                if ((kv0 + BN > len_t) || (CAUSAL && kv0 + BN - 1 > wq_min))      // wave-uniform: boundary tiles only
+                    fwd_tile<D, CAUSAL, true, SLOW_TR>(kt, vt, qf, oacc, m_ref, l_run, sc, kv0, len_t, ql, lane STAMP_PASS);
+                else
+                    fwd_tile<D, CAUSAL, false, SLOW_TR>(kt, vt, qf, oacc, m_ref, l_run, sc, kv0, len_t, ql, lane STAMP_PASS);
+            }
+            if (it + 1 < t1) {
+                kst.store(k_lds + (slot ^ 1) * TILE_BYTES);
+                vst.store(v_lds + (slot ^ 1) * TILE_BYTES);
+            }
+            __syncthreads();
+            STAMP(5);
+        }
     }
 #ifdef HALVA_STAMP
     if (p.dbg && lane == 0 && s == 0 && hd == 0 && qb == p.nblk - 1) {
@@ -654,18 +658,29 @@ __device__ __forceinline__ void sdpa_bwd_dq_block(const SdpaParams& p, char* sme
     const bool wave_in_b = wq_min >= br.b;             // wave-uniform (br.b is a multiple of 64, strips are 32 rows)
     Stage<D, BN, NT> kst, vst;
     const int64_t krow0 = seq_row0 + start;
-    __syncthreads();      // the previous row block of this workgroup may still be reading its last tile
-    kst.load_clamped(kp, p.ld_qkv, krow0, 0, len);
-    vst.load_clamped(vp, p.ld_qkv, krow0, 0, len);
-    kst.store(k_lds);
-    vst.store(v_lds);
-    __syncthreads();
-
-    for (int it = 0; it < ntiles; ++it) {
+    // key-tile range in (up to) two segments around the tiles a branch-B row block never needs (see the forward)
+    int skip_lo = ntiles, skip_hi = ntiles;
+    if (g0 - start >= br.b) {
+        skip_lo = min(ntiles, (br.a + BN - 1) / BN);
+        skip_hi = max(skip_lo, min(ntiles, br.b / BN));
+    }
+#pragma unroll 1
+    for (int seg = 0; seg < 2; ++seg) {
+        const int t0 = seg ? skip_hi : 0, t1 = seg ? ntiles : skip_lo;
+        if (t0 >= t1) continue;
+        __syncthreads();      // earlier readers of the LDS slots (previous segment / previous row block) are done
+        kst.load_clamped(kp, p.ld_qkv, krow0, t0 * BN, len);
+        vst.load_clamped(vp, p.ld_qkv, krow0, t0 * BN, len);
+        kst.store(k_lds);
+        vst.store(v_lds);
+        __syncthreads();
+#pragma unroll 1
+        for (int it = t0; it < t1; ++it) {
         const int kv0 = it * BN;
-        const char* kt = k_lds + (it & 1) * TILE_BYTES;
-        const char* vt = v_lds + (it & 1) * TILE_BYTES;
-        if (it + 1 < ntiles) {
+        const int slot = (it - t0) & 1;
+        const char* kt = k_lds + slot * TILE_BYTES;
+        const char* vt = v_lds + slot * TILE_BYTES;
+        if (it + 1 < t1) {
             kst.load_clamped(kp, p.ld_qkv, krow0, kv0 + BN, len);
             vst.load_clamped(vp, p.ld_qkv, krow0, kv0 + BN, len);
         }
@@ -711,11 +726,12 @@ __device__ __forceinline__ void sdpa_bwd_dq_block(const SdpaParams& p, char* sme
                     dqacc[dt] = mfma32(frag_cols<D, SLOW_TR>(kt, 16 * ks, 32 * dt, lane), zb, dqacc[dt]);
             }
         }
-        if (it + 1 < ntiles) {
-            kst.store(k_lds + ((it + 1) & 1) * TILE_BYTES);
-            vst.store(v_lds + ((it + 1) & 1) * TILE_BYTES);
+        if (it + 1 < t1) {
+            kst.store(k_lds + (slot ^ 1) * TILE_BYTES);
+            vst.store(v_lds + (slot ^ 1) * TILE_BYTES);
         }
         __syncthreads();
+        }
     }
     if (q_in_T) store_rows_T<D>(dqrow, dqacc, q_valid ? p.scale : 0.f, true, lane);
 }
