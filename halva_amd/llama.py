@@ -92,7 +92,7 @@ class _LoraGroupFn(torch.autograd.Function):
         lora = A is not None
         if lora:
             Gr = A.shape[0]
-            xa2[:, K:K + Gr].copy_(torch.mm(xa2[:, :K], A.t()))
+            torch.mm(xa2[:, :K], A.t(), out=xa2[:, K:K + Gr])      # written in place through the row stride (no temporary)
             if K + Gr < width:
                 xa2[:, K + Gr:].zero_()          # padding columns (rank not a multiple of 8) must not hold NaN garbage
             lhs, rhs = xa2, Wc
