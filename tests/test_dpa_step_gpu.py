@@ -135,3 +135,19 @@ def test_optimizer_step_moves_lora_not_projector():
     assert not torch.equal(flat.master[:lo], before[:lo])
     l1 = float(eng.loss(batch_of(z), backward=False))
     assert l1 < l0
+
+
+def test_dgrad_layout_switch_gives_the_same_gradients(monkeypatch):
+    """HALVA_DGRAD_WT: dx = dy W through the transposed weight copy (NT GEMM, default) or the stored weight (NN GEMM)."""
+    import halva_amd.llama as L
+    z = load_npz("dpa_step_d64.npz")
+    grads = {}
+    for flag in (True, False):
+        monkeypatch.setattr(L, "DGRAD_TRANSPOSED_COPY", flag)
+        eng, pol, ref, flat, _ = _engine(z, 8, 8)
+        has_copy = [grp.weight_cat_t is not None for layer in pol.model.layers for _, grp in layer.groups()]
+        assert all(has_copy) if flag else not any(has_copy)
+        loss = float(eng.loss(batch_of(z), backward=True))
+        grads[flag] = (loss, flat.grad.clone())
+    assert grads[True][0] == grads[False][0]                                    # the forward does not depend on it
+    assert float((grads[True][1] - grads[False][1]).norm() / grads[False][1].norm()) < 2e-3
