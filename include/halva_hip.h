@@ -36,7 +36,8 @@ int halva_abi_version(void);
 const char* halva_last_error(void);
 
 /* ---- Llama RMSNorm.  replaces LlamaRMSNorm.forward (llava/model/language_model/modelling_llama.py:65-70)
- * y = w * cast(x_f32 * rsqrt(mean(x_f32^2) + eps)); rstd[rows] (f32) is saved for the backward.
+ * y = bf16(w * x_f32 * rsqrt(mean(x_f32^2) + eps)) - the module's fp32 value, rounded once (its intermediate cast to the input
+ * dtype is a no-op on the fp32 CPU path that parity is defined against); rstd[rows] (f32) is saved for the backward.
  * bwd gives dx only (norm weights are frozen on the LoRA DPA path; llava/train/train_halva.py:1085-1101). */
 int halva_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int d, float eps, void* stream);
 int halva_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, int64_t rows, int d,
