@@ -37,7 +37,7 @@ TFLOP_PER_PAIR = 214.7            # BASELINE.md section 2 (7B, T = 2048, LoRA r 
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def synthetic_batch(B, seed, resp_len=1419, vocab=32000, image=336, images_per_sample=None):
+def synthetic_batch(B, seed, resp_len=1419, vocab=32000, image=336, images_per_sample=None, n_phrases=6):
     """BASELINE.md section 3 layout: [BOS, 34 prompt, <image>, 12 question, 5 'ASSISTANT:', R response, EOS]."""
     g = torch.Generator().manual_seed(seed)
     pre = 1 + 34
@@ -55,7 +55,7 @@ def synthetic_batch(B, seed, resp_len=1419, vocab=32000, image=336, images_per_s
     pos = ids()
     neg = pos.clone()
     signs = torch.zeros(B, L, dtype=torch.long)
-    for k in range(6):
+    for k in range(n_phrases):
         s = off + 40 + 200 * k
         signs[:, s:s + 3] = k + 1
         neg[:, s:s + 3] = torch.randint(3, vocab, (B, 3), generator=g)
@@ -181,6 +181,9 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="debug: override the layer count (result is then marked invalid)")
     ap.add_argument("--pairs-per-group", type=int, default=int(os.environ.get("HALVA_PAIRS_PER_GROUP", "0")),
                     help="default 8 (7b) / 4 (13b) / 2 (vila13b)")
+    ap.add_argument("--resp-len", type=int, default=0,
+                    help="response length in tokens (default: fill T to 2048 / 4096 as BASELINE.md section 3 prescribes; other values "
+                         "mark the line invalid - e.g. 128 resembles the real HALVA data, where the shared prefix dominates)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -230,8 +233,8 @@ def main():
                         ref_rows_per_group=2 * args.pairs_per_group)
     B = args.pairs_per_gpu
     n_patch = dpa.model_spec(policy).n_patch                     # 576 (CLIP-L/336) or 196 (SigLIP-384 + mlp_downsample)
-    batch = synthetic_batch(B, 1234 + ctx.rank, resp_len=seq - n_patch - 53, image=384 if vila else 336,
-                            images_per_sample=1 if vila else None)
+    batch = synthetic_batch(B, 1234 + ctx.rank, resp_len=args.resp_len or (seq - n_patch - 53), image=384 if vila else 336,
+                            images_per_sample=1 if vila else None, n_phrases=6 if not args.resp_len else max(1, min(6, (args.resp_len - 43) // 200 + 1)))
     batch["images"] = batch["images"].to(dev, torch.bfloat16)          # inputs resident in HBM before the timed region
     batch["ref_images"] = batch["ref_images"].to(dev, torch.bfloat16)
 
@@ -274,14 +277,14 @@ def main():
                                        "BASELINE metric)" % (seq, B)) if vila else
                                       ("configs[%d]: LLaVA-1.5-%s LoRA(r=128) DPA step, 336px, T=2048 post-splice, %d pairs per GPU per "
                                        "step (fwd+bwd+loss+grad all-reduce+AdamW)" % (1 if args.model == "7b" else 3, args.model.upper(), B)),
-                          "pairs_per_gpu": B, "global_pairs": B * ctx.world, "seq_len": seq, "parallelism": "dp%d" % ctx.world,
+                          "pairs_per_gpu": B, "global_pairs": B * ctx.world, "seq_len": seq if not args.resp_len else n_patch + 53 + args.resp_len, "parallelism": "dp%d" % ctx.world,
                           "pairs_per_group": args.pairs_per_group, "recompute": "none",
                           "prefix_sharing": None if eng.last_packing is None else
                           {"rows_run": eng.last_packing[0], "rows_of_the_two_separate_sequences": eng.last_packing[1],
                            "note": "the correct and the hallucinated row of a pair share ONE pass over their common prefix "
                                    "(image + prompt + identical start of the response: 668 of 2048 rows in this layout); results are "
                                    "those of the reference's two separate rows (HALVA_SHARE_PREFIX=0 runs them separately)"},
-                          "valid": not bool(args.layers) and args.model == "7b"},
+                          "valid": not bool(args.layers) and args.model == "7b" and not args.resp_len},
                "loss": round(loss_val, 5),
                # reference-algorithm FLOPs per pair x pairs/s: with prefix sharing fewer are executed
                "step_tflops_per_gpu": None if tf_pair is None else round(pairs_per_s / ctx.world * tf_pair, 1),
