@@ -157,3 +157,29 @@ def test_product_fails_loudly_without_gpu():
             hip.load()
     finally:
         hip.LIB_PATH, hip._lib = old, saved
+
+
+def test_bench_synthetic_batch_follows_baseline_layout():
+    """[BOS, 34 prompt, <image>, 12 question, 5 'ASSISTANT:', R response, EOS], T = 2048 after the splice,
+    six 3-token phrases at 40 + 200k, neg == pos outside the phrases - and what the prefix-sharing plan makes of it."""
+    import numpy as np
+    import bench
+    from halva_amd import splice as SP
+    from halva_amd.dpa import concat_pos_neg, phrase_slots
+    b = bench.synthetic_batch(2, 7)
+    ids, neg = b["input_ids"].numpy(), b["neg_input_ids"].numpy()
+    assert ids.shape == (2, 1 + 34 + 1 + 12 + 5 + 1419 + 1) and (ids[:, 0] == 1).all() and (ids[:, 35] == -200).all() and (ids[:, -1] == 2).all()
+    off = 1 + 34 + 1 + 12 + 5
+    diff = ids != neg
+    spans = np.zeros_like(diff)
+    for k in range(6):
+        spans[:, off + 40 + 200 * k: off + 43 + 200 * k] = True
+    assert not (diff & ~spans).any() and (b["pos_signs"].numpy() > 0).sum() == 2 * 18
+    assert (b["labels"].numpy()[:, :off] == -100).all() and (b["labels"].numpy()[:, off:] == ids[:, off:]).all()
+    c_ids, c_lab, c_att, c_sig = concat_pos_neg(b)
+    plan = SP.plan_splice(c_ids, c_att, c_lab, c_sig, 576, 2048, "right", image_map=[0, 1, 0, 1])
+    assert plan.T == 2048 and plan.seq_len.tolist() == [2048] * 4
+    assert len(phrase_slots(plan.signs.numpy()[:2, 1:])) == 6
+    pk = SP.pack_pairs(plan)
+    assert pk.br_a.tolist() == [628 + 40] * 2 and pk.br_b.tolist() == [2048] * 2       # shared: prefix + the first 40 response tokens
+    assert pk.rows_packed == 2 * (2048 + 2048 - 668) and pk.rows_unpacked == 4 * 2048
