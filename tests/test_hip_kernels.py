@@ -221,6 +221,43 @@ def test_sdpa_branch_fwd_bwd(T, lens, starts, br_a, br_b, H, D):
             assert rel_err(o[s, starts[s]:e].detach(), plain[s, starts[s]:e]) < 3e-3
 
 
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_sdpa_branch_random_layouts(seed):
+    """Random packed layouts as halva_amd/splice.py:pack_pairs produces them (prefix, rest of the correct row, pad to 64, rest of
+    the hallucinated row; empty parts included), two rows per launch, against the dense-mask reference."""
+    rng = np.random.RandomState(100 + seed)
+    H, D = 2, 128
+    lens, br_a, br_b = [], [], []
+    for _ in range(2):
+        L = int(rng.choice([0, 1, 17, 64, 130, 333]))           # common prefix
+        la = int(rng.choice([0, 1, 40, 64, 200]))               # rest of the correct row
+        nb = int(rng.choice([0, 1, 33, 64, 257]))               # rest of the hallucinated row
+        if L + la == 0:
+            la = 5
+        b = (L + la + 63) // 64 * 64
+        lens.append(b + nb), br_a.append(L), br_b.append(b)
+    T = max(lens) + int(rng.randint(0, 40))
+    starts = [0, 0]
+    g = torch.Generator().manual_seed(seed)
+    qkv = bf(torch.randn(2, T, 3, H, D, generator=g))
+    dout = bf(torch.randn(2, T, H, D, generator=g))
+    for s in range(2):
+        dout[s, lens[s]:] = 0
+    qg = qkv.to(DEV).view(2, T, 3 * H * D).clone().requires_grad_(True)
+    mk = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    out = K().sdpa_causal(qg, mk(starts), mk(lens), H, D, mk(br_a), mk(br_b))
+    out.backward(dout.to(DEV).view(2, T, H * D))
+    r = qkv.float().requires_grad_(True)
+    ref = _branch_ref(r, starts, lens, br_a, br_b)
+    ref.backward(dout.float())
+    o = out.view(2, T, H, D).cpu().float()
+    assert torch.isfinite(o).all() and torch.isfinite(qg.grad).all()
+    assert rel_err(o, ref) < 1e-2, (lens, br_a, br_b)
+    dq = qg.grad.view(2, T, 3, H, D).cpu().float()
+    for i, n in enumerate("dq dk dv".split()):
+        assert rel_err(dq[:, :, i], r.grad[:, :, i]) < 2e-2, (n, lens, br_a, br_b)
+
+
 def test_sdpa_full_clip_shape():
     N, S, H, D = 2, 577, 16, 64
     g = torch.Generator().manual_seed(4)
