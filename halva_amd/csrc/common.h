@@ -40,8 +40,12 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(bf16_t, b);
 }
+// one v_cvt_pk_bf16_f32 (the scalar form above only sometimes folds into it)
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ float bf16_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }

@@ -959,6 +959,357 @@ __global__ __launch_bounds__(256, 1) void sdpa_bwd_dkv_kernel(const SdpaParams p
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// backward, part 2, two-role form.  The one-wave-per-SIMD kernel above keeps K, V, dK and dV of its 32 keys in 362 registers.
+// Here the two waves of a SIMD split that state: wave w (0..3, "V side") owns K fragments and dV of key strip w, wave w+4
+// ("K side") owns V fragments and dK of the SAME strip, so both fit the 256-register budget of two waves per SIMD and one's
+// MFMAs run beside the other's vector work.  Per 32-row sub-tile:
+//   V side:  S = Q K^T  ->  P = exp2(S*sc - lse) (masks applied here)  ->  P to LDS (bf16, accumulator layout)  ->  dV^T += dO^T P
+//   K side:  dP = dO V^T  ->  P from LDS  ->  dZ = P o (dP - delta)  ->  dK^T += Q^T dZ
+// The K side runs one staged step behind the V side, so the workgroup barrier of the step (needed for the Q/dO ring anyway) is the
+// only synchronisation; the Q/dO ring has 3 slots (steps t-1, t and the one being fetched), P has 2 (by step parity).
+// ---------------------------------------------------------------------------------------------------
+// Fill one [64][D] tile image (the tile_off layout) straight from global memory, no register staging: each
+// global_load_lds_dwordx4 writes 1 KiB of LDS at (wave-uniform base + 16 * lane), so lane l of chunk c fetches the 16 bytes
+// whose tile_off is 1024 c + 16 l - the swizzle is applied to the SOURCE address.  Rows outside [0, limit) read the nearest
+// valid row, as Stage::load_clamped.  NW waves share the tile's chunks.
+template <int D, int NW>
+__device__ __forceinline__ void stage_tile_dma(char* tile, const bf16_t* base, int64_t ld, int64_t grow_local0, int local0, int limit,
+                                               int wave, int lane) {
+    constexpr int CHUNKS = 64 * D * 2 / 1024, SUBROW = (D / 32) * 512;
+    static_assert(CHUNKS % NW == 0, "chunks must split evenly over the waves");
+#pragma unroll
+    for (int i = 0; i < CHUNKS / NW; ++i) {
+        const int c = wave + NW * i;
+        const int o = 1024 * c + 16 * lane;
+        const int band = o / SUBROW, rem = o % SUBROW;
+        const int row = 8 * band + ((rem % 512) >> 6);
+        const int ch = 4 * (rem / 512) + (((rem >> 4) & 3) ^ ((row >> 2) & 3));
+        const int loc = min(max(local0 + row, 0), limit - 1);
+        const bf16_t* src = base + (grow_local0 + loc) * ld + ch * 8;
+        // written as asm: the builtin makes hipcc drain vmcnt(0) before the next ds_read_b64_tr_b16, i.e. in the middle of the step
+        const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(tile + 1024 * c);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
+}
+// the loads above are invisible to the compiler's counters: wait for them by hand before the barrier that publishes the tile
+// (s_waitcnt vmcnt(0) as the builtin, not asm: the compiler then also knows that nothing of its own is pending afterwards)
+__device__ __forceinline__ void stage_tile_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
+#ifndef DKV2_INTERLEAVE
+#define DKV2_INTERLEAVE 0
+#endif
+template <int D, bool CAUSAL, bool SLOW_TR, int ROLE>
+__device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* smem, int s, int hd, int kb, int strip) {
+    constexpr int BQ = 64, SUB = 2, KS = D / 16, DT = D / 32, NT = 512;
+    constexpr int TILE_BYTES = BQ * D * 2;
+    char* q_lds = smem;                                    // [3][BQ][D]
+    char* do_lds = smem + 3 * TILE_BYTES;                  // [3][BQ][D]
+    float* lse_lds = reinterpret_cast<float*>(smem + 6 * TILE_BYTES);   // [3][BQ]
+    float* dlt_lds = lse_lds + 3 * BQ;                                  // [3][BQ]
+    char* p_lds = reinterpret_cast<char*>(dlt_lds + 3 * BQ);            // [2 parity][4 strips][SUB][64 lanes][2][16 B]
+
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int start = p.seq_start ? p.seq_start[s] : 0;
+    const int len = p.seq_len ? p.seq_len[s] : p.T;
+    const int64_t seq_row0 = (int64_t)s * p.T;
+    const int gk = kb * 128 + 32 * strip + (lane & 31);
+    const int kl = gk - start;
+    const bool k_in_T = gk < p.T;
+    const bool k_valid = k_in_T && kl >= 0 && kl < len;
+    bf16_t* outrow = (ROLE ? p.dk : p.dv) + (seq_row0 + gk) * p.ld_qkv + hd * D;
+
+    const int kblk_min = kb * 128 - start;
+    int q_begin = 0;
+    if (CAUSAL) q_begin = max(0, kblk_min) / BQ * BQ;
+    const bool block_has_keys = (kblk_min < len) && (kblk_min + 128 > 0);
+    const Branch br = load_branch(p, s);
+    const int q_stop = (kblk_min >= br.a && kblk_min + 127 < br.b) ? min(len, br.b) : len;
+    const int ntiles = (block_has_keys && q_stop > q_begin) ? (q_stop - q_begin + BQ - 1) / BQ : 0;
+    const bool key_hidden = kl >= br.a && kl < br.b;
+    if (ntiles == 0) {
+        if (k_in_T) store_rows_zero<D>(outrow, lane);
+        return;
+    }
+
+    // this wave's stationary operand: K fragments (V side) or V fragments (K side)
+    const bf16_t* stat = (ROLE ? p.v : p.k) + (seq_row0 + gk) * p.ld_qkv + hd * D;
+    s16x8 sf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) sf[ks] = k_valid ? *reinterpret_cast<const s16x8*>(stat + 16 * ks + 8 * h) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+    const float sc = p.scale * kLog2e;
+    const int wk_min = kblk_min + 32 * strip;
+    const bool wave_has_pad_keys = __any(!k_valid);
+
+    const bf16_t* qp = p.q + hd * D;
+    const bf16_t* dop = p.d_o + hd * D;
+    const int wave = strip + 4 * ROLE;
+    const int64_t qrow0 = seq_row0 + start;
+    const float* lse_g = p.lse + ((int64_t)s * p.H + hd) * p.T + start;
+    const float* dlt_g = p.delta + ((int64_t)s * p.H + hd) * p.T + start;
+    float st_lse = 0.f, st_dlt = 0.f;
+    auto load_stats = [&](int q0) {
+        if (threadIdx.x < BQ) {
+            const int ql = min(q0 + (int)threadIdx.x, len - 1);
+            st_lse = lse_g[ql];
+            st_dlt = dlt_g[ql];
+        }
+    };
+    auto store_stats = [&](int buf) {
+        if (threadIdx.x < BQ) {
+            lse_lds[buf * BQ + threadIdx.x] = st_lse * kLog2e;
+            dlt_lds[buf * BQ + threadIdx.x] = st_dlt;
+        }
+    };
+    __syncthreads();      // the previous key block of this workgroup may still be reading the rings
+    load_stats(q_begin);
+    stage_tile_dma<D, NT / 64>(q_lds, qp, p.ld_qkv, qrow0, q_begin, len, wave, lane);
+    stage_tile_dma<D, NT / 64>(do_lds, dop, p.ld_do, qrow0, q_begin, len, wave, lane);
+    store_stats(0);
+    stage_tile_dma_wait();
+    __syncthreads();
+
+#ifdef HALVA_STAMP
+    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+    int slot = ROLE ? 2 : 0;          // ring slot of step t - ROLE (the K side's first pass, t = 0, is idle)
+    int slot_next = 1;                // ring slot the fetch of step t + 1 goes to
+#pragma unroll 1
+    for (int t = 0; t <= ntiles; ++t) {
+        STAMP(5);
+        if (t + 1 < ntiles) {
+            const int qn = q_begin + (t + 1) * BQ;
+            load_stats(qn);
+            stage_tile_dma<D, NT / 64>(q_lds + slot_next * TILE_BYTES, qp, p.ld_qkv, qrow0, qn, len, wave, lane);
+            stage_tile_dma<D, NT / 64>(do_lds + slot_next * TILE_BYTES, dop, p.ld_do, qrow0, qn, len, wave, lane);
+        }
+        STAMP(0);
+        const int tt = t - ROLE;                           // the step this wave works on
+        if (tt >= 0 && tt < ntiles) {
+            const int qt0 = q_begin + tt * BQ;
+            const char* qt = q_lds + slot * TILE_BYTES;
+            const char* dot = do_lds + slot * TILE_BYTES;
+            const float* lse_t = lse_lds + slot * BQ;
+            const float* dlt_t = dlt_lds + slot * BQ;
+            char* pt = p_lds + (((tt & 1) * 4 + strip) * SUB) * 2048 + lane * 32;
+            const char* rows_tile = ROLE ? dot : qt;       // S = Q K^T  |  dP = dO V^T
+            const char* cols_tile = ROLE ? qt : dot;       // dV^T += dO^T P  |  dK^T += Q^T dZ
+            const bool q_in_b = qt0 >= br.b;               // br.b and qt0 are multiples of 64: uniform over the step
+            const bool hidden = q_in_b && wk_min >= br.a && wk_min + 31 < br.b;
+            bool active[SUB];
+#pragma unroll
+            for (int sub = 0; sub < SUB; ++sub) {          // a sub-tile takes part iff it has rows, reaches the strip's diagonal, is not hidden
+                const int q0 = qt0 + 32 * sub;
+                active[sub] = (q0 < len) && (!CAUSAL || (q0 + 31 >= wk_min)) && !hidden;
+            }
+            f32x16 a[SUB];
+            s16x8 b0[SUB], b1[SUB];
+            auto first = [&](int sub) {
+                if (!active[sub]) return;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a[sub][r] = 0.f;
+                s16x8 fr[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) fr[ks] = frag_rows<D>(rows_tile, 32 * sub, ks, lane);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) a[sub] = mfma32(fr[ks], sf[ks], a[sub]);
+            };
+            auto vec = [&](int sub) {
+                if (!active[sub]) return;
+                const int q0 = qt0 + 32 * sub;
+                f32x16& x = a[sub];
+                if (ROLE == 0) {
+                    if ((q0 + 32 > len) || (CAUSAL && q0 < wk_min + 31) || wave_has_pad_keys ||
+                        (q_in_b && wk_min < br.b && wk_min + 31 >= br.a)) {      // wave-uniform
+                        const bool lane_off = !k_valid || (q_in_b && key_hidden);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ql = q0 + acc_row(r, h);
+                            if (ql >= len || (CAUSAL && kl > ql) || lane_off) x[r] = -INFINITY;      // -> P = 0
+                        }
+                    }
+                    u32x4 w0, w1;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_t + 32 * sub + 8 * g + 4 * h);
+#pragma unroll
+                        for (int j = 0; j < 4; j += 2) {
+                            const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(x[4 * g + j], sc, -l4[j]));
+                            const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(x[4 * g + j + 1], sc, -l4[j + 1]));
+                            const unsigned w = pack_bf16x2(e0, e1);
+                            if (g < 2) w0[2 * g + j / 2] = w;
+                            else w1[2 * (g - 2) + j / 2] = w;
+                        }
+                    }
+                    *reinterpret_cast<u32x4*>(pt + sub * 2048) = w0;
+                    *reinterpret_cast<u32x4*>(pt + sub * 2048 + 16) = w1;
+                    b0[sub] = __builtin_bit_cast(s16x8, w0);
+                    b1[sub] = __builtin_bit_cast(s16x8, w1);
+                } else {
+                    // one step behind: P of this step was written before the last barrier
+                    const u32x4 p0 = *reinterpret_cast<const u32x4*>(pt + sub * 2048);
+                    const u32x4 p1 = *reinterpret_cast<const u32x4*>(pt + sub * 2048 + 16);
+                    u32x4 w0, w1;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 d4 = *reinterpret_cast<const f32x4*>(dlt_t + 32 * sub + 8 * g + 4 * h);
+#pragma unroll
+                        for (int j = 0; j < 4; j += 2) {
+                            const unsigned pw = g < 2 ? p0[2 * g + j / 2] : p1[2 * (g - 2) + j / 2];
+                            const float z0 = bf16_lo(pw) * (x[4 * g + j] - d4[j]);
+                            const float z1 = bf16_hi(pw) * (x[4 * g + j + 1] - d4[j + 1]);
+                            const unsigned w = pack_bf16x2(z0, z1);
+                            if (g < 2) w0[2 * g + j / 2] = w;
+                            else w1[2 * (g - 2) + j / 2] = w;
+                        }
+                    }
+                    b0[sub] = __builtin_bit_cast(s16x8, w0);
+                    b1[sub] = __builtin_bit_cast(s16x8, w1);
+                }
+            };
+            auto second = [&](int sub) {
+                if (!active[sub]) return;
+                s16x8 fc[DT][2];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    fc[dt][0] = frag_cols<D, SLOW_TR>(cols_tile, 32 * sub, 32 * dt, lane);
+                    fc[dt][1] = frag_cols<D, SLOW_TR>(cols_tile, 32 * sub + 16, 32 * dt, lane);
+                }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) acc[dt] = mfma32(fc[dt][0], b0[sub], acc[dt]);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) acc[dt] = mfma32(fc[dt][1], b1[sub], acc[dt]);
+            };
+            // whole, unmasked step (the common case): four straight-line blocks, vector work in the shadow of the other sub-tile's MFMAs
+            //   1: first(0)      2: first(1) || vec(0)      3: second(0) || vec(1)      4: second(1)
+            const bool interior = (qt0 + BQ <= len) && (!CAUSAL || qt0 >= wk_min + 31) && !wave_has_pad_keys &&
+                                  !(q_in_b && wk_min < br.b && wk_min + 31 >= br.a);      // wave-uniform
+            if (DKV2_INTERLEAVE && interior) {
+                constexpr int PPS = 8 / KS, PPD = 8 / (2 * DT);
+                const float* stat_t = ROLE ? dlt_t : lse_t;
+                auto pair = [&](const f32x16& x, int r, const f32x4(&st)[4], const u32x4& p_lo, const u32x4& p_hi) -> unsigned {
+                    const float t0 = st[r >> 2][r & 3], t1 = st[r >> 2][(r & 3) + 1];
+                    if (ROLE == 0)
+                        return pack_bf16x2(__builtin_amdgcn_exp2f(__builtin_fmaf(x[r], sc, -t0)), __builtin_amdgcn_exp2f(__builtin_fmaf(x[r + 1], sc, -t1)));
+                    const unsigned w = r < 8 ? p_lo[r >> 1] : p_hi[(r - 8) >> 1];
+                    return pack_bf16x2(bf16_lo(w) * (x[r] - t0), bf16_hi(w) * (x[r + 1] - t1));
+                };
+                f32x4 st0[4], st1[4];
+                u32x4 p00 = {0u, 0u, 0u, 0u}, p01 = p00, p10 = p00, p11 = p00;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) st0[g] = *reinterpret_cast<const f32x4*>(stat_t + 8 * g + 4 * h);
+                if (ROLE) {
+                    p00 = *reinterpret_cast<const u32x4*>(pt);
+                    p01 = *reinterpret_cast<const u32x4*>(pt + 16);
+                }
+                f32x16 x0, x1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x0[r] = 0.f, x1[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) x0 = mfma32(frag_rows<D>(rows_tile, 0, ks, lane), sf[ks], x0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) st1[g] = *reinterpret_cast<const f32x4*>(stat_t + 32 + 8 * g + 4 * h);
+                if (ROLE) {
+                    p10 = *reinterpret_cast<const u32x4*>(pt + 2048);
+                    p11 = *reinterpret_cast<const u32x4*>(pt + 2048 + 16);
+                }
+                u32x4 w00, w01, w10, w11;
+                FENCE();
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    x1 = mfma32(frag_rows<D>(rows_tile, 32, ks, lane), sf[ks], x1);
+                    FENCE();
+#pragma unroll
+                    for (int q = 0; q < PPS; ++q) {
+                        const int i = ks * PPS + q;
+                        const unsigned w = pair(x0, 2 * i, st0, p00, p01);
+                        if (i < 4) w00[i] = w;
+                        else w01[i - 4] = w;
+                    }
+                    FENCE();
+                }
+                if (!ROLE) {
+                    *reinterpret_cast<u32x4*>(pt) = w00;
+                    *reinterpret_cast<u32x4*>(pt + 16) = w01;
+                }
+#pragma unroll
+                for (int i = 0; i < 2 * DT; ++i) {
+                    const int half = i / DT, dt = i % DT;
+                    acc[dt] = mfma32(frag_cols<D, SLOW_TR>(cols_tile, 16 * half, 32 * dt, lane), __builtin_bit_cast(s16x8, half ? w01 : w00), acc[dt]);
+                    FENCE();
+#pragma unroll
+                    for (int q = 0; q < PPD; ++q) {
+                        const int j = i * PPD + q;
+                        const unsigned w = pair(x1, 2 * j, st1, p10, p11);
+                        if (j < 4) w10[j] = w;
+                        else w11[j - 4] = w;
+                    }
+                    FENCE();
+                }
+                if (!ROLE) {
+                    *reinterpret_cast<u32x4*>(pt + 2048) = w10;
+                    *reinterpret_cast<u32x4*>(pt + 2048 + 16) = w11;
+                }
+#pragma unroll
+                for (int i = 0; i < 2 * DT; ++i) {
+                    const int half = i / DT, dt = i % DT;
+                    acc[dt] = mfma32(frag_cols<D, SLOW_TR>(cols_tile, 32 + 16 * half, 32 * dt, lane), __builtin_bit_cast(s16x8, half ? w11 : w10), acc[dt]);
+                }
+            } else {
+                first(0), vec(0), second(0), first(1), vec(1), second(1);
+            }
+        }
+#ifdef HALVA_STAMP
+        asm volatile("" : "+v"(acc[0][15]), "+v"(acc[DT - 1][15]));
+#endif
+        STAMP(3);
+        if (t + 1 < ntiles) store_stats(slot_next);
+        stage_tile_dma_wait();
+        STAMP(4);
+        slot = (slot == 2) ? 0 : slot + 1;
+        slot_next = (slot_next == 2) ? 0 : slot_next + 1;
+        __syncthreads();
+    }
+#ifdef HALVA_STAMP
+    if (p.dbg && lane == 0 && kb == 0 && s == 0 && hd < 4) {
+        const int wave = strip + 4 * ROLE;
+        for (int i = 0; i < 6; ++i) p.dbg[(hd * 8 + wave) * 8 + i] = stamp_acc[i];
+        p.dbg[(hd * 8 + wave) * 8 + 6] = ntiles;
+    }
+#endif
+    if (k_in_T) store_rows_T<D>(outrow, acc, k_valid ? (ROLE ? p.scale : 1.f) : 0.f, true, lane);
+}
+
+template <int D, bool CAUSAL, bool SLOW_TR, int ROLE>
+__device__ __forceinline__ void sdpa_bwd_dkv2_role(const SdpaParams& p, char* smem, int strip) {
+    int s, hd, b;
+    if (CAUSAL) {      // key block b is visited by (nblk - b) query blocks: pair b with nblk-1-b
+        map_block(blockIdx.x, (p.nblk + 1) / 2, p.H, p.npairs, false, s, hd, b);
+        sdpa_bwd_dkv2_block<D, CAUSAL, SLOW_TR, ROLE>(p, smem, s, hd, b, strip);
+        if (b != p.nblk - 1 - b) sdpa_bwd_dkv2_block<D, CAUSAL, SLOW_TR, ROLE>(p, smem, s, hd, p.nblk - 1 - b, strip);
+    } else {
+        map_block(blockIdx.x, p.nblk, p.H, p.npairs, false, s, hd, b);
+        sdpa_bwd_dkv2_block<D, CAUSAL, SLOW_TR, ROLE>(p, smem, s, hd, b, strip);
+    }
+}
+
+template <int D, bool CAUSAL, bool SLOW_TR>
+__global__ __launch_bounds__(512) void sdpa_bwd_dkv2_kernel(const SdpaParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // the role is a per-wave constant: branch on it once, on the scalar unit, so that each side gets its own register allocation
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave < 4) sdpa_bwd_dkv2_role<D, CAUSAL, SLOW_TR, 0>(p, smem, wave);
+    else sdpa_bwd_dkv2_role<D, CAUSAL, SLOW_TR, 1>(p, smem, wave - 4);
+}
+
 bool slow_tr_requested() {
     const char* e = getenv("HALVA_SDPA_SLOW_TR");
     return e && e[0] == '1';
@@ -1009,6 +1360,12 @@ int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st) {
     const int rc = slow ? launch_one(sdpa_bwd_dq_kernel<D, CAUSAL, true, 8>, p, CAUSAL, 256, 512, lds_dq, S, st, "sdpa_bwd_dq")
                         : launch_one(sdpa_bwd_dq_kernel<D, CAUSAL, false, 8>, p, CAUSAL, 256, 512, lds_dq, S, st, "sdpa_bwd_dq");
     if (rc != HALVA_OK) return rc;
+    // HALVA_DKV2=0 selects the older one-wave-per-SIMD kernel (kept for A/B runs and for the slow-transpose debug path)
+    static const bool two_role = !(getenv("HALVA_DKV2") && atoi(getenv("HALVA_DKV2")) == 0);
+    if (two_role && !slow) {
+        const size_t lds2 = 6 * 64 * D * 2 + 6 * 64 * sizeof(float) + 2 * 4 * 2 * 2048;
+        return launch_one(sdpa_bwd_dkv2_kernel<D, CAUSAL, false>, p, CAUSAL, 128, 512, lds2, S, st, "sdpa_bwd_dkv2");
+    }
     return slow ? launch_one(sdpa_bwd_dkv_kernel<D, CAUSAL, true>, p, CAUSAL, 128, 256, lds_dkv, S, st, "sdpa_bwd_dkv")
                 : launch_one(sdpa_bwd_dkv_kernel<D, CAUSAL, false>, p, CAUSAL, 128, 256, lds_dkv, S, st, "sdpa_bwd_dkv");
 }

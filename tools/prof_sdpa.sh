@@ -1,0 +1,11 @@
+#!/bin/bash
+# per-kernel durations of the SDPA microbench; usage: tools/prof_sdpa.sh <tag> (env passes through, e.g. HALVA_DKV2=1)
+R=$PWD; tag=${1:-run}
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_sdpa_$tag -o p --output-format csv -- python3 $R/tools/bench_sdpa.py > /dev/null 2>&1
+f=$(find $R/gpurun_out/prof_sdpa_$tag -name '*kernel_stats.csv' | head -1)
+python3 - "$f" <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if "sdpa" in r["Name"]: print("%-60s calls %4s avg %8.1f us" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3))
+PY
