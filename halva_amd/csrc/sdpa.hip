@@ -994,13 +994,41 @@ __device__ __forceinline__ void stage_tile_dma(char* tile, const bf16_t* base, i
                      : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
     }
 }
+// The same fill for a run of whole tiles 64 rows apart, with next to no per-lane state: a wave's chunks c = wave + NW i hold the same
+// (row, chunk) pattern shifted by a whole number of rows, so ONE 32-bit lane offset serves all of them and the rest of the address -
+// tile origin + that row shift - is scalar (the saddr form of the instruction).  No 64-bit vector arithmetic in the loop.
+template <int D, int NW>
+struct TileDma {
+    static constexpr int CHUNKS = 64 * D * 2 / 1024, SUBROW = (D / 32) * 512, PER_WAVE = CHUNKS / NW;
+    static_assert((1024 * NW) % SUBROW == 0, "chunks of one wave must differ by whole 8-row bands");
+    static constexpr int ROWS_PER_I = 8 * (1024 * NW / SUBROW);
+    unsigned voff;          // byte offset of this lane's 16 bytes of chunk `wave` from the tile's first row
+    const char* origin;     // the next tile's first row (wave-uniform)
+    __device__ __forceinline__ void init(const bf16_t* base, int64_t ld, int64_t grow_local0, int local0, int wave, int lane) {
+        const int o = 1024 * wave + 16 * lane;
+        const int band = o / SUBROW, rem = o % SUBROW;
+        const int row = 8 * band + ((rem % 512) >> 6);
+        const int ch = 4 * (rem / 512) + (((rem >> 4) & 3) ^ ((row >> 2) & 3));
+        voff = (unsigned)((row * ld + ch * 8) * 2);
+        origin = reinterpret_cast<const char*>(base + (grow_local0 + local0) * ld);
+    }
+    // fetch the tile at `origin` (all 64 rows must exist), then move one tile down
+    __device__ __forceinline__ void issue_and_advance(char* tile, int64_t ld, int wave) {
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(tile + 1024 * (wave + NW * i));
+            const char* rows = origin + (int64_t)i * ROWS_PER_I * ld * 2;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rows) : "memory");
+        }
+        origin += 64 * ld * 2;
+    }
+};
 // the loads above are invisible to the compiler's counters: wait for them by hand before the barrier that publishes the tile
 // (s_waitcnt vmcnt(0) as the builtin, not asm: the compiler then also knows that nothing of its own is pending afterwards)
 __device__ __forceinline__ void stage_tile_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
-#ifndef DKV2_INTERLEAVE
-#define DKV2_INTERLEAVE 0
-#endif
 template <int D, bool CAUSAL, bool SLOW_TR, int ROLE>
 __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* smem, int s, int hd, int kb, int strip) {
     constexpr int BQ = 64, SUB = 2, KS = D / 16, DT = D / 32, NT = 512;
@@ -1050,7 +1078,6 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
 
     const bf16_t* qp = p.q + hd * D;
     const bf16_t* dop = p.d_o + hd * D;
-    const int wave = strip + 4 * ROLE;
     const int64_t qrow0 = seq_row0 + start;
     const float* lse_g = p.lse + ((int64_t)s * p.H + hd) * p.T + start;
     const float* dlt_g = p.delta + ((int64_t)s * p.H + hd) * p.T + start;
@@ -1070,8 +1097,19 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
     };
     __syncthreads();      // the previous key block of this workgroup may still be reading the rings
     load_stats(q_begin);
-    stage_tile_dma<D, NT / 64>(q_lds, qp, p.ld_qkv, qrow0, q_begin, len, wave, lane);
-    stage_tile_dma<D, NT / 64>(do_lds, dop, p.ld_do, qrow0, q_begin, len, wave, lane);
+#ifndef DKV2_DMA_WAVES
+#define DKV2_DMA_WAVES 4
+#endif
+    constexpr int NDMA = DKV2_DMA_WAVES;  // 4: the V-side waves fetch the tiles; 8: every wave takes a share
+    constexpr bool dma_wave = (NDMA == 8) || ROLE == 0;
+    const int dma_id = NDMA == 8 ? strip + 4 * ROLE : strip;
+    TileDma<D, NDMA> qdma, dodma;
+    if (dma_wave) {
+        stage_tile_dma<D, NDMA>(q_lds, qp, p.ld_qkv, qrow0, q_begin, len, dma_id, lane);
+        stage_tile_dma<D, NDMA>(do_lds, dop, p.ld_do, qrow0, q_begin, len, dma_id, lane);
+        qdma.init(qp, p.ld_qkv, qrow0, q_begin + BQ, dma_id, lane);      // stand on tile 1
+        dodma.init(dop, p.ld_do, qrow0, q_begin + BQ, dma_id, lane);
+    }
     store_stats(0);
     stage_tile_dma_wait();
     __syncthreads();
@@ -1088,8 +1126,17 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
         if (t + 1 < ntiles) {
             const int qn = q_begin + (t + 1) * BQ;
             load_stats(qn);
-            stage_tile_dma<D, NT / 64>(q_lds + slot_next * TILE_BYTES, qp, p.ld_qkv, qrow0, qn, len, wave, lane);
-            stage_tile_dma<D, NT / 64>(do_lds + slot_next * TILE_BYTES, dop, p.ld_do, qrow0, qn, len, wave, lane);
+            // The V side requests the whole tile: its waves finish a step's arithmetic some 500 cycles before the K side's, and a request
+            // costs its wave about 100 cycles wherever it is placed (tried: between the MFMAs of the first block - no cheaper).
+            if (dma_wave) {
+                if (qn + BQ <= len) {
+                    qdma.issue_and_advance(q_lds + slot_next * TILE_BYTES, p.ld_qkv, dma_id);
+                    dodma.issue_and_advance(do_lds + slot_next * TILE_BYTES, p.ld_do, dma_id);
+                } else {      // the sequence's last, partial tile
+                    stage_tile_dma<D, NDMA>(q_lds + slot_next * TILE_BYTES, qp, p.ld_qkv, qrow0, qn, len, dma_id, lane);
+                    stage_tile_dma<D, NDMA>(do_lds + slot_next * TILE_BYTES, dop, p.ld_do, qrow0, qn, len, dma_id, lane);
+                }
+            }
         }
         STAMP(0);
         const int tt = t - ROLE;                           // the step this wave works on
@@ -1104,167 +1151,98 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
             const char* cols_tile = ROLE ? qt : dot;       // dV^T += dO^T P  |  dK^T += Q^T dZ
             const bool q_in_b = qt0 >= br.b;               // br.b and qt0 are multiples of 64: uniform over the step
             const bool hidden = q_in_b && wk_min >= br.a && wk_min + 31 < br.b;
-            bool active[SUB];
-#pragma unroll
-            for (int sub = 0; sub < SUB; ++sub) {          // a sub-tile takes part iff it has rows, reaches the strip's diagonal, is not hidden
-                const int q0 = qt0 + 32 * sub;
-                active[sub] = (q0 < len) && (!CAUSAL || (q0 + 31 >= wk_min)) && !hidden;
-            }
-            f32x16 a[SUB];
-            s16x8 b0[SUB], b1[SUB];
-            auto first = [&](int sub) {
-                if (!active[sub]) return;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a[sub][r] = 0.f;
-                s16x8 fr[KS];
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) fr[ks] = frag_rows<D>(rows_tile, 32 * sub, ks, lane);
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) a[sub] = mfma32(fr[ks], sf[ks], a[sub]);
-            };
-            auto vec = [&](int sub) {
-                if (!active[sub]) return;
-                const int q0 = qt0 + 32 * sub;
-                f32x16& x = a[sub];
-                if (ROLE == 0) {
-                    if ((q0 + 32 > len) || (CAUSAL && q0 < wk_min + 31) || wave_has_pad_keys ||
-                        (q_in_b && wk_min < br.b && wk_min + 31 >= br.a)) {      // wave-uniform
-                        const bool lane_off = !k_valid || (q_in_b && key_hidden);
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int ql = q0 + acc_row(r, h);
-                            if (ql >= len || (CAUSAL && kl > ql) || lane_off) x[r] = -INFINITY;      // -> P = 0
-                        }
-                    }
-                    u32x4 w0, w1;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_t + 32 * sub + 8 * g + 4 * h);
-#pragma unroll
-                        for (int j = 0; j < 4; j += 2) {
-                            const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(x[4 * g + j], sc, -l4[j]));
-                            const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(x[4 * g + j + 1], sc, -l4[j + 1]));
-                            const unsigned w = pack_bf16x2(e0, e1);
-                            if (g < 2) w0[2 * g + j / 2] = w;
-                            else w1[2 * (g - 2) + j / 2] = w;
-                        }
-                    }
-                    *reinterpret_cast<u32x4*>(pt + sub * 2048) = w0;
-                    *reinterpret_cast<u32x4*>(pt + sub * 2048 + 16) = w1;
-                    b0[sub] = __builtin_bit_cast(s16x8, w0);
-                    b1[sub] = __builtin_bit_cast(s16x8, w1);
-                } else {
-                    // one step behind: P of this step was written before the last barrier
-                    const u32x4 p0 = *reinterpret_cast<const u32x4*>(pt + sub * 2048);
-                    const u32x4 p1 = *reinterpret_cast<const u32x4*>(pt + sub * 2048 + 16);
-                    u32x4 w0, w1;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 d4 = *reinterpret_cast<const f32x4*>(dlt_t + 32 * sub + 8 * g + 4 * h);
-#pragma unroll
-                        for (int j = 0; j < 4; j += 2) {
-                            const unsigned pw = g < 2 ? p0[2 * g + j / 2] : p1[2 * (g - 2) + j / 2];
-                            const float z0 = bf16_lo(pw) * (x[4 * g + j] - d4[j]);
-                            const float z1 = bf16_hi(pw) * (x[4 * g + j + 1] - d4[j + 1]);
-                            const unsigned w = pack_bf16x2(z0, z1);
-                            if (g < 2) w0[2 * g + j / 2] = w;
-                            else w1[2 * (g - 2) + j / 2] = w;
-                        }
-                    }
-                    b0[sub] = __builtin_bit_cast(s16x8, w0);
-                    b1[sub] = __builtin_bit_cast(s16x8, w1);
-                }
-            };
-            auto second = [&](int sub) {
-                if (!active[sub]) return;
-                s16x8 fc[DT][2];
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    fc[dt][0] = frag_cols<D, SLOW_TR>(cols_tile, 32 * sub, 32 * dt, lane);
-                    fc[dt][1] = frag_cols<D, SLOW_TR>(cols_tile, 32 * sub + 16, 32 * dt, lane);
-                }
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) acc[dt] = mfma32(fc[dt][0], b0[sub], acc[dt]);
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) acc[dt] = mfma32(fc[dt][1], b1[sub], acc[dt]);
-            };
-            // whole, unmasked step (the common case): four straight-line blocks, vector work in the shadow of the other sub-tile's MFMAs
-            //   1: first(0)      2: first(1) || vec(0)      3: second(0) || vec(1)      4: second(1)
+            // Both sub-tiles are always computed; a step that is not whole and unmasked (sequence tail, causal diagonal, pad keys, the
+            // rows of branch B meeting keys of branch A) turns the affected scores into -inf on the V side, which makes P - and with
+            // it dZ on the K side - exactly zero there.  A strip entirely hidden from this step's rows skips the step.
             const bool interior = (qt0 + BQ <= len) && (!CAUSAL || qt0 >= wk_min + 31) && !wave_has_pad_keys &&
                                   !(q_in_b && wk_min < br.b && wk_min + 31 >= br.a);      // wave-uniform
-            if (DKV2_INTERLEAVE && interior) {
-                constexpr int PPS = 8 / KS, PPD = 8 / (2 * DT);
+            if (!hidden) {
+                // Every LDS read is placed by hand one block ahead of its use and nothing may cross a slot boundary: left to itself the
+                // scheduler hoists all reads to the top of the step and the register allocator spills.
+#define SLOT() __builtin_amdgcn_sched_barrier(0)
+                constexpr int PPS = 8 / KS, PPD = 8 / (2 * DT), NS = KS;      // NS slots per block (KS == 2 * DT)
+                static_assert(KS == 2 * DT, "slot count");
                 const float* stat_t = ROLE ? dlt_t : lse_t;
-                auto pair = [&](const f32x16& x, int r, const f32x4(&st)[4], const u32x4& p_lo, const u32x4& p_hi) -> unsigned {
-                    const float t0 = st[r >> 2][r & 3], t1 = st[r >> 2][(r & 3) + 1];
+                auto pair = [&](const f32x16& x, int r, const f32x4& st, unsigned pw) -> unsigned {
+                    const float t0 = st[r & 3], t1 = st[(r & 3) + 1];
                     if (ROLE == 0)
                         return pack_bf16x2(__builtin_amdgcn_exp2f(__builtin_fmaf(x[r], sc, -t0)), __builtin_amdgcn_exp2f(__builtin_fmaf(x[r + 1], sc, -t1)));
-                    const unsigned w = r < 8 ? p_lo[r >> 1] : p_hi[(r - 8) >> 1];
-                    return pack_bf16x2(bf16_lo(w) * (x[r] - t0), bf16_hi(w) * (x[r + 1] - t1));
+                    return pack_bf16x2(bf16_lo(pw) * (x[r] - t0), bf16_hi(pw) * (x[r + 1] - t1));
                 };
-                f32x4 st0[4], st1[4];
-                u32x4 p00 = {0u, 0u, 0u, 0u}, p01 = p00, p10 = p00, p11 = p00;
+                auto mask_scores = [&](f32x16& x, int q0) {
+                    const bool lane_off = !k_valid || (q_in_b && key_hidden);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) st0[g] = *reinterpret_cast<const f32x4*>(stat_t + 8 * g + 4 * h);
-                if (ROLE) {
-                    p00 = *reinterpret_cast<const u32x4*>(pt);
-                    p01 = *reinterpret_cast<const u32x4*>(pt + 16);
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int ql = q0 + acc_row(r, h);
+                        if (ql >= len || (CAUSAL && kl > ql) || lane_off) x[r] = -INFINITY;      // -> P = 0
+                    }
+                };
+                auto col_frag = [&](int sub, int i) { return frag_cols<D, SLOW_TR>(cols_tile, 32 * sub + 16 * (i / DT), 32 * (i % DT), lane); };
+                s16x8 fa[NS], fb[NS], fc[NS], fd[NS];
+                f32x4 st0[4], st1[4];
+                u32x4 p0[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, p1[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+                u32x4 w0[2], w1[2];
                 f32x16 x0, x1;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) x0[r] = 0.f, x1[r] = 0.f;
+                // ---- block 1: first product of sub-tile 0; fetch the second sub-tile's row fragments and sub-tile 0's statistics
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) x0 = mfma32(frag_rows<D>(rows_tile, 0, ks, lane), sf[ks], x0);
+                for (int ks = 0; ks < NS; ++ks) fa[ks] = frag_rows<D>(rows_tile, 0, ks, lane);
+                SLOT();
 #pragma unroll
-                for (int g = 0; g < 4; ++g) st1[g] = *reinterpret_cast<const f32x4*>(stat_t + 32 + 8 * g + 4 * h);
-                if (ROLE) {
-                    p10 = *reinterpret_cast<const u32x4*>(pt + 2048);
-                    p11 = *reinterpret_cast<const u32x4*>(pt + 2048 + 16);
+                for (int ks = 0; ks < NS; ++ks) {
+                    x0 = mfma32(fa[ks], sf[ks], x0);
+                    fb[ks] = frag_rows<D>(rows_tile, 32, ks, lane);
+                    if (ks % (NS / 4) == 0) st0[ks / (NS / 4)] = *reinterpret_cast<const f32x4*>(stat_t + 8 * (ks / (NS / 4)) + 4 * h);
+                    if (ROLE && ks == NS - 2) p0[0] = *reinterpret_cast<const u32x4*>(pt);
+                    if (ROLE && ks == NS - 1) p0[1] = *reinterpret_cast<const u32x4*>(pt + 16);
+                    SLOT();
                 }
-                u32x4 w00, w01, w10, w11;
-                FENCE();
+                if (ROLE == 0 && !interior) mask_scores(x0, qt0);
+                STAMP(1);
+                SLOT();
+                // ---- block 2: first product of sub-tile 1 || vector work of sub-tile 0; fetch sub-tile 0's column fragments
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    x1 = mfma32(frag_rows<D>(rows_tile, 32, ks, lane), sf[ks], x1);
-                    FENCE();
+                for (int ks = 0; ks < NS; ++ks) {
+                    x1 = mfma32(fb[ks], sf[ks], x1);
+                    fc[ks] = col_frag(0, ks);
 #pragma unroll
                     for (int q = 0; q < PPS; ++q) {
-                        const int i = ks * PPS + q;
-                        const unsigned w = pair(x0, 2 * i, st0, p00, p01);
-                        if (i < 4) w00[i] = w;
-                        else w01[i - 4] = w;
+                        const int i = ks * PPS + q;      // pair i: accumulator registers 2i, 2i+1
+                        w0[i >> 2][i & 3] = pair(x0, 2 * i, st0[i >> 1], p0[i >> 2][i & 3]);
                     }
-                    FENCE();
+                    if (ks % (NS / 4) == NS / 4 - 1) st1[ks / (NS / 4)] = *reinterpret_cast<const f32x4*>(stat_t + 32 + 8 * (ks / (NS / 4)) + 4 * h);
+                    if (ROLE && ks == NS / 2 - 1) p1[0] = *reinterpret_cast<const u32x4*>(pt + 2048);
+                    if (ROLE && ks == NS - 1) p1[1] = *reinterpret_cast<const u32x4*>(pt + 2048 + 16);
+                    SLOT();
                 }
                 if (!ROLE) {
-                    *reinterpret_cast<u32x4*>(pt) = w00;
-                    *reinterpret_cast<u32x4*>(pt + 16) = w01;
+                    *reinterpret_cast<u32x4*>(pt) = w0[0];
+                    *reinterpret_cast<u32x4*>(pt + 16) = w0[1];
+                    if (!interior) mask_scores(x1, qt0 + 32);
                 }
+                STAMP(2);
+                SLOT();
+                // ---- block 3: second product of sub-tile 0 || vector work of sub-tile 1; fetch sub-tile 1's column fragments
 #pragma unroll
-                for (int i = 0; i < 2 * DT; ++i) {
-                    const int half = i / DT, dt = i % DT;
-                    acc[dt] = mfma32(frag_cols<D, SLOW_TR>(cols_tile, 16 * half, 32 * dt, lane), __builtin_bit_cast(s16x8, half ? w01 : w00), acc[dt]);
-                    FENCE();
+                for (int i = 0; i < NS; ++i) {
+                    acc[i % DT] = mfma32(fc[i], __builtin_bit_cast(s16x8, w0[i / DT]), acc[i % DT]);
+                    fd[i] = col_frag(1, i);
 #pragma unroll
                     for (int q = 0; q < PPD; ++q) {
                         const int j = i * PPD + q;
-                        const unsigned w = pair(x1, 2 * j, st1, p10, p11);
-                        if (j < 4) w10[j] = w;
-                        else w11[j - 4] = w;
+                        w1[j >> 2][j & 3] = pair(x1, 2 * j, st1[j >> 1], p1[j >> 2][j & 3]);
                     }
-                    FENCE();
+                    SLOT();
                 }
                 if (!ROLE) {
-                    *reinterpret_cast<u32x4*>(pt + 2048) = w10;
-                    *reinterpret_cast<u32x4*>(pt + 2048 + 16) = w11;
+                    *reinterpret_cast<u32x4*>(pt + 2048) = w1[0];
+                    *reinterpret_cast<u32x4*>(pt + 2048 + 16) = w1[1];
                 }
+                // ---- block 4: second product of sub-tile 1
 #pragma unroll
-                for (int i = 0; i < 2 * DT; ++i) {
-                    const int half = i / DT, dt = i % DT;
-                    acc[dt] = mfma32(frag_cols<D, SLOW_TR>(cols_tile, 32 + 16 * half, 32 * dt, lane), __builtin_bit_cast(s16x8, half ? w11 : w10), acc[dt]);
-                }
-            } else {
-                first(0), vec(0), second(0), first(1), vec(1), second(1);
+                for (int i = 0; i < NS; ++i) acc[i % DT] = mfma32(fd[i], __builtin_bit_cast(s16x8, w1[i / DT]), acc[i % DT]);
+#undef SLOT
             }
         }
 #ifdef HALVA_STAMP
@@ -1307,7 +1285,7 @@ __global__ __launch_bounds__(512) void sdpa_bwd_dkv2_kernel(const SdpaParams p) 
     // the role is a per-wave constant: branch on it once, on the scalar unit, so that each side gets its own register allocation
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave < 4) sdpa_bwd_dkv2_role<D, CAUSAL, SLOW_TR, 0>(p, smem, wave);
-    else sdpa_bwd_dkv2_role<D, CAUSAL, SLOW_TR, 1>(p, smem, wave - 4);
+    else sdpa_bwd_dkv2_role<D, CAUSAL, SLOW_TR, 1>(p, smem, wave - 4);      // (raising these waves' s_setprio changes nothing)
 }
 
 bool slow_tr_requested() {

@@ -16,7 +16,7 @@ buf = (ctypes.c_uint64 * 4096)()
 ctypes.CDLL("libamdhip64.so").hipMemcpy(buf, ctypes.c_void_p(lib.halva_dbg_buffer()), 4096 * 8, 2)
 a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8)
 names = ["issue loads", "S,dP mfma", "softmax valu", "dV,dK mfma", "lds store", "barrier"]
-NW = 8 if os.environ.get("HALVA_DKV2", "0") != "0" else 4
+NW = 4 if os.environ.get("HALVA_DKV2", "1") == "0" else 8
 for w in range(NW):
     r = a[w]; nt = int(r[6])
     if nt: print("wave %d tiles(64 rows) %d  " % (w, nt) + "  ".join("%s %.0f" % (n, r[i] / nt) for i, n in enumerate(names)) + "  total/tile %.0f" % (sum(r[:6]) / nt))
