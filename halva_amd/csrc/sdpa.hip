@@ -236,6 +236,75 @@ struct Stage {
     }
 };
 
+// Fill one [64][D] tile image (the tile_off layout) straight from global memory, no register staging: each
+// global_load_lds_dwordx4 writes 1 KiB of LDS at (wave-uniform base + 16 * lane), so lane l of chunk c fetches the 16 bytes
+// whose tile_off is 1024 c + 16 l - the swizzle is applied to the SOURCE address.  Rows outside [0, limit) read the nearest
+// valid row, as Stage::load_clamped.  NW waves share the tile's chunks.
+template <int D, int NW, int ROWS = 64>      // ROWS = 128: two consecutive 64-row images
+__device__ __forceinline__ void stage_tile_dma(char* tile, const bf16_t* base, int64_t ld, int64_t grow_local0, int local0, int limit,
+                                               int wave, int lane) {
+    constexpr int CHUNKS = ROWS * D * 2 / 1024, SUBROW = (D / 32) * 512;
+    static_assert(CHUNKS % NW == 0, "chunks must split evenly over the waves");
+#pragma unroll
+    for (int i = 0; i < CHUNKS / NW; ++i) {
+        const int c = wave + NW * i;
+        const int o = 1024 * c + 16 * lane;
+        const int band = o / SUBROW, rem = o % SUBROW;
+        const int row = 8 * band + ((rem % 512) >> 6);
+        const int ch = 4 * (rem / 512) + (((rem >> 4) & 3) ^ ((row >> 2) & 3));
+        const int loc = min(max(local0 + row, 0), limit - 1);
+        const bf16_t* src = base + (grow_local0 + loc) * ld + ch * 8;
+        // written as asm: the builtin makes hipcc drain vmcnt(0) before the next ds_read_b64_tr_b16, i.e. in the middle of the step
+        const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(tile + 1024 * c);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
+}
+// The same fill for a run of whole tiles 64 rows apart, with next to no per-lane state: a wave's chunks c = wave + NW i hold the same
+// (row, chunk) pattern shifted by a whole number of rows, so ONE 32-bit lane offset serves all of them and the rest of the address -
+// tile origin + that row shift - is scalar (the saddr form of the instruction).  No 64-bit vector arithmetic in the loop.
+template <int D, int NW, int ROWS = 64>
+struct TileDma {
+    static constexpr int CHUNKS = ROWS * D * 2 / 1024, SUBROW = (D / 32) * 512, PER_WAVE = CHUNKS / NW;
+    static_assert((1024 * NW) % SUBROW == 0, "chunks of one wave must differ by whole 8-row bands");
+    static constexpr int ROWS_PER_I = 8 * (1024 * NW / SUBROW);
+    unsigned voff;          // byte offset of this lane's 16 bytes of chunk `wave` from the tile's first row
+    const char* origin;     // the next tile's first row (wave-uniform)
+    __device__ __forceinline__ void init(const bf16_t* base, int64_t ld, int64_t grow_local0, int local0, int wave, int lane) {
+        const int o = 1024 * wave + 16 * lane;
+        const int band = o / SUBROW, rem = o % SUBROW;
+        const int row = 8 * band + ((rem % 512) >> 6);
+        const int ch = 4 * (rem / 512) + (((rem >> 4) & 3) ^ ((row >> 2) & 3));
+        voff = (unsigned)((row * ld + ch * 8) * 2);
+        origin = reinterpret_cast<const char*>(base + (grow_local0 + local0) * ld);
+    }
+    // fetch the tile at `origin` (all ROWS rows must exist), then move one tile down
+    __device__ __forceinline__ void issue_and_advance(char* tile, int64_t ld, int wave) {
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(tile + 1024 * (wave + NW * i));
+            const char* rows = origin + (int64_t)i * ROWS_PER_I * ld * 2;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rows) : "memory");
+        }
+        origin += ROWS * ld * 2;
+    }
+    // the same in pieces: request i of PER_WAVE, then advance() once all are out
+    __device__ __forceinline__ void issue_one(int i, char* tile, int64_t ld, int wave) const {
+        const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(tile + 1024 * (wave + NW * i));
+        const char* rows = origin + (int64_t)i * ROWS_PER_I * ld * 2;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rows) : "memory");
+    }
+    __device__ __forceinline__ void advance(int64_t ld) { origin += ROWS * ld * 2; }
+};
+// the loads above are invisible to the compiler's counters: wait for them by hand before the barrier that publishes the tile
+// (s_waitcnt vmcnt(0) as the builtin, not asm: the compiler then also knows that nothing of its own is pending afterwards)
+__device__ __forceinline__ void stage_tile_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 // Write a [D x 32] transposed accumulator (lane = row of the output, registers = columns d) as bf16 rows:
 // out_row[d] for d = 32*dt + 8*g + 4*h + (0..3) -> 8-byte stores.
 template <int D>
@@ -436,6 +505,9 @@ __device__ __forceinline__ void fwd_tile(const char* kt, const char* vt, const s
     STAMP(4);
 }
 
+#ifndef FWD_DMA
+#define FWD_DMA 1
+#endif
 template <int D, bool CAUSAL, bool SLOW_TR>
 __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, int s, int hd, int qb) {
     constexpr int NW = 8, BN = 64, KS = D / 16, DT = D / 32, BM = 32 * NW, NT = 64 * NW;
@@ -489,7 +561,11 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
 
     const Branch br = load_branch(p, s);
     const bool wave_in_b = wq_min >= br.b;             // wave-uniform (br.b is a multiple of 64, strips are 32 rows)
+    // K/V tiles arrive by LDS-DMA (no staging registers, no ds_write pass); the slow-transpose debug build keeps register staging
+    constexpr bool DMA = !SLOW_TR && FWD_DMA;
+    const int wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // used for the DMA addresses only
     Stage<D, BN, NT> kst, vst;
+    TileDma<D, NW> kdma, vdma;
     const int64_t krow0 = seq_row0 + start;
 #ifdef HALVA_STAMP
     unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_prev;
@@ -507,10 +583,18 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
         const int t0 = seg ? skip_hi : 0, t1 = seg ? ntiles : skip_lo;
         if (t0 >= t1) continue;
         __syncthreads();      // earlier readers of the LDS slots (previous segment / previous row block) are done
-        kst.load_clamped(kp, p.ld_qkv, krow0, t0 * BN, len);
-        vst.load_clamped(vp, p.ld_qkv, krow0, t0 * BN, len);
-        kst.store(k_lds);
-        vst.store(v_lds);
+        if (DMA) {
+            stage_tile_dma<D, NW>(k_lds, kp, p.ld_qkv, krow0, t0 * BN, len, wave_u, lane);
+            stage_tile_dma<D, NW>(v_lds, vp, p.ld_qkv, krow0, t0 * BN, len, wave_u, lane);
+            kdma.init(kp, p.ld_qkv, krow0, (t0 + 1) * BN, wave_u, lane);
+            vdma.init(vp, p.ld_qkv, krow0, (t0 + 1) * BN, wave_u, lane);
+            stage_tile_dma_wait();
+        } else {
+            kst.load_clamped(kp, p.ld_qkv, krow0, t0 * BN, len);
+            vst.load_clamped(vp, p.ld_qkv, krow0, t0 * BN, len);
+            kst.store(k_lds);
+            vst.store(v_lds);
+        }
         __syncthreads();
 #pragma unroll 1
         for (int it = t0; it < t1; ++it) {
@@ -519,8 +603,16 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
             const char* kt = k_lds + slot * TILE_BYTES;
             const char* vt = v_lds + slot * TILE_BYTES;
             if (it + 1 < t1) {
-                kst.load_clamped(kp, p.ld_qkv, krow0, kv0 + BN, len);
-                vst.load_clamped(vp, p.ld_qkv, krow0, kv0 + BN, len);
+                if (!DMA) {
+                    kst.load_clamped(kp, p.ld_qkv, krow0, kv0 + BN, len);
+                    vst.load_clamped(vp, p.ld_qkv, krow0, kv0 + BN, len);
+                } else if (kv0 + 2 * BN <= len) {
+                    kdma.issue_and_advance(k_lds + (slot ^ 1) * TILE_BYTES, p.ld_qkv, wave_u);
+                    vdma.issue_and_advance(v_lds + (slot ^ 1) * TILE_BYTES, p.ld_qkv, wave_u);
+                } else {      // the sequence's last, partial tile
+                    stage_tile_dma<D, NW>(k_lds + (slot ^ 1) * TILE_BYTES, kp, p.ld_qkv, krow0, kv0 + BN, len, wave_u, lane);
+                    stage_tile_dma<D, NW>(v_lds + (slot ^ 1) * TILE_BYTES, vp, p.ld_qkv, krow0, kv0 + BN, len, wave_u, lane);
+                }
             }
             STAMP(0);
             const bool hidden = wave_in_b && kv0 >= br.a && kv0 < br.b;                       // tile wholly inside [a, b)
@@ -531,7 +623,9 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
                 else
                     fwd_tile<D, CAUSAL, false, SLOW_TR>(kt, vt, qf, oacc, m_ref, l_run, sc, kv0, len_t, ql, lane STAMP_PASS);
             }
-            if (it + 1 < t1) {
+            if (DMA) {
+                stage_tile_dma_wait();
+            } else if (it + 1 < t1) {
                 kst.store(k_lds + (slot ^ 1) * TILE_BYTES);
                 vst.store(v_lds + (slot ^ 1) * TILE_BYTES);
             }
@@ -597,75 +691,6 @@ __global__ __launch_bounds__(256) void sdpa_delta_kernel(const SdpaParams p, int
         p.delta[(s * p.H + hd) * p.T + t] = acc;
     }
 }
-
-// Fill one [64][D] tile image (the tile_off layout) straight from global memory, no register staging: each
-// global_load_lds_dwordx4 writes 1 KiB of LDS at (wave-uniform base + 16 * lane), so lane l of chunk c fetches the 16 bytes
-// whose tile_off is 1024 c + 16 l - the swizzle is applied to the SOURCE address.  Rows outside [0, limit) read the nearest
-// valid row, as Stage::load_clamped.  NW waves share the tile's chunks.
-template <int D, int NW, int ROWS = 64>      // ROWS = 128: two consecutive 64-row images
-__device__ __forceinline__ void stage_tile_dma(char* tile, const bf16_t* base, int64_t ld, int64_t grow_local0, int local0, int limit,
-                                               int wave, int lane) {
-    constexpr int CHUNKS = ROWS * D * 2 / 1024, SUBROW = (D / 32) * 512;
-    static_assert(CHUNKS % NW == 0, "chunks must split evenly over the waves");
-#pragma unroll
-    for (int i = 0; i < CHUNKS / NW; ++i) {
-        const int c = wave + NW * i;
-        const int o = 1024 * c + 16 * lane;
-        const int band = o / SUBROW, rem = o % SUBROW;
-        const int row = 8 * band + ((rem % 512) >> 6);
-        const int ch = 4 * (rem / 512) + (((rem >> 4) & 3) ^ ((row >> 2) & 3));
-        const int loc = min(max(local0 + row, 0), limit - 1);
-        const bf16_t* src = base + (grow_local0 + loc) * ld + ch * 8;
-        // written as asm: the builtin makes hipcc drain vmcnt(0) before the next ds_read_b64_tr_b16, i.e. in the middle of the step
-        const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(tile + 1024 * c);
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-    }
-}
-// The same fill for a run of whole tiles 64 rows apart, with next to no per-lane state: a wave's chunks c = wave + NW i hold the same
-// (row, chunk) pattern shifted by a whole number of rows, so ONE 32-bit lane offset serves all of them and the rest of the address -
-// tile origin + that row shift - is scalar (the saddr form of the instruction).  No 64-bit vector arithmetic in the loop.
-template <int D, int NW, int ROWS = 64>
-struct TileDma {
-    static constexpr int CHUNKS = ROWS * D * 2 / 1024, SUBROW = (D / 32) * 512, PER_WAVE = CHUNKS / NW;
-    static_assert((1024 * NW) % SUBROW == 0, "chunks of one wave must differ by whole 8-row bands");
-    static constexpr int ROWS_PER_I = 8 * (1024 * NW / SUBROW);
-    unsigned voff;          // byte offset of this lane's 16 bytes of chunk `wave` from the tile's first row
-    const char* origin;     // the next tile's first row (wave-uniform)
-    __device__ __forceinline__ void init(const bf16_t* base, int64_t ld, int64_t grow_local0, int local0, int wave, int lane) {
-        const int o = 1024 * wave + 16 * lane;
-        const int band = o / SUBROW, rem = o % SUBROW;
-        const int row = 8 * band + ((rem % 512) >> 6);
-        const int ch = 4 * (rem / 512) + (((rem >> 4) & 3) ^ ((row >> 2) & 3));
-        voff = (unsigned)((row * ld + ch * 8) * 2);
-        origin = reinterpret_cast<const char*>(base + (grow_local0 + local0) * ld);
-    }
-    // fetch the tile at `origin` (all ROWS rows must exist), then move one tile down
-    __device__ __forceinline__ void issue_and_advance(char* tile, int64_t ld, int wave) {
-#pragma unroll
-        for (int i = 0; i < PER_WAVE; ++i) {
-            const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(tile + 1024 * (wave + NW * i));
-            const char* rows = origin + (int64_t)i * ROWS_PER_I * ld * 2;
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rows) : "memory");
-        }
-        origin += ROWS * ld * 2;
-    }
-    // the same in pieces: request i of PER_WAVE, then advance() once all are out
-    __device__ __forceinline__ void issue_one(int i, char* tile, int64_t ld, int wave) const {
-        const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(tile + 1024 * (wave + NW * i));
-        const char* rows = origin + (int64_t)i * ROWS_PER_I * ld * 2;
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rows) : "memory");
-    }
-    __device__ __forceinline__ void advance(int64_t ld) { origin += ROWS * ld * 2; }
-};
-// the loads above are invisible to the compiler's counters: wait for them by hand before the barrier that publishes the tile
-// (s_waitcnt vmcnt(0) as the builtin, not asm: the compiler then also knows that nothing of its own is pending afterwards)
-__device__ __forceinline__ void stage_tile_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 // ===================================================================================================
 // backward, part 1: dQ  (same skeleton as the forward)
