@@ -284,6 +284,9 @@ def main():
                            "note": "the correct and the hallucinated row of a pair share ONE pass over their common prefix "
                                    "(image + prompt + identical start of the response: 668 of 2048 rows in this layout); results are "
                                    "those of the reference's two separate rows (HALVA_SHARE_PREFIX=0 runs them separately)"},
+                          "gemm_table": None if not eng.gemm_table else
+                          "library GEMM kernels chosen from a measured table (%s; halva_amd/gemm_tuning.py), HALVA_GEMM_TABLE=0 = library "
+                          "heuristic" % os.path.basename(eng.gemm_table),
                           "valid": not bool(args.layers) and args.model == "7b" and not args.resp_len},
                "loss": round(loss_val, 5),
                # reference-algorithm FLOPs per pair x pairs/s: with prefix sharing fewer are executed

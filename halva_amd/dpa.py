@@ -242,6 +242,8 @@ class DPAEngine:
         # share_prefix: True = when it saves rows, "always" = even when the 64-row alignment padding eats the saving (tests)
         self.share_prefix = (os.environ.get("HALVA_SHARE_PREFIX", "1") != "0") if share_prefix is None else share_prefix
         self.last_packing = None
+        from .gemm_tuning import enable_tuned_gemms
+        self.gemm_table = enable_tuned_gemms()      # measured hipBLASLt / rocBLAS kernel choices for the step's large matmuls
 
     @property
     def spec(self):
