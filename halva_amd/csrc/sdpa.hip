@@ -167,20 +167,7 @@ struct Stage {
     static_assert(ROWS * NCH % NT == 0, "tile must split evenly over the workgroup");
     u32x4 r[PER_THREAD];
 
-    // rows [row_local0, row_local0 + ROWS) of a sequence; rows with local index outside [0, limit) read as zeros
-    __device__ __forceinline__ void load(const bf16_t* base, int64_t ld, int64_t grow0, int local0, int limit) {
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int cid = threadIdx.x + NT * i;
-            const int row = cid / NCH, ch = cid % NCH;
-            const int loc = local0 + row;
-            if (loc >= 0 && loc < limit)
-                r[i] = *reinterpret_cast<const u32x4*>(base + (grow0 + row) * ld + ch * 8);
-            else
-                r[i] = u32x4{0u, 0u, 0u, 0u};
-        }
-    }
-    // branch-free variant: rows outside [0, limit) read the nearest valid row (finite data; callers mask those rows)
+    // rows outside [0, limit) read the nearest valid row (finite data; callers mask those rows): branch-free
     __device__ __forceinline__ void load_clamped(const bf16_t* base, int64_t ld, int64_t grow_local0, int local0, int limit) {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
@@ -188,42 +175,6 @@ struct Stage {
             const int row = cid / NCH, ch = cid % NCH;
             const int loc = min(max(local0 + row, 0), limit - 1);
             r[i] = *reinterpret_cast<const u32x4*>(base + (grow_local0 + loc) * ld + ch * 8);
-        }
-    }
-    // the same three operations for a sub-group of the workgroup whose threads are numbered tid = 0..NT-1
-    __device__ __forceinline__ void load_clamped_t(int tid, const bf16_t* base, int64_t ld, int64_t grow_local0, int local0, int limit) {
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int cid = tid + NT * i;
-            const int row = cid / NCH, ch = cid % NCH;
-            const int loc = min(max(local0 + row, 0), limit - 1);
-            r[i] = *reinterpret_cast<const u32x4*>(base + (grow_local0 + loc) * ld + ch * 8);
-        }
-    }
-    __device__ __forceinline__ void store_t(int tid, char* tile) const {
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int cid = tid + NT * i;
-            const int row = cid / NCH, ch = cid % NCH;
-            *reinterpret_cast<u32x4*>(tile + tile_off<D>(row, ch)) = r[i];
-        }
-    }
-    // pointer-bumping variant for full tiles: ptr[i] addresses this thread's chunk i of the NEXT tile to fetch
-    __device__ __forceinline__ void init_ptrs(const bf16_t* (&ptr)[PER_THREAD], const bf16_t* base, int64_t ld, int64_t grow_local0,
-                                              int local0, int tid = -1) const {
-        if (tid < 0) tid = threadIdx.x;
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int cid = tid + NT * i;
-            const int row = cid / NCH, ch = cid % NCH;
-            ptr[i] = base + (grow_local0 + local0 + row) * ld + ch * 8;
-        }
-    }
-    __device__ __forceinline__ void load_bump(const bf16_t* (&ptr)[PER_THREAD], int64_t stride_elems) {
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            r[i] = *reinterpret_cast<const u32x4*>(ptr[i]);
-            ptr[i] += stride_elems;
         }
     }
     __device__ __forceinline__ void store(char* tile) const {
@@ -291,15 +242,6 @@ struct TileDma {
         }
         origin += ROWS * ld * 2;
     }
-    // the same in pieces: request i of PER_WAVE, then advance() once all are out
-    __device__ __forceinline__ void issue_one(int i, char* tile, int64_t ld, int wave) const {
-        const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(tile + 1024 * (wave + NW * i));
-        const char* rows = origin + (int64_t)i * ROWS_PER_I * ld * 2;
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rows) : "memory");
-    }
-    __device__ __forceinline__ void advance(int64_t ld) { origin += ROWS * ld * 2; }
 };
 // the loads above are invisible to the compiler's counters: wait for them by hand before the barrier that publishes the tile
 // (s_waitcnt vmcnt(0) as the builtin, not asm: the compiler then also knows that nothing of its own is pending afterwards)
@@ -1086,7 +1028,7 @@ __global__ __launch_bounds__(256, 1) void sdpa_bwd_dkv_kernel(const SdpaParams p
 // ---------------------------------------------------------------------------------------------------
 template <int D, bool CAUSAL, bool SLOW_TR, int ROLE>
 __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* smem, int s, int hd, int kb, int strip) {
-    constexpr int BQ = 64, SUB = 2, KS = D / 16, DT = D / 32, NT = 512;
+    constexpr int BQ = 64, SUB = 2, KS = D / 16, DT = D / 32;
     constexpr int TILE_BYTES = BQ * D * 2;
     char* q_lds = smem;                                    // [3][BQ][D]
     char* do_lds = smem + 3 * TILE_BYTES;                  // [3][BQ][D]
@@ -1152,12 +1094,11 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
     };
     __syncthreads();      // the previous key block of this workgroup may still be reading the rings
     load_stats(q_begin);
-#ifndef DKV2_DMA_WAVES
-#define DKV2_DMA_WAVES 4
-#endif
-    constexpr int NDMA = DKV2_DMA_WAVES;  // 4: the V-side waves fetch the tiles; 8: every wave takes a share
-    constexpr bool dma_wave = (NDMA == 8) || ROLE == 0;
-    const int dma_id = NDMA == 8 ? strip + 4 * ROLE : strip;
+    // The four V-side waves fetch the tiles: they finish a step's arithmetic ahead of their K-side partners (measured against
+    // all eight waves taking a share: -0.5 %).
+    constexpr int NDMA = 4;
+    constexpr bool dma_wave = ROLE == 0;
+    const int dma_id = strip;
     TileDma<D, NDMA> qdma, dodma;
     if (dma_wave) {
         stage_tile_dma<D, NDMA>(q_lds, qp, p.ld_qkv, qrow0, q_begin, len, dma_id, lane);
