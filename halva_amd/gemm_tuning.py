@@ -1,7 +1,8 @@
 """Library-GEMM solution tables.  The step's large matmuls are plain hipBLASLt / rocBLAS calls issued by PyTorch-ROCm; which of a
 library's several hundred kernels serves a given (layout, m, n, k, ld) is the library's heuristic unless PyTorch's TunableOp has a
-measured answer.  A table measured on MI355X for the shapes of the headline workload (BASELINE.json configs[1]: LLaVA-1.5-7B,
-T=2048, 16 pairs/GPU, prefix sharing on) is shipped under halva_amd/tuned/ and loaded when the engine is built: +4 % step throughput,
+measured answer.  A table measured on MI355X for the shapes of the bench workloads (the headline one - BASELINE.json configs[1]:
+LLaVA-1.5-7B, T=2048, 16 pairs/GPU, prefix sharing on - and the 13B / VILA-13B extras) is shipped under halva_amd/tuned/ and loaded
+when the engine is built: +3.5 % step throughput on the headline workload,
 results within the bf16 noise of the default kernels (same arithmetic, different tiling).  Shapes not in the table - other models,
 other batch layouts - keep the library default; nothing is tuned at run time unless HALVA_GEMM_TUNE=1 asks for it.
 
@@ -15,7 +16,7 @@ import os
 
 import torch
 
-SHIPPED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gfx950_llava7b_T2048_tunableop.csv")
+SHIPPED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gfx950_tunableop.csv")
 _state = {"loaded": None}
 
 
