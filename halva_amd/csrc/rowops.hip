@@ -7,6 +7,15 @@ namespace {
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kMaxChunks = 16;   // 16 chunks x 64 lanes x 8 elements = rows up to d = 8192 stay in registers
+// The row buffers are sized by a template parameter (10 chunks for d <= 5120, else 16): with the 16-chunk buffers the backward
+// needs 178 registers = 2 waves per SIMD, too few rows in flight to cover the HBM latency of its load -> reduce -> store chain
+// (10 chunks: 122 registers, 4 waves; an 8-chunk instantiation makes hipcc cache the unpacked floats - 256 registers - so d = 4096
+// runs the 10-chunk one with two predicated-off iterations).
+#define RMSNORM_DISPATCH(d, CALL)          \
+    do {                                   \
+        if ((d) <= 5120) { CALL(10); }     \
+        else { CALL(16); }                 \
+    } while (0)
 
 __device__ __forceinline__ void unpack8(const u32x4& v, float (&f)[8]) {
 #pragma unroll
@@ -27,6 +36,7 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
 // x * rstd to the input dtype before multiplying by w; on the fp32 CPU path that parity is measured against that is a no-op,
 // and emulating the bf16 double rounding moved the fixture loss by 1.2e-3 - more than every other bf16 effect together.)
 // ---------------------------------------------------------------------------------------------------
+template <int MAXC>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ w,
                                                           u32x4* __restrict__ y, float* __restrict__ rstd, int64_t rows,
                                                           int nchunk, int64_t ldy_chunks, float eps, float inv_d) {
@@ -34,10 +44,10 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const u32x4* __restric
     const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row >= rows) return;
     const u32x4* xr = x + row * nchunk;
-    u32x4 buf[kMaxChunks];
+    u32x4 buf[MAXC];
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxChunks; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
             buf[i] = xr[c];
@@ -52,7 +62,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const u32x4* __restric
     if (lane == 0) rstd[row] = r;
     u32x4* yr = y + row * ldy_chunks;
 #pragma unroll
-    for (int i = 0; i < kMaxChunks; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
             float f[8], g[8];
@@ -66,6 +76,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const u32x4* __restric
 }
 
 // dx = r * (g - n * mean(g * n)),  g = dy * w,  n = x * r
+template <int MAXC>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ x,
                                                           const u32x4* __restrict__ w, const float* __restrict__ rstd,
                                                           u32x4* __restrict__ dx, int64_t rows, int nchunk, int64_t lddy_chunks,
@@ -76,10 +87,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const u32x4* __restric
     const u32x4* xr = x + row * nchunk;
     const u32x4* dyr = dy + row * lddy_chunks;
     const float r = rstd[row];
-    u32x4 bx[kMaxChunks], bg[kMaxChunks];   // bg holds g = dy * w packed back as two-halves? keep dy, recompute g
+    u32x4 bx[MAXC], bg[MAXC];   // bg holds g = dy * w packed back as two-halves? keep dy, recompute g
     float dot = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxChunks; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
             bx[i] = xr[c];
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const u32x4* __restric
     dot = wave_sum(dot) * inv_d;
     u32x4* dxr = dx + row * nchunk;
 #pragma unroll
-    for (int i = 0; i < kMaxChunks; ++i) {
+    for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
             float fx[8], fd[8], fw[8];
@@ -216,8 +227,11 @@ extern "C" int halva_rmsnorm_fwd_ld(const void* x, const void* w, void* y, int64
                     8 * 64 * kMaxChunks);
     if (rows <= 0) return HALVA_OK;
     const int blocks = (int)((rows + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, (const u32x4*)w,
-                       (u32x4*)y, rstd, rows, d / 8, ldy / 8, eps, 1.f / d);
+#define FWD(C)                                                                                                           \
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel<C>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, (const u32x4*)w, \
+                       (u32x4*)y, rstd, rows, d / 8, ldy / 8, eps, 1.f / d)
+    RMSNORM_DISPATCH(d, FWD);
+#undef FWD
     HALVA_CHECK_LAUNCH("rmsnorm_fwd");
     return HALVA_OK;
 }
@@ -235,8 +249,11 @@ extern "C" int halva_rmsnorm_bwd_ld(const void* dy, int64_t lddy, const void* x,
                     8 * 64 * kMaxChunks);
     if (rows <= 0) return HALVA_OK;
     const int blocks = (int)((rows + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)dy, (const u32x4*)x,
-                       (const u32x4*)w, rstd, (u32x4*)dx, rows, d / 8, lddy / 8, 1.f / d);
+#define BWD(C)                                                                                                             \
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<C>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)dy, (const u32x4*)x, \
+                       (const u32x4*)w, rstd, (u32x4*)dx, rows, d / 8, lddy / 8, 1.f / d)
+    RMSNORM_DISPATCH(d, BWD);
+#undef BWD
     HALVA_CHECK_LAUNCH("rmsnorm_bwd");
     return HALVA_OK;
 }
