@@ -76,11 +76,11 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const u32x4* __restric
 }
 
 // dx = r * (g - n * mean(g * n)),  g = dy * w,  n = x * r
-template <int MAXC>
+template <int MAXC, bool HAS_RES>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ x,
                                                           const u32x4* __restrict__ w, const float* __restrict__ rstd,
-                                                          u32x4* __restrict__ dx, int64_t rows, int nchunk, int64_t lddy_chunks,
-                                                          float inv_d) {
+                                                          const u32x4* dres, u32x4* dx, int64_t rows, int nchunk,
+                                                          int64_t lddy_chunks, float inv_d) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -115,6 +115,12 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const u32x4* __restric
             unpack8(w[c], fw);
 #pragma unroll
             for (int j = 0; j < 8; ++j) fx[j] = r * (fd[j] * fw[j] - fx[j] * r * dot);
+            if (HAS_RES) {      // + the gradient arriving through the residual connection (bf16 sum of two bf16 gradients, as autograd's)
+                float fr[8];
+                unpack8(dres[row * nchunk + c], fr);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fx[j] = bf16_round(fx[j]) + fr[j];
+            }
             dxr[c] = pack8(fx);
         }
     }
@@ -243,15 +249,24 @@ extern "C" int halva_rmsnorm_bwd(const void* dy, const void* x, const void* w, c
 
 extern "C" int halva_rmsnorm_bwd_ld(const void* dy, int64_t lddy, const void* x, const void* w, const float* rstd, void* dx,
                                     int64_t rows, int d, void* stream) {
+    return halva_rmsnorm_bwd_res_ld(dy, lddy, x, w, rstd, nullptr, dx, rows, d, stream);
+}
+
+extern "C" int halva_rmsnorm_bwd_res_ld(const void* dy, int64_t lddy, const void* x, const void* w, const float* rstd,
+                                        const void* dres, void* dx, int64_t rows, int d, void* stream) {
     HALVA_CHECK_ARG(dy && x && w && rstd && dx, "rmsnorm_bwd: null pointer");
     HALVA_CHECK_ARG(lddy >= d && lddy % 8 == 0, "rmsnorm_bwd: dy row stride %lld must be >= d and a multiple of 8", (long long)lddy);
     HALVA_CHECK_ARG(d > 0 && d % 8 == 0 && d <= 8 * 64 * kMaxChunks, "rmsnorm_bwd: d=%d must be a multiple of 8 and <= %d", d,
                     8 * 64 * kMaxChunks);
     if (rows <= 0) return HALVA_OK;
     const int blocks = (int)((rows + kWavesPerBlock - 1) / kWavesPerBlock);
-#define BWD(C)                                                                                                             \
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel<C>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)dy, (const u32x4*)x, \
-                       (const u32x4*)w, rstd, (u32x4*)dx, rows, d / 8, lddy / 8, 1.f / d)
+#define BWD(C)                                                                                                                 \
+    if (dres)                                                                                                                  \
+        hipLaunchKernelGGL((rmsnorm_bwd_kernel<C, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)dy,   \
+                           (const u32x4*)x, (const u32x4*)w, rstd, (const u32x4*)dres, (u32x4*)dx, rows, d / 8, lddy / 8, 1.f / d); \
+    else                                                                                                                       \
+        hipLaunchKernelGGL((rmsnorm_bwd_kernel<C, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)dy,  \
+                           (const u32x4*)x, (const u32x4*)w, rstd, (const u32x4*)nullptr, (u32x4*)dx, rows, d / 8, lddy / 8, 1.f / d)
     RMSNORM_DISPATCH(d, BWD);
 #undef BWD
     HALVA_CHECK_LAUNCH("rmsnorm_bwd");

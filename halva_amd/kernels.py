@@ -56,6 +56,44 @@ def rmsnorm(x, w, eps, out_width=None):
     return _RMSNorm.apply(x, w, eps, out_width)
 
 
+class _RMSNormFork(torch.autograd.Function):
+    """The residual fork of a decoder layer as ONE node: returns (rmsnorm(x), x).  The second output is what the residual
+    connection must consume (modelling_llama.py:395-417); its gradient then arrives here together with the norm's and the
+    backward kernel adds it while writing dx - instead of autograd's separate accumulation pass over the hidden state."""
+
+    @staticmethod
+    def forward(ctx, x, w, eps, out_width):
+        _chk(x, torch.bfloat16, "x"), _chk(w, torch.bfloat16, "w")
+        d = x.shape[-1]
+        rows = x.numel() // d
+        width = out_width or d
+        y = torch.empty(*x.shape[:-1], width, dtype=x.dtype, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        call("halva_rmsnorm_fwd_ld", ptr(x), ptr(w), ptr(y), width, ptr(rstd), rows, d, float(eps), stream_ptr())
+        ctx.save_for_backward(x, w, rstd)
+        ctx.width = width
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x, w, rstd = ctx.saved_tensors
+        d = x.shape[-1]
+        if dy is None:                                  # only the residual path carried a gradient
+            return dres, None, None, None
+        dy = _chk(dy.contiguous(), torch.bfloat16, "dy")
+        if dres is not None:
+            dres = _chk(dres.contiguous(), torch.bfloat16, "dres")
+        dx = torch.empty_like(x)
+        call("halva_rmsnorm_bwd_res_ld", ptr(dy), ctx.width, ptr(x), ptr(w), ptr(rstd), ptr(dres), ptr(dx), x.numel() // d, d,
+             stream_ptr())
+        return dx, None, None, None
+
+
+def rmsnorm_fork(x, w, eps, out_width=None):
+    """(rmsnorm(x), x) with the two gradients summed inside the backward kernel; use the second output for the residual add."""
+    return _RMSNormFork.apply(x, w, eps, out_width)
+
+
 # ------------------------------------------------------------------------------------------------
 def rope_tables(head_dim, max_pos, base=10000.0, device="cuda", linear_factor=1.0):
     """cos/sin tables [max_pos, D/2] in bf16 (modelling_llama.py:79-106: computed in fp32, cast to the compute dtype).

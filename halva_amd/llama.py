@@ -169,6 +169,12 @@ class RMSNormW(nn.Module):
     def forward(self, x, out_width=None):
         return K.rmsnorm(x, self.weight, self.variance_epsilon, out_width)
 
+    def fork(self, x, out_width=None):
+        """(norm(x), x) for a pre-norm residual block: hand the second result to the residual add (kernels._RMSNormFork)."""
+        if not (torch.is_grad_enabled() and x.requires_grad) or os.environ.get("HALVA_NORM_FORK", "1") == "0":
+            return K.rmsnorm(x, self.weight, self.variance_epsilon, out_width), x
+        return K.rmsnorm_fork(x, self.weight, self.variance_epsilon, out_width)
+
 
 class LoraGroup(nn.Module):
     """A fused frozen weight [sum(out_g), in] plus the LoRA factors of its G targets.
@@ -300,11 +306,12 @@ class DecoderLayer(nn.Module):
 
     def forward(self, x, info, use_lora=True):
         # every producer kernel writes straight into the (wider) operand buffer of the projection that follows it
-        h = self.input_layernorm(x, self.qkv.in_width)
+        # (norm(x), x) come out of one autograd node so that the residual's gradient is added inside the norm's backward kernel
+        h, x = self.input_layernorm.fork(x, self.qkv.in_width)
         qkv = self.qkv(h, None, use_lora)
         a = K.attention(qkv, info.cos, info.sin, info.seq_start, info.seq_len, self.H, self.D, self.o.in_width, info.branch)
         x = self.o(a, x, use_lora)
-        h = self.post_attention_layernorm(x, self.gate_up.in_width)
+        h, x = self.post_attention_layernorm.fork(x, self.gate_up.in_width)
         act = K.swiglu(self.gate_up(h, None, use_lora), self.down.in_width)
         return self.down(act, x, use_lora)
 

@@ -48,6 +48,11 @@ int halva_rmsnorm_fwd_ld(const void* x, const void* w, void* y, int64_t ldy, flo
                          void* stream);
 int halva_rmsnorm_bwd_ld(const void* dy, int64_t lddy, const void* x, const void* w, const float* rstd, void* dx, int64_t rows,
                          int d, void* stream);
+/* the decoder layer's residual fork in one pass: dx = rmsnorm_bwd(dy) + dres, where dres [rows, d] is the gradient that reaches
+ * the same hidden state through the residual connection (modelling_llama.py:395-417: `hidden_states = residual + ...`).  Saves
+ * the separate read-read-write pass of autograd's accumulation.  dres == NULL: plain halva_rmsnorm_bwd_ld.  dx may alias dres. */
+int halva_rmsnorm_bwd_res_ld(const void* dy, int64_t lddy, const void* x, const void* w, const float* rstd, const void* dres,
+                             void* dx, int64_t rows, int d, void* stream);
 
 /* ---- RoPE, in place on the q and k thirds of a packed qkv buffer [rows, 3, H, D] (bf16).
  * replaces apply_rotary_pos_emb (modelling_llama.py:154-169) as called from

@@ -71,6 +71,31 @@ def test_rmsnorm(rows, d):
     assert rel_err(xg.grad, xr.grad) < 6e-3          # bf16 output rounding of dx (2^-9 relative per element)
 
 
+@pytest.mark.parametrize("rows,d,width", [(37, 4096, 4480), (9, 5120, 5120)])
+def test_rmsnorm_fork_sums_the_residual_gradient_in_the_kernel(rows, d, width):
+    """(norm(x), x) as one autograd node: forward equals rmsnorm, backward is BIT-identical to autograd's accumulation of the norm's
+    dx (a bf16 tensor) and the residual gradient - the decoder layer's use (DecoderLayer.forward)."""
+    g = torch.Generator().manual_seed(3)
+    x = bf(torch.randn(rows, d, generator=g) * 2).to(DEV)
+    w = bf(1 + 0.1 * torch.randn(d, generator=g)).to(DEV)
+    dy = bf(torch.randn(rows, width, generator=g)).to(DEV)
+    dres = bf(torch.randn(rows, d, generator=g)).to(DEV)
+    xa = x.clone().requires_grad_(True)
+    y, xr = K().rmsnorm_fork(xa, w, 1e-5, width)
+    (y * dy).sum().backward(retain_graph=True)
+    only_norm = xa.grad.clone()
+    xa.grad = None
+    ((y * dy).sum() + (xr * dres).sum()).backward()
+    xb = x.clone().requires_grad_(True)
+    yb = K().rmsnorm(xb, w, 1e-5, width)
+    assert torch.equal(y[:, :d], yb[:, :d]) and torch.equal(xr, x)
+    ((yb * dy).sum() + (xb * dres).sum()).backward()          # autograd: bf16(dx_norm) + dres, rounded to bf16
+    assert torch.equal(xa.grad, xb.grad)
+    xc = x.clone().requires_grad_(True)
+    (K().rmsnorm(xc, w, 1e-5, width) * dy).sum().backward()
+    assert torch.equal(only_norm, xc.grad)                     # no residual gradient: the plain kernel
+
+
 def test_rope_forward_and_inverse():
     S, T, H, D = 2, 37, 3, 128
     g = torch.Generator().manual_seed(1)
