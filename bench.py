@@ -110,7 +110,7 @@ def sdpa_roofline(dev, S=8, T=2048, H=32, D=128, iters=10):
             j = json.load(f)
         if j.get("shape") == {"S": S, "T": T, "H": H, "D": D}:
             traffic = j.get("sdpa_causal_bwd_hbm_bytes_per_launch")
-    return {"bound": "mfma", "kernel": "sdpa_causal_bwd (delta + dQ + dK/dV launches, D=128)", "achieved": round(bwd_flop / tb / 1e12, 2),
+    return {"bound": "mfma", "kernel": "sdpa_causal_bwd (dQ + dK/dV launches, D=128)", "achieved": round(bwd_flop / tb / 1e12, 2),
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(bwd_flop / tb / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "traffic_source": "profiles/r01_sdpa_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bytes = (2*FETCH+WRITE)*1024)",
             "launch_ms": round(tb * 1e3, 3), "shape": {"S": S, "T": T, "H": H, "D": D},

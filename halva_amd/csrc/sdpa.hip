@@ -6,15 +6,16 @@
 //
 // Structure (all three kernels): a workgroup is 4 waves (256 threads); each wave owns a 32-row strip of the
 // "stationary" operand in registers (Q rows in fwd/dQ, K/V rows in dK/dV) and the workgroup streams 64-row
-// (fwd, dQ) or 32-row (dK/dV) tiles of the other operand through LDS, double buffered, register staged
-// (global loads for tile i+1 are issued before the MFMAs of tile i and written to LDS after them).
+// tiles of the other operand through LDS (double buffered; a 3-slot ring in dK/dV), fetched by LDS-DMA: the requests for
+// tile i+1 are issued before the MFMAs of tile i and waited for at the barrier that ends it.
 //
 //   fwd    S^T = K Q^T (key on the accumulator rows, query on the lane) so the softmax row statistics are
 //          lane-local: 32 in-register max/add + one cross-half shuffle; P^T is cast to bf16 in registers and is
 //          already the B operand of O^T += V^T P^T; V^T comes from the row-major LDS tile via ds_read_b64_tr_b16.
-//   dQ     same skeleton: S^T, dP^T = V dO^T, dZ^T = P^T (dP^T - delta), dQ^T += K^T dZ^T (K^T by tr reads).
+//   dQ     same skeleton: S^T, dP^T = V dO^T, dZ^T = P^T (dP^T - delta), dQ^T += K^T dZ^T (K^T by tr reads); forms delta.
 //   dK/dV  S = Q K^T and dP = dO V^T with the KEY on the lane (K/V fragments stay in registers); P and dZ
-//          accumulators are directly the B operands of dV^T += dO^T P and dK^T += Q^T dZ (Q^T/dO^T by tr reads).
+//          accumulators are directly the B operands of dV^T += dO^T P and dK^T += Q^T dZ (Q^T/dO^T by tr reads).  The two
+//          waves of a SIMD split a key strip between them (sdpa_bwd_dkv2_*).
 // LDS tiles use one XOR swizzle that is conflict-free for both ds_read_b128 row reads and transposed reads.
 // No atomics: dQ has its own kernel, so results are bitwise reproducible.
 #include "common.h"
@@ -607,35 +608,7 @@ __global__ __launch_bounds__(512) void sdpa_fwd_kernel(const SdpaParams p) {
 }
 
 // ===================================================================================================
-// backward, part 0: delta[s, h, t] = sum_d dO * O
-// ===================================================================================================
-template <int D>
-__global__ __launch_bounds__(256) void sdpa_delta_kernel(const SdpaParams p, int64_t total) {
-    // one 16-lane group per (token, head): D/8 chunks of 8 elements
-    constexpr int LPR = D / 8;   // lanes per row (16 for D=128, 8 for D=64)
-    const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
-    const int c = threadIdx.x % LPR;
-    float acc = 0.f;
-    int64_t tok = 0;
-    int hd = 0;
-    if (gid < total) {
-        tok = gid / p.H;
-        hd = (int)(gid % p.H);
-        const u32x4 a = *reinterpret_cast<const u32x4*>(p.o_in + tok * p.ld_o + hd * D + c * 8);
-        const u32x4 b = *reinterpret_cast<const u32x4*>(p.d_o + tok * p.ld_do + hd * D + c * 8);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc += bf16_lo(a[i]) * bf16_lo(b[i]) + bf16_hi(a[i]) * bf16_hi(b[i]);
-    }
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (gid < total && c == 0) {
-        const int64_t s = tok / p.T, t = tok % p.T;
-        p.delta[(s * p.H + hd) * p.T + t] = acc;
-    }
-}
-
-// ===================================================================================================
-// backward, part 1: dQ  (same skeleton as the forward)
+// backward, part 1: dQ  (same skeleton as the forward), and delta[s, h, t] = sum_d dO * O for both backward kernels
 // ===================================================================================================
 template <int D, bool CAUSAL, bool SLOW_TR, int NW>
 __device__ __forceinline__ void sdpa_bwd_dq_block(const SdpaParams& p, char* smem, int s, int hd, int qb) {
@@ -680,7 +653,21 @@ __device__ __forceinline__ void sdpa_bwd_dq_block(const SdpaParams& p, char* sme
     }
     const int64_t stat = ((int64_t)s * p.H + hd) * p.T + gq;
     const float lse2 = q_valid ? p.lse[stat] * kLog2e : INFINITY;      // padded query rows: P = exp2(-inf) = 0
-    const float dlt = q_valid ? p.delta[stat] : 0.f;
+    // delta = rowsum(O o dO): this lane holds half of its row of dO already; the other half sits on lane ^ 32.  Written out for the
+    // dK/dV kernel, which runs after this one (this used to be a launch of its own: 52 us of the backward's 1.2 ms).
+    float dsum = 0.f;
+    if (q_valid) {
+        const bf16_t* orow = p.o_in + (seq_row0 + gq) * p.ld_o + hd * D;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const u32x4 ov = *reinterpret_cast<const u32x4*>(orow + 16 * ks + 8 * h);
+            const u32x4 dv = __builtin_bit_cast(u32x4, dof[ks]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dsum += bf16_lo(ov[i]) * bf16_lo(dv[i]) + bf16_hi(ov[i]) * bf16_hi(dv[i]);
+        }
+    }
+    const float dlt = xhalf_sum(dsum);
+    if (q_valid && h == 0) p.delta[stat] = dlt;
     const float sc = p.scale * kLog2e;
 
     f32x16 dqacc[DT];
@@ -1322,12 +1309,6 @@ int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st) {
 #ifdef HALVA_STAMP
     p.dbg = halva_dbg_buffer();
 #endif
-    {
-        const int64_t total = (int64_t)S * p.T * p.H;
-        const int64_t threads = total * (D / 8);
-        hipLaunchKernelGGL((sdpa_delta_kernel<D>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, total);
-        HALVA_CHECK_LAUNCH("sdpa_delta");
-    }
     const size_t lds_dq = 4 * 64 * D * 2;
     const size_t lds_dkv = 4 * DKV_BQ * D * 2 + 4 * DKV_BQ * sizeof(float);
     const bool slow = slow_tr_requested();
