@@ -12,7 +12,7 @@ cd $R
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && rocprofv3 --kernel-trace --pmc $c -d $OUT/traffic/$c -o t --output-format csv -- python3 $R/tools/bench_sdpa.py > /dev/null 2>&1)
 done
-python3 tools/summarize_pmc.py $OUT/traffic sdpa_fwd sdpa_delta sdpa_bwd_dq sdpa_bwd_dkv > $OUT/traffic.json
+python3 tools/summarize_pmc.py $OUT/traffic sdpa_fwd sdpa_bwd_dq sdpa_bwd_dkv > $OUT/traffic.json
 bash tools/pmc_sdpa.sh $tag > /dev/null 2>&1; mkdir -p $OUT/sq; cp gpurun_out/pmc_sdpa_$tag/summary.json $OUT/sq/summary.json
 python3 bench.py > $OUT/bench_stdout.log 2>&1
 rm -rf $OUT/stats $OUT/traffic gpurun_out/pmc_sdpa_$tag
