@@ -254,9 +254,11 @@ def main():
             torch.cuda.synchronize()
         small = ("aten::add", "aten::add_", "aten::copy_", "aten::clone", "aten::fill_", "aten::zero_", "aten::mul", "aten::cat",
                  "aten::index", "aten::sigmoid", "aten::contiguous", "aten::_to_copy")
+        if os.environ["HALVA_BENCH_TORCH_PROFILE"] == "mm":
+            small = ("aten::mm", "aten::addmm", "aten::addmm_")
         rows = [e for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=5) if e.key in small]
         rows.sort(key=lambda e: -e.self_device_time_total)
-        for e in rows[:40]:
+        for e in rows[:60]:
             print("%-14s %8.2f ms %5d calls  shapes %s\n      %s" % (e.key, e.self_device_time_total / 1e3, e.count, str(e.input_shapes)[:110],
                                                                    " <- ".join(str(f).split("/")[-1] for f in e.stack[:5])), file=sys.stderr)
     dp.barrier(ctx)

@@ -82,6 +82,7 @@ struct GemmParams {
     int64_t lda, ldb, ldc;
     int M, N, K;
     int epilogue, out_f32, accumulate;
+    int ksplit;     // > 0: blockIdx.z owns k in [z * ksplit, min(K, (z + 1) * ksplit)) and writes its f32 partial to C + z * M * ldc
 };
 
 template <bool TA, bool TB>
@@ -104,9 +105,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 
     Operand<TA> sa;
     Operand<TB> sb;
-    const int nk = (p.K + 63) / 64;
-    sa.load(p.A, p.lda, m0, p.M, 0, p.K);
-    sb.load(p.B, p.ldb, n0, p.N, 0, p.K);
+    GemmParams q = p;      // this block's view of the problem (a k-slab of it when the launch is split over k)
+    if (p.ksplit > 0) {
+        const int64_t kb = (int64_t)blockIdx.z * p.ksplit;
+        q.K = (int)min((int64_t)p.ksplit, p.K - kb);
+        q.A = p.A + (TA ? kb * p.lda : kb);
+        q.B = p.B + (TB ? kb * p.ldb : kb);
+        q.C = (float*)p.C + (int64_t)blockIdx.z * p.M * p.ldc;
+    }
+    const int nk = (q.K + 63) / 64;
+    sa.load(q.A, q.lda, m0, q.M, 0, q.K);
+    sb.load(q.B, q.ldb, n0, q.N, 0, q.K);
     sa.store(a_lds);
     sb.store(b_lds);
     __syncthreads();
@@ -114,8 +123,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         const char* at = a_lds + (it & 1) * TILE;
         const char* bt = b_lds + (it & 1) * TILE;
         if (it + 1 < nk) {
-            sa.load(p.A, p.lda, m0, p.M, (it + 1) * 64, p.K);
-            sb.load(p.B, p.ldb, n0, p.N, (it + 1) * 64, p.K);
+            sa.load(q.A, q.lda, m0, q.M, (it + 1) * 64, q.K);
+            sb.load(q.B, q.ldb, n0, q.N, (it + 1) * 64, q.K);
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
                 }
                 if (p.epilogue == 1) v = gelu_erf(p.out_f32 ? v : bf16_round(v));
                 if (p.out_f32) {
-                    float* c = (float*)p.C + idx;
+                    float* c = (float*)q.C + idx;
                     *c = p.accumulate ? *c + v : v;
                 } else {
                     bf16_t* c = (bf16_t*)p.C + idx;
@@ -206,9 +215,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
     atomicAdd(out + n, s);
 }
 
+// C[i] += alpha * sum_z ws[z][i]  (fixed order: the split-k weight gradients stay bitwise reproducible)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t mn, int splits,
+                                                            float alpha) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= mn) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(ws + z * mn + i);
+    f32x4* c = reinterpret_cast<f32x4*>(C + i);
+    *c = *c + s * alpha;
+}
+
 template <bool TA, bool TB>
 int launch_gemm(const GemmParams& p, hipStream_t st) {
-    const dim3 grid((p.N + 127) / 128, (p.M + 127) / 128), block(256);
+    const dim3 grid((p.N + 127) / 128, (p.M + 127) / 128, p.ksplit > 0 ? (p.K + p.ksplit - 1) / p.ksplit : 1), block(256);
     const size_t lds = 4 * 128 * 64 * 2;
     (void)hipFuncSetAttribute((const void*)gemm_kernel<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((gemm_kernel<TA, TB>), grid, block, lds, st, p);
@@ -245,6 +265,42 @@ extern "C" int halva_gemm_bf16(const void* A, const void* B, const void* bias, v
     if (!trans_a && !trans_b) return launch_gemm<false, false>(p, (hipStream_t)stream);
     if (!trans_a && trans_b) return launch_gemm<false, true>(p, (hipStream_t)stream);
     return launch_gemm<true, true>(p, (hipStream_t)stream);
+}
+
+extern "C" int halva_wgrad_accumulate(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int M, int N, int64_t rows,
+                                      float alpha, float* ws, int64_t ws_floats, void* stream) {
+    HALVA_CHECK_ARG(A && B && C && ws, "wgrad_accumulate: null pointer");
+    HALVA_CHECK_ARG(M > 0 && N > 0 && rows > 0 && rows < (1ll << 31), "wgrad_accumulate: bad sizes %d %d %lld", M, N, (long long)rows);
+    HALVA_CHECK_ARG(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N,
+                    "wgrad_accumulate: M, lda, ldb must be multiples of 8 and the strides cover the columns");
+    HALVA_CHECK_ARG((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)ws) & 15) == 0, "wgrad_accumulate: 16-byte aligned pointers");
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    const int64_t mn = (int64_t)M * N;
+    HALVA_CHECK_ARG(ws_floats >= mn, "wgrad_accumulate: workspace of %lld floats, need at least M * N = %lld", (long long)ws_floats,
+                    (long long)mn);
+    // as many k-slabs as keep the whole grid resident at once (2 workgroups per CU x 256 CUs): a second, partial round of
+    // workgroups costs more than the extra parallelism brings (measured at 256..1536 workgroups, tools/bench_wgrad.py)
+    int splits = (int)max((int64_t)1, min((int64_t)min(64, 512 / tiles), ws_floats / mn));
+    const int ksplit = (int)(((rows + splits - 1) / splits + 63) / 64 * 64);
+    splits = (int)((rows + ksplit - 1) / ksplit);
+    GemmParams p{};
+    p.A = (const bf16_t*)A;
+    p.B = (const bf16_t*)B;
+    p.C = ws;
+    p.lda = lda;
+    p.ldb = ldb;
+    p.ldc = N;
+    p.M = M;
+    p.N = N;
+    p.K = (int)rows;
+    p.out_f32 = 1;
+    p.ksplit = ksplit;
+    const int rc = launch_gemm<true, true>(p, (hipStream_t)stream);
+    if (rc != HALVA_OK) return rc;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, C, mn, splits,
+                       alpha);
+    HALVA_CHECK_LAUNCH("splitk_reduce");
+    return HALVA_OK;
 }
 
 extern "C" int halva_vit_patch_embed(const void* images, const void* weight_kp, const void* bias, void* col_ws, void* out, int n,

@@ -34,6 +34,7 @@ SIGNATURES = {
     "halva_sdpa_causal_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "halva_sdpa_full_fwd": [_P, _P, _I, _I, _I, _I, _F, _P],
     "halva_gemm_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "halva_wgrad_accumulate": [_P, _L, _P, _L, _P, _I, _I, _L, _F, _P, _L, _P],
     "halva_clip_patch_embed": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "halva_vit_patch_embed": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "halva_layernorm_fwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],

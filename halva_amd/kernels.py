@@ -89,6 +89,29 @@ class _RMSNormFork(torch.autograd.Function):
         return dx, None, None, None
 
 
+_wgrad_ws = {}
+
+
+def wgrad_accumulate(C, A, B, alpha=1.0):
+    """C [M, N] f32 += alpha * A^T B for bf16 column windows A [rows, M], B [rows, N] of wider row-major buffers (LoRA weight
+    gradients, include/halva_hip.h:halva_wgrad_accumulate).  Split over the rows; partials are summed in a fixed order."""
+    rows, M = A.shape
+    N = B.shape[1]
+    assert B.shape[0] == rows and C.shape == (M, N) and C.dtype == torch.float32 and C.is_contiguous()
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.stride(1) == 1 and B.stride(1) == 1
+    ws = _wgrad_ws.get(C.device)
+    if ws is None:
+        ws = _wgrad_ws[C.device] = torch.empty(48 * 2 ** 20, dtype=torch.float32, device=C.device)      # 192 MB: 30+ slabs at these sizes
+    call("halva_wgrad_accumulate", ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), M, N, rows, float(alpha), ptr(ws), ws.numel(),
+         stream_ptr())
+
+
+def wgrad_supported(A, B):
+    """Shapes / alignment halva_wgrad_accumulate takes (16-byte row chunks); anything else stays on the library GEMM."""
+    return (A.shape[1] % 8 == 0 and B.shape[1] % 8 == 0 and A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0 and A.stride(1) == 1
+            and B.stride(1) == 1 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0 and A.shape[1] * B.shape[1] <= 16 * 2 ** 20)
+
+
 def rmsnorm_fork(x, w, eps, out_width=None):
     """(rmsnorm(x), x) with the two gradients summed inside the backward kernel; use the second output for the residual add."""
     return _RMSNormFork.apply(x, w, eps, out_width)

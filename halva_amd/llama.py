@@ -66,6 +66,8 @@ def _jsonable(v):
 # Keep a transposed copy of every fused frozen weight for the backward (dx = dy W as an NT GEMM).  Costs the frozen weights'
 # memory once more (13.5 GB at 7B, 26 GB at 13B - of 288 GB); HALVA_DGRAD_WT=0 turns it off.
 DGRAD_TRANSPOSED_COPY = os.environ.get("HALVA_DGRAD_WT", "1") != "0"
+WGRAD_KERNEL = os.environ.get("HALVA_WGRAD_KERNEL", "1") != "0"      # LoRA weight gradients through halva_wgrad_accumulate
+K_ = K      # the kernels module under a name that _LoraGroupFn's local `K` (in_features) does not shadow
 
 LORA_TARGETS = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
 
@@ -123,17 +125,30 @@ class _LoraGroupFn(torch.autograd.Function):
             # NT form (both operands K-major), measured 12 % faster than NN at these shapes on MI355X.
             dxa = torch.mm(dy2, WcT.t()) if WcT is not None else torch.mm(dy2, Wc)
             da = dxa[:, K:K + A.shape[0]]
-            gA = torch.mm(da.t(), xa2[:, :K])
+            # Weight gradients of the factors: one side of each product is only r..G r wide and the contraction runs over every token
+            # row, a shape the library serves with 32-86 tiles.  With an f32 sink they go through the split-k kernel
+            # (halva_wgrad_accumulate: 76 vs 136 us for a [4096 x 128] factor at 27 k rows), straight into main_grad.
+            fused = (sink and WGRAD_KERNEL and A.main_grad.is_contiguous() and all(B.main_grad.is_contiguous() for B in Bs)
+                     and K_.wgrad_supported(da, xa2[:, :K]) and K_.wgrad_supported(dy2[:, :Bs[0].shape[0]], xa2[:, K:K + r]))
+            if fused:
+                K_.wgrad_accumulate(A.main_grad, da, xa2[:, :K], 1.0)
+            else:
+                gA = torch.mm(da.t(), xa2[:, :K])
             off = 0
             for g, B in enumerate(Bs):
                 n = B.shape[0]
-                gB = torch.mm(dy2[:, off:off + n].t(), xa2[:, K + g * r:K + (g + 1) * r])
-                if sink:
-                    B.main_grad.add_(gB, alpha=scale)
+                if fused:
+                    K_.wgrad_accumulate(B.main_grad, dy2[:, off:off + n], xa2[:, K + g * r:K + (g + 1) * r], scale)
                 else:
-                    dBs[g] = gB * scale
+                    gB = torch.mm(dy2[:, off:off + n].t(), xa2[:, K + g * r:K + (g + 1) * r])
+                    if sink:
+                        B.main_grad.add_(gB, alpha=scale)
+                    else:
+                        dBs[g] = gB * scale
                 off += n
-            if sink:
+            if fused:
+                pass
+            elif sink:
                 A.main_grad.add_(gA)
             else:
                 dA = gA

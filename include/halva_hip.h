@@ -113,6 +113,16 @@ int halva_sdpa_full_fwd(const void* qkv, void* out, int N, int S, int H, int D, 
  * epilogue (needed by the GELU backward); accumulate != 0 adds into C (gradient accumulation, f32 or bf16). */
 int halva_gemm_bf16(const void* A, const void* B, const void* bias, void* C, void* pre_act, int M, int N, int K,
                     int trans_a, int trans_b, int epilogue, halva_dtype out_dtype, int accumulate, void* stream);
+
+/* ---- LoRA weight gradients: C[M, N] (f32) += alpha * A^T B with A [rows, M] and B [rows, N] bf16 column windows of wider row-major
+ * buffers (row strides lda / ldb), i.e. what peft's lora_A / lora_B receive from autograd on the DPA path
+ * (llava/train/train_halva.py:1085-1101 makes them the only trainable decoder tensors): dB_g = scale * dy_g^T (x A_g^T),
+ * dA = (scale * dy B)^T x.  One side of the product is 128..384 wide, the contraction runs over all token rows, so the library
+ * GEMM has 32-86 tiles for 256 CUs; here the rows are split into k-slabs (partials in ws, summed in a fixed order - no atomics).
+ * ws: scratch of ws_floats >= M * N floats; the number of slabs is what fits, up to one resident
+ * round of workgroups (512). */
+int halva_wgrad_accumulate(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int M, int N, int64_t rows, float alpha,
+                           float* ws, int64_t ws_floats, void* stream);
 /* images [n, 3, hw, hw] bf16; weight_kp [d, Kp] bf16 = the conv weight flattened to [d, 3*p*p] and zero padded to
  * Kp (multiple of 8); col_ws: caller scratch [n * (hw/p)^2, Kp] bf16 -> out [n, (hw/p)^2, d] bf16 */
 int halva_clip_patch_embed(const void* images, const void* weight_kp, void* col_ws, void* out, int n, int hw, int p, int d,

@@ -445,3 +445,23 @@ def test_splice_rows_against_golden():
         ref, _, _, _ = host.splice(z[p + "ids"], z[p + "mask"], z[p + "labels"], z[p + "signs"], feats.float().numpy(),
                                    emb.float().numpy(), m["max_len"], m["padding_side"])
         assert torch.equal(out.float(), torch.from_numpy(ref))          # pure row copies: bit exact
+
+
+@pytest.mark.parametrize("rows,M,N,lda,ldb", [(1000, 128, 256, 640, 384), (3428, 512, 128, 1536, 4224), (77, 8, 8, 8, 8),
+                                                (27424, 384, 4096, 4480, 4480)])
+def test_wgrad_accumulate_matches_fp32_reference(rows, M, N, lda, ldb):
+    """C += alpha * A^T B over column windows of wider buffers (the LoRA weight gradients), accumulated into an f32 sink; two runs agree bitwise."""
+    g = torch.Generator().manual_seed(5)
+    abuf = bf(torch.randn(rows, lda, generator=g)).to(DEV)
+    bbuf = bf(torch.randn(rows, ldb, generator=g)).to(DEV)
+    a0, b0 = (lda - M) // 16 * 8, (ldb - N) // 16 * 8                 # 16-byte aligned windows inside the buffers
+    A, B = abuf[:, a0:a0 + M], bbuf[:, b0:b0 + N]
+    C0 = torch.randn(M, N, generator=g).to(DEV)
+    ref = C0.double() + 0.5 * (A.double().t() @ B.double())
+    out = []
+    for _ in range(2):
+        C = C0.clone()
+        K().wgrad_accumulate(C, A, B, 0.5)
+        out.append(C)
+    assert torch.equal(out[0], out[1])
+    assert float((out[0].double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())) * max(1, rows // 2000)
