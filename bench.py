@@ -118,6 +118,53 @@ def sdpa_roofline(dev, S=8, T=2048, H=32, D=128, iters=10):
                     "launch_ms": round(tf * 1e3, 3)}}
 
 
+def visible_pairs(T, br_a=None, br_b=None, seq_len=None):
+    """(query, key) pairs a causal sequence scores: n(n+1)/2, or for a packed [prefix | A | pad | B] row the A-side triangle over
+    prefix + A plus, for every B row, the prefix and its own causal part (B never looks at A: halva_sdpa_branch_fwd)."""
+    if br_a is None:
+        return T * (T + 1) // 2
+    la, lb = min(seq_len, br_b) - br_a, max(0, seq_len - br_b)
+    n1 = br_a + la
+    return n1 * (n1 + 1) // 2 + lb * br_a + lb * (lb + 1) // 2
+
+
+def in_step_roofline(probe, layout, micro):
+    """The SDPA-backward launches of the TIMED steps themselves (events recorded by kernels._SdpaCausal.backward on the launch
+    stream): algorithmic FLOPs = 2.5 x 4 D x visible pairs x H per sequence, over the summed launch time.  `micro` (the same
+    kernels at the plain 8 x 2048 layer shape, timed after the steps) stays in the record for comparison with profiles/."""
+    flop = ms = 0.0
+    kinds = {}
+    for e0, e1, S, T, H, D, branched in probe:
+        if branched and layout is not None and layout[0] == T and len(layout[1]) == S:
+            pairs = sum(visible_pairs(T, a, b, n) for a, b, n in zip(*layout[1:]))
+        else:
+            pairs = S * visible_pairs(T)
+        t = e0.elapsed_time(e1)
+        flop += 2.5 * 4.0 * D * pairs * H
+        ms += t
+        k = kinds.setdefault("%dx%d%s" % (S, T, " packed" if branched else ""), [0, 0.0])
+        k[0] += 1
+        k[1] += t
+    out = dict(micro)
+    step_traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_sdpa_pmc.json")
+    if os.path.exists(pmc):
+        with open(pmc) as f:
+            step_traffic = json.load(f).get("in_step", {}).get("sdpa_causal_bwd_hbm_bytes_per_launch")
+    out.update({"traffic": step_traffic,
+                "traffic_source": "profiles/r01_sdpa_pmc.json:in_step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --steps 1`, "
+                                  "average over the step's sdpa_bwd_dq + sdpa_bwd_dkv2 dispatches, bytes = (2*FETCH+WRITE)*1024)",
+                "achieved": round(flop / ms / 1e9, 2), "frac": round(flop / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
+                "launch_ms": round(ms / len(probe), 3), "launches": len(probe),
+                "measured": "HIP events around every sdpa_causal_bwd launch of the timed steps (launch stream); FLOPs of the layouts "
+                            "actually run: " + ", ".join("%s: %d launches avg %.3f ms" % (k, v[0], v[1] / v[0]) for k, v in kinds.items()),
+                "microbench": {"shape": micro["shape"], "achieved": micro["achieved"], "frac": micro["frac"], "launch_ms": micro["launch_ms"],
+                               "traffic": micro["traffic"],
+                               "note": "same kernels at the plain per-layer shape the traffic counters were collected on"}})
+    out.pop("shape", None)
+    return out
+
+
 def cpu_baseline(budget_s=25.0):
     """The oracle (CPU restatement of the reference's path, oracle/) timed on this box's host cores: ONE sequence of the
     7B geometry at T = 2048 through a bounded number of decoder layers (fwd + bwd, LoRA r = 128, bf16) and the
@@ -261,6 +308,8 @@ def main():
         for e in rows[:60]:
             print("%-14s %8.2f ms %5d calls  shapes %s\n      %s" % (e.key, e.self_device_time_total / 1e3, e.count, str(e.input_shapes)[:110],
                                                                    " <- ".join(str(f).split("/")[-1] for f in e.stack[:5])), file=sys.stderr)
+    from halva_amd import kernels as HK
+    HK.sdpa_bwd_probe = [] if not args.no_roofline else None      # HIP events around every SDPA-backward launch of the timed steps
     dp.barrier(ctx)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -269,6 +318,7 @@ def main():
     torch.cuda.synchronize()
     dp.barrier(ctx)
     dt = time.perf_counter() - t0
+    probe, HK.sdpa_bwd_probe = HK.sdpa_bwd_probe, None
     if ctx.world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -277,6 +327,8 @@ def main():
     pairs_per_s = ctx.world * B * args.steps / dt
 
     roof = None if args.no_roofline else sdpa_roofline(dev)
+    if roof is not None and probe:
+        roof = in_step_roofline(probe, eng.last_layout, roof)
     cpu = None
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()

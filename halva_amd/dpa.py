@@ -242,6 +242,7 @@ class DPAEngine:
         # share_prefix: True = when it saves rows, "always" = even when the 64-row alignment padding eats the saving (tests)
         self.share_prefix = (os.environ.get("HALVA_SHARE_PREFIX", "1") != "0") if share_prefix is None else share_prefix
         self.last_packing = None
+        self.last_layout = None
         from .gemm_tuning import enable_tuned_gemms
         self.gemm_table = enable_tuned_gemms()      # measured hipBLASLt / rocBLAS kernel choices for the step's large matmuls
 
@@ -289,6 +290,7 @@ class DPAEngine:
             h = pol.hidden_states(embeds, None, torch.zeros(g, dtype=torch.int32), packed.seq_len, branch=branch)
             hid, dense, target = _kept_rows(gp.labels, packed.row_of)
             self.last_packing = (packed.rows_packed, packed.rows_unpacked)
+            self.last_layout = (packed.T, packed.br_a.tolist(), packed.br_b.tolist(), packed.seq_len.tolist())      # host ints (bench accounting)
         else:
             h = self._hidden(pol, gp, feats)
             hid, dense, target = _kept_rows(gp.labels)

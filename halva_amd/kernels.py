@@ -150,6 +150,9 @@ class _RopeQK(torch.autograd.Function):
         return dqkv, None, None, None, None, None
 
 
+sdpa_bwd_probe = None      # a list: every causal-SDPA backward launch appends (start event, end event, S, T, H, D, branched)
+
+
 class _SdpaCausal(torch.autograd.Function):
     """flash_attn_varlen_qkvpacked_func(causal=True) + unpad/pad_input (llama_flash_attn_monkey_patch.py:71-91).
     qkv: [S, T, 3*H*D] bf16 (already rotated).  Returns [S, T, H*D].  If cos/sin are given the backward also applies
@@ -185,8 +188,15 @@ class _SdpaCausal(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         delta = torch.empty(S, H, T, dtype=torch.float32, device=qkv.device)
         br_a, br_b, pos = ctx.branch if ctx.branch is not None else (None, None, None)
+        probe = sdpa_bwd_probe
+        if probe is not None:          # bench.py: HIP events around the launch, on the stream it goes to
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         call("halva_sdpa_branch_bwd", ptr(qkv), ptr(out), width, ptr(dout), dout.shape[-1], ptr(lse), ptr(dqkv), ptr(delta),
              ptr(seq_start), ptr(seq_len), ptr(br_a), ptr(br_b), S, T, H, D, 0.0, stream_ptr())
+        if probe is not None:
+            e1.record()
+            probe.append((e0, e1, S, T, H, D, ctx.branch is not None))
         cos, sin = ctx.rope
         if cos is not None:
             _rope_inplace(dqkv, cos, sin, T, H, D, True, pos)

@@ -183,3 +183,17 @@ def test_bench_synthetic_batch_follows_baseline_layout():
     pk = SP.pack_pairs(plan)
     assert pk.br_a.tolist() == [628 + 40] * 2 and pk.br_b.tolist() == [2048] * 2       # shared: prefix + the first 40 response tokens
     assert pk.rows_packed == 2 * (2048 + 2048 - 668) and pk.rows_unpacked == 4 * 2048
+
+
+def test_bench_visible_pairs_counts_what_the_branch_mask_lets_through():
+    """bench.py's FLOP accounting for packed [prefix | A | pad | B] rows against a brute-force count of the attention mask
+    (rows >= br_b do not see [br_a, br_b); include/halva_hip.h)."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for T, a, b, n in [(200, 37, 128, 200), (192, 60, 128, 150), (128, 5, 64, 64), (100, 0, 64, 100)]:
+        brute = sum(1 for q in range(n) for k in range(q + 1) if not (q >= b and a <= k < b) and (k < min(n, b) or k >= b))
+        # keys in [min(n, b), b) are padding of the A part: never valid
+        assert bench.visible_pairs(T, a, b, n) == brute, (T, a, b, n)
+    assert bench.visible_pairs(2048) == 2048 * 2049 // 2
