@@ -128,7 +128,8 @@ class _LoraGroupFn(torch.autograd.Function):
             # Weight gradients of the factors: one side of each product is only r..G r wide and the contraction runs over every token
             # row, a shape the library serves with 32-86 tiles.  With an f32 sink they go through the split-k kernel
             # (halva_wgrad_accumulate: 76 vs 136 us for a [4096 x 128] factor at 27 k rows), straight into main_grad.
-            fused = (sink and WGRAD_KERNEL and A.main_grad.is_contiguous() and all(B.main_grad.is_contiguous() for B in Bs)
+            fused = (sink and WGRAD_KERNEL and all(t.main_grad.is_contiguous() and t.main_grad.data_ptr() % 16 == 0 and
+                                                   t.main_grad.dtype == torch.float32 for t in (A, *Bs))
                      and K_.wgrad_supported(da, xa2[:, :K]) and K_.wgrad_supported(dy2[:, :Bs[0].shape[0]], xa2[:, K:K + r]))
             if fused:
                 K_.wgrad_accumulate(A.main_grad, da, xa2[:, :K], 1.0)
