@@ -197,3 +197,41 @@ def test_bench_visible_pairs_counts_what_the_branch_mask_lets_through():
         # keys in [min(n, b), b) are padding of the A part: never valid
         assert bench.visible_pairs(T, a, b, n) == brute, (T, a, b, n)
     assert bench.visible_pairs(2048) == 2048 * 2049 // 2
+
+
+def test_tile_dma_source_swizzle_inverts_the_lds_tile_layout():
+    """csrc/sdpa.hip: an LDS-DMA request writes 1 KiB at (wave-uniform base + 16 * lane), so lane l of chunk c must FETCH the 16 bytes
+    whose tile_off is 1024 c + 16 l (stage_tile_dma / TileDma::init).  Integer mirror of both formulas: the source map is the exact
+    inverse of tile_off, a bijection onto the tile, and a wave's chunks differ by whole rows (what lets one lane offset serve them)."""
+    for D in (128, 64):
+        subrow = (D // 32) * 512
+
+        def tile_off(row, ch):
+            return subrow * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3))
+
+        def source_of(c, lane):
+            o = 1024 * c + 16 * lane
+            band, rem = o // subrow, o % subrow
+            row = 8 * band + ((rem % 512) >> 6)
+            ch = 4 * (rem // 512) + (((rem >> 4) & 3) ^ ((row >> 2) & 3))
+            return row, ch
+
+        for rows in (64, 128):
+            chunks = rows * D * 2 // 1024
+            seen = set()
+            for c in range(chunks):
+                for lane in range(64):
+                    row, ch = source_of(c, lane)
+                    assert 0 <= row < rows and 0 <= ch < D // 8
+                    assert tile_off(row, ch) == 1024 * c + 16 * lane
+                    seen.add((row, ch))
+            assert len(seen) == rows * D // 8
+            for nw in (4, 8):                       # waves sharing a tile: chunk (wave + nw i) = chunk `wave` shifted by i * rows_per_i rows
+                if (1024 * nw) % subrow:
+                    continue
+                rows_per_i = 8 * (1024 * nw // subrow)
+                for wave in range(nw):
+                    for i in range(chunks // nw):
+                        for lane in (0, 17, 63):
+                            r0, c0 = source_of(wave, lane)
+                            assert source_of(wave + nw * i, lane) == (r0 + i * rows_per_i, c0)
