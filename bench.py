@@ -6,8 +6,10 @@ pair (pos, neg, policy-on-ref with grad, frozen reference without), the phrase-l
 all-reduce and AdamW on the LoRA/projector parameters - LLaVA-1.5-7B geometry, 336 px images, T = 2048 post-splice,
 LoRA r=128, bf16, synthetic data and random-init weights (no datasets/checkpoints offline).
 
-N = 1: configs[1] (bs = 16 pairs on one MI355X).  N > 1: the same 16 pairs PER GPU (weak scaling), one process per GPU
-(launched by torch.distributed.run), one RCCL all-reduce of the flat trainable-gradient buffer per step.
+N = 1: configs[1] (bs = 16 pairs on one MI355X).  N > 1: the same 16 pairs PER GPU (weak scaling), one process per GPU -
+either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or, for a plain
+`python bench.py --gpus N`, started by this file itself as N fresh child processes BEFORE the parent touches the GPU -
+and one bucketed RCCL all-reduce of the flat trainable-gradient buffer per step, issued from inside the last backward.
 Prints ONE JSON line on rank 0 with `roofline` (dominant hand-written kernel: the fused causal SDPA backward, timed live
 with HIP events on the launch stream) and `cpu_baseline` (the oracle's CPU restatement timed on the host cores, rank 0,
 N = 1 only, bounded sample).
@@ -211,10 +213,50 @@ def cpu_baseline(budget_s=25.0):
     t_head = time.time() - t0
     L = cfg["num_hidden_layers"]
     pair_s = 3 * (L * t_fb) + 1 * (L * t_fwd) + 4 * t_head
-    return {"value": round(1.0 / pair_s, 6), "unit": "paired-samples/sec", "cores": cores, "kind": "port",
+    return {"value": round(1.0 / pair_s, 6), "unit": "paired-samples/sec", "cores": cores,
+            "kind": "port (extrapolated: one decoder layer + one lm_head/loss call timed, scaled to a pair)",
             "sample": "oracle (torch-CPU bf16 restatement): 1 decoder layer of the 7B geometry at T=2048 timed fwd (%.2fs) and "
                       "fwd+bwd (%.2fs), lm_head+logp+KL on 1419 rows (%.2fs); pair = 3x32 fwd+bwd + 1x32 fwd layers + 4 heads "
                       "(CLIP tower omitted, <1%%) => %.0f s/pair" % (t_fwd, t_fb, t_head, pair_s)}
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this file (one per GPU) and wait for them.
+    Runs before this process has made any GPU call (torch.cuda.device_count() does not initialise the runtime); nothing is
+    exec'ed over a process that has.  HALVA_BENCH_SHARE_GPU=1 (diagnostic, for a 1-GPU box): the ranks share the visible
+    devices round-robin and exchange gradients over gloo instead of RCCL."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    share = os.environ.get("HALVA_BENCH_SHARE_GPU") == "1"
+    if ndev < n and not share:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (n, ndev))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % max(ndev, 1) if share else r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if share:
+            env["HALVA_DIST_BACKEND"] = "gloo"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:            # one rank failed: the others would wait in a collective forever
+                    q.terminate()
+        time.sleep(0.2)
+    return rc
 
 
 def main():
@@ -234,6 +276,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     from halva_amd import dp, dpa, hip
     from halva_amd.llava_model import build_random_llava
@@ -242,9 +286,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the DPA hot path)")
     ctx = dp.DistContext.from_env("nccl")
     if ctx.world != args.gpus:
-        if args.gpus > 1 and ctx.world == 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d" % (args.gpus, ctx.world))
     torch.cuda.set_device(ctx.local_rank)
     dev = torch.device("cuda", ctx.local_rank)
 
@@ -285,10 +327,19 @@ def main():
     batch["images"] = batch["images"].to(dev, torch.bfloat16)          # inputs resident in HBM before the timed region
     batch["ref_images"] = batch["ref_images"].to(dev, torch.bfloat16)
 
+    # the gradient exchange starts inside the step's last backward (layer bucket by layer bucket) and is finished before AdamW
+    reducer = dp.GradReducer.for_flat(flat, ctx) if ctx.world > 1 else None
+    comm_probe = []
+
     def step():
         flat.zero_grad()
-        loss = eng.loss(batch, backward=True)
-        dp.allreduce_mean_(flat.grad, ctx)
+        loss = eng.loss(batch, backward=True, reducer=reducer)
+        if reducer is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            reducer.finish()
+            e1.record()
+            comm_probe.append((e0, e1, reducer.issued_early))
         opt.step()
         return loss
 
@@ -310,6 +361,7 @@ def main():
                                                                    " <- ".join(str(f).split("/")[-1] for f in e.stack[:5])), file=sys.stderr)
     from halva_amd import kernels as HK
     HK.sdpa_bwd_probe = [] if not args.no_roofline else None      # HIP events around every SDPA-backward launch of the timed steps
+    del comm_probe[:]
     dp.barrier(ctx)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -319,10 +371,7 @@ def main():
     dp.barrier(ctx)
     dt = time.perf_counter() - t0
     probe, HK.sdpa_bwd_probe = HK.sdpa_bwd_probe, None
-    if ctx.world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t)
+    dt = dp.max_scalar(dt, ctx)
     loss_val = float(last)
     pairs_per_s = ctx.world * B * args.steps / dt
 
@@ -332,8 +381,28 @@ def main():
     cpu = None
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
+    comm = None
+    if reducer is not None and comm_probe:
+        comm = {"bytes_per_step": int(flat.grad.numel() * 4), "buckets": len(reducer.buckets) + (reducer.late is not None),
+                "buckets_issued_inside_backward": comm_probe[-1][2],
+                "exposed_ms_per_step": round(sum(a.elapsed_time(b) for a, b, _ in comm_probe) / len(comm_probe), 3),
+                "backend": torch.distributed.get_backend(),
+                "note": "exposed = compute-stream time between the end of the last backward and the averaged gradient being ready "
+                        "(rank 0); the buckets of the upper layers are reduced while the lower layers are still being differentiated"}
     if ctx.rank == 0:
         tf_pair = TFLOP_PER_PAIR if (args.model == "7b" and not args.layers) else None
+        tf_exec = None
+        if tf_pair is not None:
+            # FLOPs actually issued: prefix sharing runs fewer rows of the pos/neg passes than the reference's two separate rows
+            # (linear layers scale with the rows, attention with the visible (query, key) pairs of the packed layout)
+            tf_exec = tf_pair
+            if eng.last_packing is not None and eng.last_layout is not None:
+                Tp, bra, brb, sl = eng.last_layout
+                row_ratio = eng.last_packing[0] / float(eng.last_packing[1])
+                pair_ratio = sum(visible_pairs(Tp, a, b_, n) for a, b_, n in zip(bra, brb, sl)) / float(2 * len(sl) * visible_pairs(seq))
+                lin = 2 * ((27.06 + 1.31) + (27.06 + 2.62))
+                att = 2 * (1.10 + 2.75)
+                tf_exec = tf_pair - lin * (1 - row_ratio) - att * (1 - pair_ratio)
         rec = {"metric": "paired-samples/sec (DPA step) LLaVA-1.5-7B @336px", "value": round(pairs_per_s, 4),
                "unit": "paired-samples/sec", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -355,9 +424,14 @@ def main():
                           "heuristic" % os.path.basename(eng.gemm_table),
                           "valid": not bool(args.layers) and args.model == "7b" and not args.resp_len},
                "loss": round(loss_val, 5),
-               # reference-algorithm FLOPs per pair x pairs/s: with prefix sharing fewer are executed
+               # reference-equivalent: the reference algorithm's FLOPs per pair x pairs/s; executed: the FLOPs
+               # this build issues for the same result (prefix sharing skips the duplicated prefix rows)
                "step_tflops_per_gpu": None if tf_pair is None else round(pairs_per_s / ctx.world * tf_pair, 1),
                "step_mfma_frac": None if tf_pair is None else round(pairs_per_s / ctx.world * tf_pair / PEAK_BF16_TFLOPS, 4),
+               "step_tflops_per_gpu_executed": None if tf_exec is None else round(pairs_per_s / ctx.world * tf_exec, 1),
+               "step_mfma_frac_executed": None if tf_exec is None else round(pairs_per_s / ctx.world * tf_exec / PEAK_BF16_TFLOPS, 4),
+               "tflop_per_pair": None if tf_pair is None else {"reference_equivalent": tf_pair, "executed": round(tf_exec, 1)},
+               "grad_allreduce": comm,
                "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(rec), flush=True)

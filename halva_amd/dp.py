@@ -7,8 +7,15 @@ exchange the path needs is the mean of the trainable gradients: the flat fp32 bu
 (xGMI is point-to-point: big buckets keep every link of the ring busy and amortise launch latency).
 `HalvaTrainer.compute_loss` bypasses any wrapper forward (reference halva_trainer.py:548,573), so DDP-style hooks could
 not be used anyway - the explicit all-reduce is the natural design.
+
+The exchange is overlapped with the tail of the step's LAST backward (`GradReducer`): the flat buffer is laid out layer by
+layer, the backward finishes the layers from the top down, and the moment layer i's input gradient exists every kernel that
+adds into the segments of layers >= i has been enqueued - so the bucket that ends there is handed to RCCL (which runs on its
+own stream behind an event of the compute stream) while the layers below are still being differentiated.  Only the last
+bucket (bottom layers + projector) is exposed.
 """
 import os
+import re
 
 import torch
 import torch.distributed as dist
@@ -22,14 +29,16 @@ class DistContext:
 
     @classmethod
     def from_env(cls, backend=None):
-        """Read RANK / WORLD_SIZE / LOCAL_RANK (torchrun or the `deepspeed` shim); initialise torch.distributed if needed.
-        backend: "nccl" (= RCCL on ROCm) on GPUs, "gloo" for the CPU tests."""
+        """Read RANK / WORLD_SIZE / LOCAL_RANK (torchrun, `bench.py --gpus N`'s own spawner or the `deepspeed` shim);
+        initialise torch.distributed if needed.  backend: "nccl" (= RCCL on ROCm) on GPUs, "gloo" for the CPU tests and
+        for several ranks sharing one GPU (HALVA_DIST_BACKEND overrides)."""
         world = int(os.environ.get("WORLD_SIZE", "1"))
         rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", "0"))
         if world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
+            backend = os.environ.get("HALVA_DIST_BACKEND") or backend
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
             if backend == "nccl":
@@ -38,26 +47,139 @@ class DistContext:
         return cls(rank, world, local)
 
 
+def _is_gloo(ctx):
+    return dist.get_backend(ctx.group) == "gloo"
+
+
+def _allreduce_sum_async(t, ctx):
+    """Sum `t` (a contiguous slice of the flat buffer) over the ranks; returns a finisher to call before `t` is read.
+    RCCL: asynchronous on the backend's stream, ordered behind the work already enqueued on the current stream.
+    gloo (CPU tests / ranks sharing a GPU): device tensors are staged through the host."""
+    if t.is_cuda and _is_gloo(ctx):
+        host = t.detach().cpu()
+        h = dist.all_reduce(host, op=dist.ReduceOp.SUM, group=ctx.group, async_op=True)
+
+        def fin():
+            h.wait()
+            t.copy_(host)
+        return fin
+    h = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=ctx.group, async_op=True)
+    return h.wait
+
+
 def allreduce_mean_(flat, ctx):
-    """In-place mean over ranks of a flat gradient buffer, bucketed.  Returns the buffer."""
+    """In-place mean over ranks of a flat gradient buffer, bucketed, after the fact (no overlap).  Returns the buffer."""
     if ctx.world == 1:
         return flat
-    handles = []
-    for lo in range(0, flat.numel(), BUCKET_ELEMS):
-        handles.append(dist.all_reduce(flat[lo:lo + BUCKET_ELEMS], op=dist.ReduceOp.SUM, group=ctx.group, async_op=True))
-    for h in handles:
-        h.wait()
+    fins = [_allreduce_sum_async(flat[lo:lo + BUCKET_ELEMS], ctx) for lo in range(0, flat.numel(), BUCKET_ELEMS)]
+    for f in fins:
+        f()
     flat.div_(ctx.world)
     return flat
 
 
-def mean_scalar(x, ctx):
-    if ctx.world == 1:
-        return float(x)
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+def layer_boundaries(names, offsets):
+    """({layer index: first flat element of that layer's parameters}, first element of the tail without a layer index) from
+    FlatTrainables' names/offsets ("...layers.<i>....").  The tail is the projector: it sits BEHIND the last layer in the buffer
+    but its gradient is the LAST thing a backward produces (below layer 0), so it can only be exchanged at the end."""
+    first, tail = {}, None
+    for n, o in zip(names, offsets):
+        m = re.search(r"layers\.(\d+)\.", n)
+        if m:
+            first.setdefault(int(m.group(1)), int(o))
+            tail = None
+        elif tail is None:
+            tail = int(o)
+    return first, tail
+
+
+class GradReducer:
+    """Mean of the flat fp32 gradient over the ranks, issued bucket by bucket WHILE the step's last backward is still running.
+
+    begin()            before that backward (nothing of the buffer is final yet);
+    ready_from(lo)     "every element at or beyond `lo` will not change any more" - called from the backward (tensor hook on
+                       a decoder layer's input, see LlamaModel.grad_ready_hook) with non-increasing `lo`; complete buckets
+                       [lo_b, hi_b) with lo_b >= lo are handed to the backend;
+    finish()           after the backward returned: the remaining head of the buffer and the late tail, wait for everything,
+                       divide by world.
+    Buckets are cut at layer boundaries, at least `min_bucket` elements each, walking down from `late_from` (default: the end
+    of the buffer); [late_from, end) - the projector - is one more bucket that only finish() may hand over."""
+
+    def __init__(self, flat_grad, ctx, boundaries=(), min_bucket=None, late_from=None):
+        self.g, self.ctx = flat_grad, ctx
+        min_bucket = BUCKET_ELEMS // 2 if min_bucket is None else min_bucket
+        n = flat_grad.numel()
+        top = n if late_from is None else int(late_from)
+        cuts = sorted({int(b) for b in boundaries if 0 < int(b) < top}, reverse=True)
+        self.buckets = []                      # top-down: [(lo, hi)], hi exclusive
+        self.late = (top, n) if top < n else None
+        hi = top
+        for c in cuts:
+            if hi - c >= min_bucket:
+                self.buckets.append((c, hi))
+                hi = c
+        if hi > 0:
+            self.buckets.append((0, hi))
+        self._next = 0
+        self._fins = []
+        self.issued_early = 0
+
+    @classmethod
+    def for_flat(cls, flat, ctx, min_bucket=None):
+        """Reducer over a FlatTrainables' gradient buffer with its layer boundaries as bucket cuts."""
+        first, tail = layer_boundaries(flat.names, flat.offsets[:-1])
+        r = cls(flat.grad, ctx, first.values(), min_bucket, late_from=tail)
+        r.first = first
+        return r
+
+    def begin(self):
+        self._next, self._fins, self.issued_early = 0, [], 0
+
+    def layer_done(self, i):
+        """The backward has produced the gradient of decoder layer i's input: layers >= i are final."""
+        lo = getattr(self, "first", {}).get(i)
+        if lo is not None:
+            self.ready_from(lo)
+
+    def _issue(self, lo, hi):
+        self._fins.append(_allreduce_sum_async(self.g[lo:hi], self.ctx))
+
+    def ready_from(self, lo):
+        if self.ctx.world == 1:
+            return
+        while self._next < len(self.buckets) and self.buckets[self._next][0] >= lo:
+            self._issue(*self.buckets[self._next])
+            self._next += 1
+            self.issued_early += 1
+
+    def finish(self):
+        if self.ctx.world == 1:
+            return self.g
+        while self._next < len(self.buckets):
+            self._issue(*self.buckets[self._next])
+            self._next += 1
+        if self.late is not None:
+            self._issue(*self.late)
+        for f in self._fins:
+            f()
+        self._fins = []
+        self.g.div_(self.ctx.world)
+        return self.g
+
+
+def _scalar(x, ctx, op):
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(ctx.group) == "nccl" else "cpu"
     t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, group=ctx.group)
-    return float(t) / ctx.world
+    dist.all_reduce(t, op=op, group=ctx.group)
+    return float(t)
+
+
+def mean_scalar(x, ctx):
+    return float(x) if ctx.world == 1 else _scalar(x, ctx, dist.ReduceOp.SUM) / ctx.world
+
+
+def max_scalar(x, ctx):
+    return float(x) if ctx.world == 1 else _scalar(x, ctx, dist.ReduceOp.MAX)
 
 
 def shard_batches(n_batches, ctx):

@@ -93,7 +93,7 @@ class _LmHeadKL(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dh,) = ctx.saved_tensors
-        return dh * g.to(dh.dtype), None, None, None
+        return dh * g.float(), None, None, None          # 0-dim fp32 scale: fp32 op-math, bf16 result (no bf16-rounded scale)
 
 
 def lm_head_logp(h_rows, lm_weight, target_i32):
@@ -343,10 +343,15 @@ class DPAEngine:
     def _groups(self, n, per):
         return [list(range(i, min(n, i + per))) for i in range(0, n, per)]
 
-    def loss(self, batch, backward=False, scale=1.0):
+    def loss(self, batch, backward=False, scale=1.0, reducer=None):
         """compute_loss of the reference (halva_trainer.py:534-592).  backward=True runs loss.backward() group by group
-        (gradients accumulate; activations of one group alive at a time) and returns the detached loss value."""
+        (gradients accumulate; activations of one group alive at a time) and returns the detached loss value.
+        reducer (halva_amd.dp.GradReducer, with backward=True): this is the LAST micro-batch before the optimizer step - the
+        data-parallel gradient exchange is started from inside the last group's backward, layer bucket by layer bucket; the
+        caller finishes it with reducer.finish()."""
         plan = self.make_plan(batch)
+        if reducer is not None:
+            reducer.begin()
         total = None
         parts = {"alignment": None, "divergence": None}
         for idx in self._groups(plan.B, self.pairs_per_group):
@@ -355,8 +360,16 @@ class DPAEngine:
                 (c * scale).backward()
                 c = c.detach()
             parts["alignment"] = c if parts["alignment"] is None else parts["alignment"] + c
-        for idx in self._groups(plan.B, self.ref_rows_per_group):
-            c, _ = self.ref_group_loss(batch, plan, idx)
+        ref_groups = self._groups(plan.B, self.ref_rows_per_group)
+        for gi, idx in enumerate(ref_groups):
+            armed = backward and reducer is not None and gi == len(ref_groups) - 1
+            lm = _llm_of(self.policy)[0].model
+            if armed:
+                lm.grad_ready_hook = reducer.layer_done
+            try:
+                c, _ = self.ref_group_loss(batch, plan, idx)
+            finally:
+                lm.grad_ready_hook = None
             if backward:
                 (c * scale).backward()
                 c = c.detach()
@@ -497,11 +510,18 @@ class AdamWFlat:
     def state_dict(self):
         return self.opt.state_dict()
 
+    def load_state_dict(self, sd):
+        """Restore step counts and moments (a checkpoint written by state_dict()); the group learning rates stay the run's."""
+        lrs = [(g["lr"], g["initial_lr"]) for g in self.opt.param_groups]
+        self.opt.load_state_dict(sd)
+        for g, (lr, ilr) in zip(self.opt.param_groups, lrs):
+            g["lr"], g["initial_lr"] = lr, ilr
+
 
 def cosine_with_warmup(step, total_steps, warmup_ratio):
     """HF get_cosine_schedule_with_warmup with num_warmup_steps = ceil(warmup_ratio * total_steps)."""
     warm = math.ceil(warmup_ratio * total_steps)
     if step < warm:
         return float(step) / float(max(1, warm))
-    prog = float(step - warm) / float(max(1, total_steps - warm))
+    prog = min(1.0, float(step - warm) / float(max(1, total_steps - warm)))      # past the end the rate stays at its floor
     return max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))

@@ -497,7 +497,7 @@ class _KLRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dpol,) = ctx.saved_tensors
-        return dpol * g.to(dpol.dtype).unsqueeze(1), None, None
+        return torch.mul(dpol, g.float().unsqueeze(1)).to(dpol.dtype), None, None       # scale applied in fp32, rounded once
 
 
 def kl_rows(pol2d, ref2d, w=None):

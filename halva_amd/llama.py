@@ -341,7 +341,8 @@ class LlamaModel(nn.Module):
         self.layers = nn.ModuleList([DecoderLayer(cfg, dtype, device) for _ in range(cfg.num_hidden_layers)])
         self.norm = RMSNormW(cfg.hidden_size, cfg.rms_norm_eps, dtype, device)
         self.gradient_checkpointing = False
-        self._rope = {}
+        self.grad_ready_hook = None     # callable(layer index): set for ONE forward by DPAEngine; fired from that forward's
+        self._rope = {}                 # backward when the gradient of a layer's input exists (halva_amd/dp.py:GradReducer)
 
     def rope(self, T, device):
         key = (str(device), max(T, 1))
@@ -365,7 +366,12 @@ class LlamaModel(nn.Module):
             self._rope = {}
             cos, sin = self.rope(T, x.device)
         info = SeqInfo(cos, sin, seq_start, seq_len, branch)
-        for layer in self.layers:
+        hook = self.grad_ready_hook if torch.is_grad_enabled() else None
+        for i, layer in enumerate(self.layers):
+            if hook is not None and x.requires_grad:
+                # the gradient of layer i's input is the last thing layer i's backward produces: every kernel that adds into
+                # the LoRA gradient segments of layers >= i has been enqueued when this fires
+                x.register_hook(lambda g, i=i, hook=hook: hook(i))
             if self.gradient_checkpointing and torch.is_grad_enabled() and x.requires_grad:
                 x = torch.utils.checkpoint.checkpoint(layer, x, info, use_lora, use_reentrant=False)
             else:

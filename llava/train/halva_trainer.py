@@ -240,10 +240,11 @@ class HalvaTrainer:
                                            eps=getattr(a, "adam_epsilon", 1e-8))
         return self.optimizer
 
-    def training_step(self, inputs, scale=1.0):
-        """One micro-batch: forward + backward group by group; gradients accumulate in the flat fp32 buffer."""
+    def training_step(self, inputs, scale=1.0, reducer=None):
+        """One micro-batch: forward + backward group by group; gradients accumulate in the flat fp32 buffer.
+        reducer: set on the last micro-batch before an optimizer step - the gradient exchange then starts inside its backward."""
         self._setup_engine()
-        return self._engine.loss(inputs, backward=True, scale=scale)
+        return self._engine.loss(inputs, backward=True, scale=scale, reducer=reducer)
 
     def _get_train_sampler(self):
         a = self.args
@@ -277,40 +278,173 @@ class HalvaTrainer:
         if self.dist.rank == 0:
             print(json.dumps(rec), flush=True)
 
+    # -- checkpoints (HF Trainer._save_checkpoint / _load_from_checkpoint as the reference inherits them; the adapter-only
+    #    branch of reference halva_trainer.py:365-390 for tune_mm_mlp_adapter) ---------------------------------------------
+    CKPT_PREFIX = "checkpoint"
+
+    def _checkpoint_dirs(self):
+        out = getattr(self.args, "output_dir", None)
+        if not out or not os.path.isdir(out):
+            return []
+        found = []
+        for n in os.listdir(out):
+            if n.startswith(self.CKPT_PREFIX + "-") and n.split("-", 1)[1].isdigit() and os.path.isdir(os.path.join(out, n)):
+                found.append((int(n.split("-", 1)[1]), os.path.join(out, n)))
+        return [p for _, p in sorted(found)]
+
+    def _save_checkpoint(self, model=None, trial=None, metrics=None):
+        """checkpoint-<global_step>/ : adapter weights in the output format (adapter_model.bin + non_lora_trainables.bin +
+        config.json), or only mm_projector.bin when tune_mm_mlp_adapter; plus everything needed to continue bit-for-bit:
+        fp32 master weights, AdamW moments, step/epoch position, torch RNG state at the start of the epoch."""
+        a = self.args
+        folder = os.path.join(a.output_dir, "%s-%d" % (self.CKPT_PREFIX, self.state.global_step))
+        if self.dist.rank == 0:
+            os.makedirs(folder, exist_ok=True)
+            self.model.config.save_pretrained(folder)
+            if getattr(a, "tune_mm_mlp_adapter", False):
+                proj, _ = dpa._projector_of(self.model)
+                torch.save({"model.mm_projector." + k: v.detach().cpu() for k, v in proj.state_dict().items()},
+                           os.path.join(folder, "mm_projector.bin"))
+            else:
+                self._save_adapter(folder)
+            torch.save({"master": self._flat.master.detach().cpu(), "names": list(self._flat.names),
+                        "optimizer": self.optimizer.state_dict(), "global_step": self.state.global_step,
+                        "epoch_index": self._pos["epoch"], "micro_in_epoch": self._pos["micro"],
+                        "micro_total": self._pos["total"], "epoch_rng_state": self._pos["rng"], "log_history": self.state.log_history,
+                        "world": self.dist.world},
+                       os.path.join(folder, "halva_state.pt"))
+            with open(os.path.join(folder, "trainer_state.json"), "w") as f:
+                json.dump({"global_step": self.state.global_step, "epoch": self.state.epoch, "log_history": self.state.log_history}, f,
+                          indent=1)
+            limit = getattr(a, "save_total_limit", None)
+            if limit is not None and limit > 0:                   # HF _rotate_checkpoints: keep the newest `limit`
+                for old in self._checkpoint_dirs()[:-limit]:
+                    import shutil
+                    shutil.rmtree(old, ignore_errors=True)
+        dp.barrier(self.dist)
+        return folder
+
+    def _save_adapter(self, folder):
+        """The trained tensors in the run's output naming (llava/train/train_halva.py:save_lora_outputs; VILA overrides)."""
+        from llava.train.train_halva import save_lora_outputs
+        a = self.args
+        save_lora_outputs(self.model, type("A", (), dict(output_dir=folder, lora_bias=getattr(a, "lora_bias", "none"),
+                                                         lora_r=getattr(a, "lora_r", 0), lora_alpha=getattr(a, "lora_alpha", 0),
+                                                         lora_dropout=getattr(a, "lora_dropout", 0.0)))())
+
+    def _load_from_checkpoint(self, folder):
+        st_path = os.path.join(folder, "halva_state.pt")
+        if not os.path.exists(st_path):
+            raise FileNotFoundError("%s holds no halva_state.pt: cannot resume from it (adapter-only checkpoints carry no "
+                                    "optimizer state)" % folder)
+        st = torch.load(st_path, map_location="cpu", weights_only=False)
+        if list(st["names"]) != list(self._flat.names):
+            raise RuntimeError("checkpoint %s was written for a different set of trainable tensors" % folder)
+        if st.get("world", self.dist.world) != self.dist.world:
+            raise RuntimeError("checkpoint %s was written by %d ranks, this run has %d: the per-rank batch order would differ"
+                               % (folder, st["world"], self.dist.world))
+        self._flat.master.copy_(st["master"])
+        self._flat.sync_compute_copy()
+        self.optimizer.load_state_dict(st["optimizer"])
+        self.state.global_step = int(st["global_step"])
+        self.state.log_history = list(st.get("log_history", []))
+        return st
+
+    def _should_save(self, end_of_epoch):
+        a = self.args
+        strat = str(getattr(a, "save_strategy", "no")).split(".")[-1].lower()
+        if strat == "steps" and not end_of_epoch:
+            n = getattr(a, "save_steps", 0)
+            n = int(n) if n >= 1 else int(math.ceil(n * self._max_steps))       # HF: a ratio of the total when < 1
+            return n > 0 and self.state.global_step % n == 0
+        return strat == "epoch" and end_of_epoch
+
     def train(self, resume_from_checkpoint=None):
+        """HF Trainer._inner_training_loop as the reference runs it (transformers 4.31): per epoch the sampler's batches are
+        dealt to the ranks, every `gradient_accumulation_steps`-th micro-batch (counted ACROSS epochs, 4.31's
+        total_batched_samples) closes an optimizer step - a trailing partial group of an epoch is not stepped on its own, its
+        gradients stay in the accumulator (unless the whole epoch is shorter than one group) - total steps =
+        ceil(epochs * floor(micro / accum)) or --max_steps, cosine schedule with warm-up over that total, checkpoint-<step>/ folders per --save_strategy /
+        --save_steps / --save_total_limit, and resume_from_checkpoint (True = newest checkpoint-* under output_dir)."""
         a = self.args
         torch.manual_seed(getattr(a, "seed", 42))
         self.create_optimizer()
-        accum = a.gradient_accumulation_steps
-        steps_per_epoch_hint = None
+        accum = max(1, int(a.gradient_accumulation_steps))
+        reducer = dp.GradReducer.for_flat(self._flat, self.dist) if self.dist.world > 1 else None
+        resume = None
+        if resume_from_checkpoint:
+            folder = resume_from_checkpoint if isinstance(resume_from_checkpoint, str) else None
+            if folder is None:
+                have = self._checkpoint_dirs()
+                if not have:
+                    raise ValueError("No valid checkpoint found in output directory (%s)" % getattr(a, "output_dir", None))
+                folder = have[-1]
+            resume = self._load_from_checkpoint(folder)
+            self.log({"resumed_from": folder, "step": self.state.global_step})
         t0 = time.time()
-        for epoch in range(int(math.ceil(a.num_train_epochs))):
+        n_epochs = int(math.ceil(a.num_train_epochs))
+        self._pos = {"epoch": 0, "micro": 0, "total": 0, "rng": None}
+        self._max_steps = None
+        done = False
+        total_micro = int(resume["micro_total"]) if resume is not None else 0
+        self._flat.zero_grad()
+        for epoch in range(n_epochs):
+            if resume is not None and epoch < resume["epoch_index"]:
+                continue
+            if resume is not None and epoch == resume["epoch_index"] and resume["epoch_rng_state"] is not None:
+                torch.set_rng_state(resume["epoch_rng_state"])          # the sampler below then draws the same order again
+            rng = torch.get_rng_state()
             loader = self.get_train_dataloader()
             n_micro = len(loader)
-            steps_per_epoch = max(1, math.ceil(n_micro / accum))
-            total_steps = getattr(a, "max_steps", -1) if getattr(a, "max_steps", -1) > 0 else int(steps_per_epoch * a.num_train_epochs)
+            steps_per_epoch = max(1, n_micro // accum)
+            max_steps = getattr(a, "max_steps", -1)
+            total_steps = max_steps if max_steps and max_steps > 0 else int(math.ceil(a.num_train_epochs * steps_per_epoch))
+            self._max_steps = total_steps
+            skip = 0
+            if resume is not None and epoch == resume["epoch_index"]:
+                skip = int(resume["micro_in_epoch"])
+                if skip >= n_micro:            # the checkpoint was written at the end of that epoch
+                    resume = None
+                    continue
+            resume = None if skip == 0 else resume
+            if self.state.global_step >= total_steps:
+                break
             running, seen = 0.0, 0
-            self._flat.zero_grad()
             for i, batch in enumerate(loader):
+                if i < skip:
+                    continue
+                resume = None
+                total_micro += 1
+                steps_now = total_micro % accum == 0 or (n_micro <= accum and (i + 1) == n_micro)
                 batch = self._to_device(batch)
-                loss = self.training_step(batch, scale=1.0 / accum)
+                loss = self.training_step(batch, scale=1.0 / accum, reducer=reducer if steps_now else None)
                 running, seen = running + float(loss), seen + 1
-                last = (i + 1) == n_micro
-                if (i + 1) % accum == 0 or last:
-                    dp.allreduce_mean_(self._flat.grad, self.dist)
-                    self.optimizer.set_lr_factor(dpa.cosine_with_warmup(self.state.global_step, total_steps,
-                                                                        getattr(a, "warmup_ratio", 0.0)))
-                    self.optimizer.step()
-                    self._flat.zero_grad()
-                    self.state.global_step += 1
-                    self.state.epoch = epoch + (i + 1) / n_micro
-                    if self.state.global_step % max(1, int(getattr(a, "logging_steps", 1))) == 0:
-                        mean = dp.mean_scalar(running / seen, self.dist)
-                        self.log({"loss": round(mean, 6), "step": self.state.global_step, "epoch": round(self.state.epoch, 4),
-                                  "learning_rate": self.optimizer.opt.param_groups[0]["lr"], "elapsed_s": round(time.time() - t0, 1)})
-                    running, seen = 0.0, 0
-                    if self.state.global_step >= total_steps:
-                        break
+                if not steps_now:
+                    continue
+                if reducer is not None:
+                    reducer.finish()
+                self.optimizer.set_lr_factor(dpa.cosine_with_warmup(self.state.global_step, total_steps,
+                                                                    getattr(a, "warmup_ratio", 0.0)))
+                self.optimizer.step()
+                self._flat.zero_grad()
+                self.state.global_step += 1
+                self.state.epoch = epoch + (i + 1) / n_micro
+                self._pos = {"epoch": epoch, "micro": i + 1, "total": total_micro, "rng": rng}
+                if self.state.global_step % max(1, int(getattr(a, "logging_steps", 1))) == 0:
+                    mean = dp.mean_scalar(running / seen, self.dist)
+                    self.log({"loss": round(mean, 6), "step": self.state.global_step, "epoch": round(self.state.epoch, 4),
+                              "learning_rate": self.optimizer.opt.param_groups[0]["lr"], "elapsed_s": round(time.time() - t0, 1)})
+                running, seen = 0.0, 0
+                if self._should_save(end_of_epoch=False):
+                    self._save_checkpoint()
+                if self.state.global_step >= total_steps:
+                    done = True
+                    break
+            if done:
+                break
+            self._pos = {"epoch": epoch + 1, "micro": 0, "total": total_micro, "rng": None}
+            if self._should_save(end_of_epoch=True):
+                self._save_checkpoint()
         for cb in self.callbacks:
             if hasattr(cb, "on_train_end"):
                 cb.on_train_end(a, self.state, None, model=self.model)

@@ -291,7 +291,7 @@ def export_llava(m, prefix):
     return out
 
 
-def make_batch(B, seed, n_patch, long_resp=False, vis=None, vocab=None):
+def make_batch(B, seed, n_patch, long_resp=False, vis=None, vocab=None, resp_base=None):
     """Synthetic collated batch in the reference's key layout (train_halva.py:963-989)."""
     vis = vis or VIS
     g = torch.Generator().manual_seed(seed)
@@ -312,7 +312,7 @@ def make_batch(B, seed, n_patch, long_resp=False, vis=None, vocab=None):
 
     inst = []
     for b in range(B):
-        rl = (14 if long_resp else 8) + 3 * b
+        rl = ((14 if long_resp else 8) if resp_base is None else resp_base) + 3 * b
         nph = 2 if b % 2 == 0 else 1            # unequal phrase counts -> batch-global slots with log2 filler
         phrases = [(1 + 4 * k, 2) for k in range(nph)]
         ids, labels, signs = seq(rl, phrases)
@@ -517,15 +517,22 @@ VIS64 = dict(hidden_size=128, intermediate_size=192, num_hidden_layers=3, num_at
              patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5, num_channels=3)
 
 
-def gen_dpa_step_d64(name="dpa_step_d64", std=0.06, lora_std=0.05):
-    """Geometry the HIP kernels support (head_dim 64) with bf16-representable weights/images, so the GPU path (bf16)
-    and the reference (fp32 here) start from identical numbers.  Weights are stored as raw bf16 bits (uint16)."""
+# head_dim 128 = the headline attention instantiation (LLaVA-1.5: 32 x 128): 2 heads x 128, responses of ~120 tokens so
+# that the causal kernel crosses 64-key tile boundaries (T ~ 140 after the splice)
+TINY128 = dict(vocab_size=160, hidden_size=256, intermediate_size=384, num_hidden_layers=2, num_attention_heads=2,
+               num_key_value_heads=2, max_position_embeddings=256, rms_norm_eps=1e-5, pad_token_id=0)
+
+
+def gen_dpa_step_d64(name="dpa_step_d64", std=0.06, lora_std=0.05, TINY64=TINY64, B=3, seed=51, max_len=64, resp_base=None,
+                     model_seed=300):
+    """Geometry the HIP kernels support (head_dim 64; TINY128: head_dim 128) with bf16-representable weights/images, so the GPU
+    path (bf16) and the reference (fp32 here) start from identical numbers.  Weights are stored as raw bf16 bits (uint16)."""
     def bits(t):
         return t.detach().bfloat16().view(torch.int16).numpy().view(np.uint16)
     tower = build_vision_tower(41, VIS64, bf16_round=True)
     n_patch = (VIS64["image_size"] // VIS64["patch_size"]) ** 2
-    B, seed, max_len, alpha = 3, 51, 64, 0.4
-    ref = build_llava(300, tower, max_len=max_len, tiny=TINY64, vis=VIS64, bf16_round=True, std=std)
+    alpha = 0.4
+    ref = build_llava(model_seed, tower, max_len=max_len, tiny=TINY64, vis=VIS64, bf16_round=True, std=std)
     policy = copy.deepcopy(ref)
     policy.model.vision_tower = tower
     ref.requires_grad_(False)
@@ -538,7 +545,7 @@ def gen_dpa_step_d64(name="dpa_step_d64", std=0.06, lora_std=0.05):
     for k, v in fac.items():
         packs[k] = bits(torch.from_numpy(v))
     packs["lora_cfg"] = np.array([4, 8.0])
-    batch = make_batch(B, seed, n_patch, vis=VIS64, vocab=TINY64["vocab_size"])
+    batch = make_batch(B, seed, n_patch, vis=VIS64, vocab=TINY64["vocab_size"], resp_base=resp_base)
     stub = trainer_stub(policy, ref, alpha)
     policy.zero_grad()
     pos_logps, neg_logps, batch_labels, all_logits, batch_signs = stub.concatenated_forward(policy, batch)
@@ -570,6 +577,31 @@ def gen_dpa_step_d64(name="dpa_step_d64", std=0.06, lora_std=0.05):
     packs["llama_cfg"] = np.frombuffer(json.dumps(TINY64).encode(), dtype=np.uint8)
     save_npz(name + ".npz", **packs)
     print("   ", name, "loss", float(loss), "align", float(align), "div", float(div))
+
+
+def gen_clip_d64():
+    """CLIP tower + projector at a geometry the HIP kernels run (2 heads x 64, 56 px -> 16 patches + CLS), bf16-exact weights and
+    images: CLIPVisionTower.forward (clip_encoder.py:37-56: hidden_states[-2], CLS dropped) and encode_images (llava_arch.py:80-83)."""
+    def bits(t):
+        return t.detach().bfloat16().view(torch.int16).numpy().view(np.uint16)
+    vis = dict(VIS64, image_size=56)
+    tower = build_vision_tower(43, vis, bf16_round=True)
+    m = build_llava(320, tower, tiny=TINY64, vis=vis, bf16_round=True, std=0.02)
+    g = torch.Generator().manual_seed(12)
+    images = torch.randn(3, 3, 56, 56, generator=g).bfloat16().float()
+    with torch.no_grad():
+        feats = tower(images)
+        proj = m.encode_images(images)
+        hs = tower.vision_tower(images, output_hidden_states=True).hidden_states
+    packs = {"images": t2n(images), "features": t2n(feats), "projected": t2n(proj), "hidden_first": t2n(hs[0]),
+             "hidden_m2": t2n(hs[-2])}
+    for n, p in tower.vision_tower.state_dict().items():
+        if "position_ids" not in n:
+            packs["clip." + n] = bits(p)
+    for n, p in m.model.mm_projector.state_dict().items():
+        packs["proj." + n] = bits(p)
+    packs["cfg"] = np.frombuffer(json.dumps(vis).encode(), dtype=np.uint8)
+    save_npz("clip_tower_d64.npz", **packs)
 
 
 def gen_llama_layer():
@@ -627,8 +659,17 @@ def main():
     gen_dpa_step(tower)
     gen_dpa_step_d64()
     gen_dpa_step_d64("dpa_step_d64_init", std=0.02, lora_std=0.02)
+    gen_dpa_step_d64("dpa_step_d128_init", std=0.02, lora_std=0.02, TINY64=TINY128, B=4, seed=61, max_len=192, resp_base=118,
+                     model_seed=310)
     gen_llama_layer()
+    gen_clip_d64()
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "d128":          # only the fixtures added in round 2 (the others reproduce bit for bit)
+        torch.set_num_threads(4)
+        gen_clip_d64()
+        gen_dpa_step_d64("dpa_step_d128_init", std=0.02, lora_std=0.02, TINY64=TINY128, B=4, seed=61, max_len=192, resp_base=118,
+                         model_seed=310)
+    else:
+        main()

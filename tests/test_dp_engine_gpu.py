@@ -1,0 +1,114 @@
+"""The data-parallel path of the REAL engine on the GPU: N ranks == one rank over the same global batch.
+
+Reference: one process per GPU (src/hallava_7b.sh:30), each with its own micro-batch from the sampler
+(llava/train/halva_trainer.py:261-272), gradients averaged over the ranks once per optimizer step.  Here two rank
+processes (started exactly like bench.py / bin/deepspeed start theirs) run halva_amd.dpa.DPAEngine on pairs {0,1} and
+{1,2} of the reference-generated fixture with the all-reduce issued from inside the last backward; a single process that
+runs the same two micro-batches one after the other with gradient accumulation (scale 1/2) must end up with the same flat
+fp32 gradient, the same mean loss and the same weights after one AdamW step.
+
+On a 1-GPU box the two ranks share the device and exchange over gloo (host-staged); with >= 2 GPUs the same test also runs
+over RCCL, one rank per GPU."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(world, out, backend, share_gpu):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if share_gpu else str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HALVA_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out], env=env))
+    codes = []
+    for p in procs:
+        try:
+            codes.append(p.wait(timeout=600))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            codes.append(-9)
+    assert codes == [0] * world, codes
+
+
+def _single_process_reference():
+    from dp_worker import micro_batch
+    from golden_util import load_npz
+    from model_util import batch_of, build_product_models
+    from halva_amd import dpa
+    z = load_npz("dpa_step_d64_init.npz")
+    pol, ref, _ = build_product_models(z, device="cuda:0")
+    flat = dpa.FlatTrainables(dpa.trainable_named_parameters(pol))
+    dpa.bind_model(flat, pol)
+    dpa.set_grad_sink(pol, True)
+    opt = dpa.AdamWFlat(flat, lr=1e-3, weight_decay=0.0, mm_projector_lr=1e-3)
+    eng = dpa.DPAEngine(pol, ref, float(z["alpha"]), pairs_per_group=1, ref_rows_per_group=1)
+    flat.zero_grad()
+    losses = [float(eng.loss(micro_batch(batch_of(z), [r, r + 1]), backward=True, scale=0.5)) for r in range(2)]
+    grad = flat.grad.detach().cpu().clone()
+    opt.step()
+    return grad, flat.master.detach().cpu(), sum(losses) / 2
+
+
+def _check(got, want):
+    grad, master, loss = want
+    assert got["world"] == 2
+    assert abs(got["loss"] - loss) < 1e-6
+    # every per-micro-batch gradient is produced by the same deterministic kernels; (a + b) / 2 vs a/2 + b/2 in fp32
+    scale = float(grad.abs().max())
+    assert scale > 0
+    assert float((got["grad"] - grad).abs().max()) <= 2e-6 * scale
+    assert float((got["master"] - master).abs().max()) <= 1e-6
+    # the exchange really was started from inside the backward: every layer bucket except the last one, and the projector
+    assert len(got["buckets"]) >= 3 and got["issued_early"] >= len(got["buckets"]) - 1
+
+
+def test_two_ranks_sharing_one_gpu_match_one_rank(tmp_path):
+    out = str(tmp_path / "dp2.pt")
+    _launch(2, out, "gloo", share_gpu=True)
+    _check(torch.load(out, weights_only=False), _single_process_reference())
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL)")
+def test_two_ranks_over_rccl_match_one_rank(tmp_path):
+    out = str(tmp_path / "dp2_rccl.pt")
+    _launch(2, out, "nccl", share_gpu=False)
+    got = torch.load(out, weights_only=False)
+    assert got["backend"] == "nccl"
+    _check(got, _single_process_reference())
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` (no launcher): the parent starts two fresh rank processes before touching the GPU and rank 0
+    prints the JSON line.  Two layers of the 7B geometry; on a 1-GPU box the ranks share the device (HALVA_BENCH_SHARE_GPU)."""
+    import json
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 2:
+        env["HALVA_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--layers", "2",
+                        "--pairs-per-gpu", "2", "--pairs-per-group", "2", "--no-cpu-baseline", "--no-roofline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_pairs"] == 4 and rec["value"] > 0
+    assert rec["grad_allreduce"]["buckets_issued_inside_backward"] >= 1

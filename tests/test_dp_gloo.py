@@ -45,6 +45,43 @@ def _worker(rank, world, port, out):
     torch.nn.functional.softplus(X @ ww).mean().backward()
     assert torch.allclose(grad, ww.grad, atol=1e-6)
     assert abs(dp.mean_scalar(float(rank), ctx) - 0.5) < 1e-12
+    # 2b. GradReducer: buckets cut at "layer" boundaries, handed over top-down as the backward reports layers done; the result is
+    #     the plain mean whatever the order/timing of the hand-over, and every bucket but the last can go out early
+    full = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    want = torch.arange(1000, dtype=torch.float32) * 1.5
+    for min_bucket, n_buckets in ((1, 5), (300, 3), (10 ** 6, 1)):
+        g = full.clone()
+        red = dp.GradReducer(g, ctx, boundaries=[0, 200, 400, 600, 800], min_bucket=min_bucket)
+        assert len(red.buckets) == n_buckets and red.buckets[0][1] == 1000 and red.buckets[-1][0] == 0
+        assert sorted(x for b in red.buckets for x in b)[0] == 0 and all(a[0] == b[1] for a, b in zip(red.buckets, red.buckets[1:]))
+        red.begin()
+        for lo in (800, 600, 400, 200):
+            red.ready_from(lo)
+        assert red.issued_early == sum(1 for b in red.buckets if b[0] >= 200)
+        red.finish()
+        assert torch.allclose(g, want)
+
+    class _Flat:
+        names = ["model.layers.0.a", "model.layers.0.b", "model.layers.1.a", "model.mm_projector.0.weight"]
+        offsets = [0, 10, 30, 60, 100]
+        grad = torch.ones(100) * (rank + 1)
+    red = dp.GradReducer.for_flat(_Flat, ctx, min_bucket=1)
+    # the projector tail [60, 100) lies behind the layers but is final only after the whole backward: never handed over early
+    assert red.first == {0: 0, 1: 30} and red.buckets == [(30, 60), (0, 30)] and red.late == (60, 100)
+    red.begin()
+    red.layer_done(1)
+    assert red.issued_early == 1
+    _Flat.grad[60:] += 1.0               # the projector gradient arrives at the very end of the backward
+    red.finish()
+    assert torch.allclose(_Flat.grad[:60], torch.full((60,), 1.5)) and torch.allclose(_Flat.grad[60:], torch.full((40,), 2.5))
+    _Flat.grad.fill_(rank + 1.0)
+    red.begin()
+    red.layer_done(1)
+    red.layer_done(0)
+    assert red.issued_early == 2
+    red.finish()
+    assert torch.allclose(_Flat.grad, torch.full((100,), 1.5))
+    assert dp.max_scalar(float(rank), ctx) == 1.0
     # 3. the trainer's loader shards the sampler's global batch list disjointly and completely
     from llava.train.halva_trainer import HalvaTrainer
 

@@ -27,7 +27,10 @@ def _engine(z, pairs_per_group, ref_rows_per_group, share_prefix=None):
 #                      loss by 4e-4, so the north-star bound (1e-3) is meaningful here;
 #   dpa_step_d64       "stress": weights N(0, 0.06), KL 0.55; bf16 alone moves the oracle's loss by 2.7e-3, so the bound is
 #                      8e-3 (3x the bf16 noise floor); used for the gradient checks (large, well-conditioned gradients).
-FIXTURES = {"dpa_step_d64_init": (1e-3, 1e-3, 1e-3), "dpa_step_d64": (8e-3, 8e-3, 8e-3)}
+#   dpa_step_d128_init head_dim 128 (2 heads x 128, hidden 256) - the headline attention instantiation - N(0, 0.02) weights,
+#                      4 pairs with ~120-token responses (T ~ 140: the causal kernel crosses 64-key tile boundaries); 1e-3.
+FIXTURES = {"dpa_step_d64_init": (1e-3, 1e-3, 1e-3), "dpa_step_d64": (8e-3, 8e-3, 8e-3), "dpa_step_d128_init": (1e-3, 1e-3, 1e-3)}
+MARGIN_TOL = {"dpa_step_d64_init": 1e-3, "dpa_step_d128_init": 1e-3, "dpa_step_d64": 8e-3}
 
 
 @pytest.mark.parametrize("fixture", list(FIXTURES))
@@ -39,9 +42,28 @@ def test_step_matches_reference_golden(ppg, rpg, share, fixture):
     z = load_npz(fixture + ".npz")
     eng, pol, ref, flat, (r, alpha, fac) = _engine(z, ppg, rpg, share)
     batch = batch_of(z)
+    margins = []
+    inner = eng.pair_group_loss
+
+    def spy(batch_, plan, idx):            # keep what every pair group hands back: (logp_dense, pos_acc, neg_acc)
+        out = inner(batch_, plan, idx)
+        margins.append((list(idx), out[1][1].detach().float().cpu().numpy(), out[1][2].detach().float().cpu().numpy()))
+        return out
+    eng.pair_group_loss = spy
     loss = eng.loss(batch, backward=True)
     torch.cuda.synchronize()
     assert (eng.last_packing is not None) == (share == "always")
+    # per-phrase log-prob sums and margins (north_star: "loss and phrase log-prob margins within 1e-3"), against the reference's
+    # own pos_acc / neg_acc (halva_trainer.py:562-568), for every pair and phrase slot
+    pos_acc = np.zeros_like(z["out.pos_acc"])
+    neg_acc = np.zeros_like(z["out.neg_acc"])
+    for idx, pa, na in margins:
+        pos_acc[idx], neg_acc[idx] = pa, na
+    mt = MARGIN_TOL[fixture]
+    assert np.abs(pos_acc - z["out.pos_acc"]).max() < mt * max(1.0, np.abs(z["out.pos_acc"]).max() / 10), (pos_acc, z["out.pos_acc"])
+    assert np.abs(neg_acc - z["out.neg_acc"]).max() < mt * max(1.0, np.abs(z["out.neg_acc"]).max() / 10), (neg_acc, z["out.neg_acc"])
+    margin, want_margin = neg_acc - pos_acc, z["out.neg_acc"] - z["out.pos_acc"]
+    assert np.abs(margin - want_margin).max() < mt * max(1.0, np.abs(want_margin).max() / 10), (margin, want_margin)
     got = float(loss)
     parts = {k: float(v) for k, v in eng.last_parts.items()}
     assert abs(got - float(z["out.loss"])) < tol_loss, (got, float(z["out.loss"]))

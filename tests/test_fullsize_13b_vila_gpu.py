@@ -1,0 +1,122 @@
+"""Size-independent properties of the DPA step at the widths of BASELINE configs[3] and configs[4] (the oracle cannot run there):
+
+  configs[3]  LLaVA-1.5-13B (reference src/hallava_13b.sh:9-11): d = 5120, 40 heads x 128, F = 13824, vocab 32000,
+              CLIP-L/14@336 -> 576 patches, T = 2048 post-splice, LoRA r = 128;
+  configs[4]  VILA-13B (reference src_vila/halva_vila_13b.sh:11-12,41-43; vila/train/halva_trainer.py:663-852): the same
+              Llama-13B widths behind SigLIP-so400m-384 (27 x 27 tokens of 1152, 16 heads x 72 run zero-padded to 128 lanes) +
+              mlp_downsample (-> 196 tokens of 4608 -> LayerNorm -> MLP), images [B, 1, 3, 384, 384], T = 4096 post-splice,
+              linear RoPE scaling (model_max_length 4096 > max_position_embeddings is exercised by the builder's max_len).
+
+The decoder / tower layer counts are cut to 2 so each test runs in seconds; every kernel and every library GEMM sees its
+full-size row width, head count, sequence length and vocabulary.  Identities (same as tests/test_fullsize_properties_gpu.py):
+identical pos / neg -> alignment = log 2; LoRA B = 0 -> divergence = 0 (both up to the bf16 GEMM noise floor, ~2e-5 nat per
+response token); loss and accumulated gradients independent of the grouping; prefix sharing (packed pairs) == separate rows."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _randomise_lora_b(layers, std, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    with torch.no_grad():
+        for layer in layers:
+            for _, grp in layer.groups():
+                for n in grp.names:
+                    getattr(grp, n).lora_B["default"].weight.normal_(0.0, std, generator=g)
+
+
+def _bind(pol):
+    from halva_amd import dpa
+    flat = dpa.FlatTrainables(dpa.trainable_named_parameters(pol))
+    dpa.bind_model(flat, pol)
+    dpa.set_grad_sink(pol, True)
+    return flat
+
+
+def _llava13b(lora_b_std=0.01, seed=7):
+    import bench
+    from halva_amd.llava_model import build_random_llava
+    geo = dict(bench.LLAMA_13B, num_hidden_layers=2)
+    clip = dict(bench.CLIP_L_336, num_hidden_layers=2)
+    pol = build_random_llava(geo, clip, lora_r=128, lora_alpha=256, seed=seed, device="cuda", max_len=2048)
+    if lora_b_std:
+        _randomise_lora_b(pol.model.layers, lora_b_std, seed + 1)
+    ref = build_random_llava(geo, clip, seed=seed, device="cuda", max_len=2048, share_base_from=pol)
+    return pol, ref, _bind(pol), dict(seq=2048, image=336, images_per_sample=None)
+
+
+def _vila13b(lora_b_std=0.01, seed=7):
+    import bench
+    from halva_amd.vila_model import build_random_vila
+    geo = dict(bench.LLAMA_13B, num_hidden_layers=2)
+    sig = dict(bench.SIGLIP_SO400M_384, num_hidden_layers=2)
+    pol = build_random_vila(geo, sig, lora_r=128, lora_alpha=256, seed=seed, device="cuda", max_len=4096)
+    if lora_b_std:
+        _randomise_lora_b(pol.llm.model.layers, lora_b_std, seed + 1)
+    ref = build_random_vila(geo, sig, seed=seed, device="cuda", max_len=4096, share_base_from=pol)
+    return pol, ref, _bind(pol), dict(seq=4096, image=384, images_per_sample=1)
+
+
+def _batch(pol, spec, B, seed=11, resp_len=None):
+    import bench
+    from halva_amd import dpa
+    n_patch = dpa.model_spec(pol).n_patch
+    assert n_patch == (576 if spec["images_per_sample"] is None else 196)
+    return bench.synthetic_batch(B, seed, resp_len=resp_len or (spec["seq"] - n_patch - 53), image=spec["image"],
+                                 images_per_sample=spec["images_per_sample"])
+
+
+def _loss(pol, ref, flat, batch, ppg, rpg, alpha, share=None):
+    from halva_amd import dpa
+    eng = dpa.DPAEngine(pol, ref, alpha, ppg, rpg, share_prefix=share)
+    flat.zero_grad()
+    loss = float(eng.loss(batch, backward=True))
+    torch.cuda.synchronize()
+    return loss, {k: float(v) for k, v in eng.last_parts.items()}, flat.grad.clone(), eng
+
+
+@pytest.mark.parametrize("build,alpha", [(_llava13b, 0.4), (_vila13b, 0.2)], ids=["llava13b", "vila13b"])
+def test_identities_at_13b_widths(build, alpha):
+    pol, ref, flat, spec = build(lora_b_std=0.0)
+    batch = _batch(pol, spec, 2)
+    for k in ("input_ids", "labels", "attention_mask"):
+        batch["neg_" + k] = batch[k].clone()                 # hallucinated == correct
+    loss, parts, grad, eng = _loss(pol, ref, flat, batch, 2, 2, alpha)
+    n_tok = int((batch["ref_labels"][:, 1:] != -100).sum())
+    assert eng.make_plan(batch).T_full == spec["seq"]        # the splice fills the model's full context (2048 / 4096)
+    assert abs(parts["alignment"] - math.log(2.0)) < 2e-3, parts
+    assert 0.0 <= parts["divergence"] < 1e-4 * n_tok / 2, (parts, n_tok)
+    assert abs(loss - math.log(2.0) - alpha * parts["divergence"]) < 2e-3
+    assert torch.isfinite(grad).all() and float(grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("build,alpha", [(_llava13b, 0.4), (_vila13b, 0.2)], ids=["llava13b", "vila13b"])
+def test_grouping_and_prefix_sharing_invariance_at_13b_widths(build, alpha):
+    pol, ref, flat, spec = build()
+    batch = _batch(pol, spec, 2)
+    l1, p1, g1, e1 = _loss(pol, ref, flat, batch, 2, 2, alpha, share=False)
+    l2, p2, g2, e2 = _loss(pol, ref, flat, batch, 1, 1, alpha, share=False)
+    l3, p3, g3, e3 = _loss(pol, ref, flat, batch, 2, 2, alpha, share="always")
+    assert e1.last_packing is None and e3.last_packing is not None and e3.last_packing[0] < e3.last_packing[1]
+    for l, p in ((l2, p2), (l3, p3)):
+        assert abs(l - l1) < 2e-3 * max(1.0, abs(l1)), (l, l1)
+        assert abs(p["alignment"] - p1["alignment"]) < 2e-3
+        assert abs(p["divergence"] - p1["divergence"]) < 2e-3 * max(1.0, p1["divergence"])
+    for g in (g2, g3):
+        assert float((g - g1).norm() / g1.norm()) < 2e-2
+    assert math.isfinite(l1) and p1["divergence"] > 0.0
+
+
+def test_vila13b_tower_and_projector_shapes():
+    """SigLIP-so400m-384 -> 729 tokens of 1152 (no CLS, 27 x 27 after the 6 dropped pixels), mlp_downsample -> 196 tokens of the
+    LLM width; the image tensor is [B, n, 3, 384, 384] and is flattened like vila/model/llava_arch.py:650-653."""
+    pol, ref, flat, spec = _vila13b()
+    imgs = torch.randn(2, 3, 384, 384, device="cuda").bfloat16()
+    with torch.no_grad():
+        f = pol.get_vision_tower()(imgs)
+        assert f.shape == (2, 729, 1152)
+        e = pol.encode_images(imgs)
+    assert e.shape == (2, 196, 5120) and torch.isfinite(e.float()).all()

@@ -466,3 +466,37 @@ def test_wgrad_accumulate_matches_fp32_reference(rows, M, N, lda, ldb):
         out.append(C)
     assert torch.equal(out[0], out[1])
     assert float((out[0].double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())) * max(1, rows // 2000)
+
+
+def test_clip_tower_features_match_reference():
+    """CLIPVisionTower.forward of the reference (clip_encoder.py:37-56 around HF CLIPVisionModel: patch conv, class token +
+    position embeddings, pre-LN, pre-norm blocks with quick_gelu, hidden_states[-2], CLS row dropped) and encode_images
+    (llava_arch.py:80-83: + mlp2x_gelu projector), run by the product tower (HIP patch-embed / LayerNorm / attention / projector
+    GEMMs) against the reference's own fp32 outputs on bf16-exact weights and images."""
+    from golden_util import load_npz, meta_of, tensors
+    from halva_amd.clip import CLIPVisionConfig, CLIPVisionTower, build_vision_projector
+    from types import SimpleNamespace
+    z = load_npz("clip_tower_d64.npz")
+    cfg = meta_of(z, "cfg")
+    for feature, want in (("patch", z["features"]), ("cls_patch", z["hidden_m2"])):
+        vt = CLIPVisionTower("fixture", args=SimpleNamespace(mm_vision_select_layer=-2, mm_vision_select_feature=feature),
+                             delay_load=True, config=CLIPVisionConfig(**cfg), device="cuda")
+        vt._alloc()
+        vt.load_hf_state_dict(tensors(z, "clip."))
+        vt.is_loaded = True
+        images = torch.from_numpy(z["images"]).cuda().bfloat16()
+        f = vt(images)
+        assert f.shape == tuple(want.shape) and f.dtype == torch.bfloat16
+        w = torch.from_numpy(want)
+        err = float((f.float().cpu() - w).norm() / w.norm())
+        assert err < 1e-2, (feature, err)                       # bf16 activations through 2 blocks + LNs: ~4e-3 observed
+        assert float((f.float().cpu() - w).abs().max()) < 0.05 * float(w.abs().max())
+    # projector on the tower's features = encode_images
+    pcfg = SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=cfg["hidden_size"], hidden_size=z["proj.0.weight"].shape[0])
+    proj = build_vision_projector(pcfg, device="cuda")
+    proj.load_state_dict({k: v.bfloat16() for k, v in tensors(z, "proj.").items()})
+    vt.select_feature = "patch"
+    y = proj(vt(images))
+    w = torch.from_numpy(z["projected"])
+    assert y.shape == tuple(w.shape)
+    assert float((y.float().cpu() - w).norm() / w.norm()) < 1e-2

@@ -1,9 +1,15 @@
 """Loss CURVE parity (north_star: "loss curve matching reference within 1e-3"): eight optimizer steps of the product (bf16
 compute through the C-ABI kernels, fp32 master weights, flat fp32 gradient buffer, AdamW with the reference's parameter groups)
 against the same eight steps of the oracle (fp32 torch-CPU restatement of the reference's compute_loss + torch.optim.AdamW) from
-the same reference-generated fixture (weights, LoRA factors, batch).  Bounds: 1e-3 at step 0 (identical weights: the north-star
-bound), 1.5e-3 on later steps (the bf16 compute copy of the parameters follows its own rounded trajectory; observed 2e-5 .. 1.05e-3),
-and 7e-4 on the mean absolute difference over the curve."""
+the same reference-generated fixture (weights, LoRA factors, batch).
+
+Two oracle curves:
+  * "bf16 parameters": what the reference's run holds (`--bf16 True` + DeepSpeed bf16, src/hallava_7b.sh:48, src/json/zero3.json):
+    fp32 master weights and AdamW state, the COMPUTE copy of every trainable tensor rounded to bf16 after each step, arithmetic in
+    fp32.  This is the curve the product must follow: every step within 1e-3 (the north-star bound);
+  * "fp32 parameters": no rounding anywhere (plain torch.optim.AdamW on fp32 leaves).  Kept as a second witness: at lr 2e-3 (400x
+    the recipe's 5e-6, so that eight steps move the loss by 0.5) the bf16 rounding of the updated factors is ~5 % of an update, and
+    the two ORACLE curves themselves differ by up to ~1e-3; the product is held to 1e-3 at step 0 and on the curve's mean."""
 import numpy as np
 import pytest
 import torch
@@ -16,7 +22,12 @@ from model_util import batch_of, build_product_models  # noqa: E402
 STEPS, LR, PROJ_LR, ALPHA = 8, 2e-3, 1e-3, 0.4
 
 
-def _oracle_curve(z):
+def _ste_bf16(t):
+    """Value = bf16(t), gradient = identity: the bf16 compute copy of an fp32 master tensor."""
+    return t + (t.detach().bfloat16().float() - t.detach())
+
+
+def _oracle_curve(z, bf16_params=False):
     from oracle import dpa as odpa
     cfg, ccfg = meta_of(z, "llama_cfg"), meta_of(z, "clip_cfg")
     base, clipW = tensors(z, "base."), tensors(z, "clip.")
@@ -37,6 +48,9 @@ def _oracle_curve(z):
     curve = []
     for _ in range(STEPS):
         opt.zero_grad()
+        if bf16_params:
+            pol.W = {k: (_ste_bf16(v) if v.requires_grad else v) for k, v in pol_W.items()}
+            pol.lora = {k: _ste_bf16(v) for k, v in lora.items()}
         loss, _ = odpa.compute_loss(pol, ref, batch, ALPHA)
         loss.backward()
         opt.step()
@@ -64,11 +78,18 @@ def _product_curve(z, ppg, rpg):
 @pytest.mark.parametrize("ppg,rpg", [(8, 8), (1, 2)])
 def test_loss_curve_matches_oracle(ppg, rpg):
     z = load_npz("dpa_step_d64_init.npz")
-    want = _oracle_curve(z)
+    want = _oracle_curve(z, bf16_params=True)
+    want32 = _oracle_curve(z, bf16_params=False)
     got = _product_curve(z, ppg, rpg)
     assert abs(want[0] - float(z["out.loss"])) < 1e-5                            # step 0 of the oracle IS the reference's own loss
+    assert abs(want32[0] - float(z["out.loss"])) < 1e-5
     assert want[-1] < want[0] - 0.05, want                                       # the curve really moves (lr 2e-3, 8 steps)
-    print("oracle ", [round(x, 5) for x in want])
-    print("product", [round(x, 5) for x in got])
+    print("oracle bf16-params", [round(x, 5) for x in want])
+    print("oracle fp32-params", [round(x, 5) for x in want32])
+    print("product           ", [round(x, 5) for x in got])
     d = np.abs(np.array(got) - np.array(want))
-    assert d[0] < 1e-3 and d.max() < 1.5e-3 and d.mean() < 7e-4, "product %s vs oracle %s" % (got, want)
+    assert d.max() < 1e-3, "product %s vs oracle (bf16 parameter copy) %s: |diff| %s" % (got, want, d)
+    d32 = np.abs(np.array(got) - np.array(want32))
+    assert d32[0] < 1e-3 and d32.mean() < 7e-4, "product %s vs oracle (fp32 parameters) %s" % (got, want32)
+    print("max |product - oracle_bf16| %.2e   max |product - oracle_fp32| %.2e   max |oracle_bf16 - oracle_fp32| %.2e"
+          % (d.max(), d32.max(), np.abs(np.array(want) - np.array(want32)).max()))

@@ -114,6 +114,18 @@ def test_clip_tower_and_projector():
     np.testing.assert_allclose(nets.projector(f, pw).numpy(), z["projected"], atol=2e-5)
 
 
+def test_clip_tower_d64_fixture():
+    """The fixture the GPU CLIP-tower test runs on (2 heads x 64, 16 patches + CLS): the oracle agrees with the reference on it."""
+    z = load_npz("clip_tower_d64.npz")
+    cfg = meta_of(z, "cfg")
+    W = tensors(z, "clip.")
+    f = nets.clip_features(torch.from_numpy(z["images"]), W, cfg, -2)
+    np.testing.assert_allclose(f.numpy(), z["features"], atol=3e-5)
+    np.testing.assert_allclose(f.numpy(), z["hidden_m2"][:, 1:], atol=3e-5)          # hidden_states[-2] with the CLS row dropped
+    pw = {"model.mm_projector." + k: v for k, v in tensors(z, "proj.").items()}
+    np.testing.assert_allclose(nets.projector(f, pw).numpy(), z["projected"], atol=3e-5)
+
+
 def test_llama_layer_against_vendored_spec():
     z = load_npz("llama_layer.npz")
     cfg = meta_of(z, "llama_cfg")
@@ -155,7 +167,8 @@ def _models_from(z):
     return pol, ref, lora
 
 
-@pytest.mark.parametrize("name", ["dpa_step_a", "dpa_step_trunc", "dpa_step_identity", "dpa_step_d64"])
+@pytest.mark.parametrize("name", ["dpa_step_a", "dpa_step_trunc", "dpa_step_identity", "dpa_step_d64", "dpa_step_d64_init",
+                                  "dpa_step_d128_init"])
 def test_compute_loss(name):
     z = load_npz(name + ".npz")
     pol, ref, lora = _models_from(z)

@@ -124,3 +124,54 @@ def test_gpu_image_pipeline_matches_cpu_dataset(tmp_path, monkeypatch):
     TH.train(argv)
     state = json.load(open(os.path.join(out, "trainer_state.json")))
     assert state["global_step"] == 3 and all(math.isfinite(r["loss"]) for r in state["log_history"])
+
+
+def _argv(paths, out, extra):
+    return ("--lora_enable True --lora_r 8 --lora_alpha 16 --mm_projector_lr 0 --loss_alpha 0.4 --model_name_or_path %s --version v1 "
+            "--data_path %s --ref_data_path %s --image_folder %s --vision_tower %s --mm_projector_type mlp2x_gelu "
+            "--mm_vision_select_layer -2 --mm_use_im_start_end False --mm_use_im_patch_token False --image_aspect_ratio pad "
+            "--group_by_modality_length True --bf16 True --output_dir %s --num_train_epochs 2 --per_device_train_batch_size 2 "
+            "--gradient_accumulation_steps 1 --learning_rate 1e-3 --warmup_ratio 0.03 --lr_scheduler_type cosine --logging_steps 1 "
+            "--model_max_length 64 %s" % (paths["ckpt"], paths["data"], paths["ref"], paths["images"], paths["vision"], out, extra)).split()
+
+
+def test_checkpoints_and_resume_continue_bit_for_bit(tmp_path, monkeypatch):
+    """--save_strategy steps --save_steps 2 writes checkpoint-2/4/6 (adapter in the output format + fp32 master weights, AdamW
+    moments, position in the epoch, RNG state); --save_total_limit keeps the newest; a run that finds checkpoint-4 in its
+    output_dir (reference train_halva.py:1222-1225 -> trainer.train(resume_from_checkpoint=True)) continues from it and ends with
+    exactly the tensors of the uninterrupted run."""
+    import shutil
+    import llava.train.train_halva as TH
+    paths = e2e_util.build(str(tmp_path))
+    e2e_util.patch_tokenizer(monkeypatch, paths["vocab_size"])
+    out_a = os.path.join(str(tmp_path), "run_a")
+    TH.train(_argv(paths, out_a, "--save_strategy steps --save_steps 2"))
+    state_a = json.load(open(os.path.join(out_a, "trainer_state.json")))
+    assert state_a["global_step"] == 6                                   # 6 samples / bs 2 = 3 micro-batches x 2 epochs, accum 1
+    assert sorted(d for d in os.listdir(out_a) if d.startswith("checkpoint-")) == ["checkpoint-2", "checkpoint-4", "checkpoint-6"]
+    for f in ("adapter_model.bin", "non_lora_trainables.bin", "config.json", "halva_state.pt", "trainer_state.json"):
+        assert os.path.exists(os.path.join(out_a, "checkpoint-4", f)), f
+    # the final artefacts equal the last checkpoint's adapter
+    fin = torch.load(os.path.join(out_a, "adapter_model.bin"))
+    ck6 = torch.load(os.path.join(out_a, "checkpoint-6", "adapter_model.bin"))
+    assert all(torch.equal(fin[k], ck6[k]) for k in fin)
+    # interrupted run: only checkpoint-4 survives
+    out_b = os.path.join(str(tmp_path), "run_b")
+    os.makedirs(out_b)
+    shutil.copytree(os.path.join(out_a, "checkpoint-4"), os.path.join(out_b, "checkpoint-4"))
+    TH.train(_argv(paths, out_b, "--save_strategy steps --save_steps 2 --save_total_limit 1"))
+    state_b = json.load(open(os.path.join(out_b, "trainer_state.json")))
+    assert state_b["global_step"] == 6
+    assert any("resumed_from" in r for r in state_b["log_history"])
+    assert [r["loss"] for r in state_b["log_history"] if "loss" in r] == [r["loss"] for r in state_a["log_history"] if "loss" in r]
+    assert sorted(d for d in os.listdir(out_b) if d.startswith("checkpoint-")) == ["checkpoint-6"]          # --save_total_limit 1
+    got = torch.load(os.path.join(out_b, "adapter_model.bin"))
+    assert set(got) == set(fin) and all(torch.equal(got[k], fin[k]) for k in fin)
+    nl_a = torch.load(os.path.join(out_a, "non_lora_trainables.bin"))
+    nl_b = torch.load(os.path.join(out_b, "non_lora_trainables.bin"))
+    assert all(torch.equal(nl_a[k], nl_b[k]) for k in nl_a)
+    # resume_from_checkpoint with nothing to resume from fails loudly instead of silently restarting
+    from llava.train.halva_trainer import HalvaTrainer
+    t = HalvaTrainer.__new__(HalvaTrainer)
+    t.args = type("A", (), dict(output_dir=os.path.join(str(tmp_path), "empty")))()
+    assert t._checkpoint_dirs() == []

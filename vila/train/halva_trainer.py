@@ -111,12 +111,20 @@ class HalvaTrainer(_Base):
         self.loss_holder["loss"].append(l)
 
     # -- engine-backed training ---------------------------------------------------------------------
-    def training_step(self, inputs, scale=1.0):
+    def training_step(self, inputs, scale=1.0, reducer=None):
         self._setup_engine()
-        loss = self._engine.loss(inputs, backward=True, scale=scale)
+        loss = self._engine.loss(inputs, backward=True, scale=scale, reducer=reducer)
         p = self._engine.last_parts
         self._record(loss, p["alignment"], p["divergence"])
         return loss
+
+    def _save_adapter(self, folder):
+        """checkpoint-<step>/ in VILA's output naming (llm.base_model.model... + mm_projector...)."""
+        from vila.train.train_halva import save_lora_outputs
+        a = self.args
+        save_lora_outputs(self.model, type("A", (), dict(output_dir=folder, lora_bias=getattr(a, "lora_bias", "none"),
+                                                         lora_r=getattr(a, "lora_r", 0), lora_alpha=getattr(a, "lora_alpha", 0),
+                                                         lora_dropout=getattr(a, "lora_dropout", 0.0)))())
 
     def _get_train_sampler(self):
         if self.train_dataset is None:
