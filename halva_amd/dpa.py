@@ -25,10 +25,12 @@ import torch
 
 from . import kernels as K
 from . import splice as SP
-from .hip import BF16, call, ptr, stream_ptr
+from .hip import BF16, F32, call, ptr, stream_ptr
 
 IGNORE_INDEX = -100
 LOGIT_CHUNK_ROWS = 8192            # 8192 x 32000 bf16 = 0.5 GB of transient logits
+# token log-probs from fp32 logits (the GEMM accumulates in fp32 anyway; this only skips the rounding of its output to bf16)
+LOGITS_F32 = os.environ.get("HALVA_LOGITS_F32", "0") == "1"
 
 
 class _LmHeadLogp(torch.autograd.Function):
@@ -45,6 +47,10 @@ class _LmHeadLogp(torch.autograd.Function):
         st = stream_ptr()
         for c0 in range(0, R, LOGIT_CHUNK_ROWS):
             c1 = min(R, c0 + LOGIT_CHUNK_ROWS)
+            if LOGITS_F32:
+                logits = torch.mm(h[c0:c1], W.t(), out_dtype=torch.float32)
+                call("halva_token_logp_fwd", ptr(logits), F32, V, ptr(target[c0:c1]), ptr(logp[c0:c1]), ptr(lse[c0:c1]), c1 - c0, V, st)
+                continue
             logits = torch.mm(h[c0:c1], W.t())
             call("halva_token_logp_fwd", ptr(logits), BF16, V, ptr(target[c0:c1]), ptr(logp[c0:c1]), ptr(lse[c0:c1]), c1 - c0, V, st)
         ctx.save_for_backward(h, target, lse)

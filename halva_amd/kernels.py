@@ -277,7 +277,20 @@ class _SpliceRows(torch.autograd.Function):
         rows = (src <= -2).nonzero().flatten()
         dfeat = torch.zeros(ctx.feat_shape, dtype=torch.float32, device=dout.device).view(-1, d)
         if rows.numel():
-            dfeat.index_add_(0, (-src[rows].long() - 2), dout.reshape(-1, d)[rows].float())
+            # a feature row feeds one output row per sequence that shows its image (two when the rows of a pair run unpacked): summed
+            # in a FIXED order - occurrence by occurrence, each pass a plain scatter with unique targets - not with float atomics,
+            # so two runs of the same step give the same bits
+            f = -src[rows].long() - 2
+            order = torch.argsort(f, stable=True)
+            fs, rs = f[order], rows[order]
+            start = torch.ones_like(fs, dtype=torch.bool)
+            start[1:] = fs[1:] != fs[:-1]
+            idx = torch.arange(fs.numel(), device=fs.device)
+            occ = idx - torch.cummax(torch.where(start, idx, torch.zeros_like(idx)), 0).values
+            do = dout.reshape(-1, d)
+            for k in range(int(occ.max()) + 1):
+                sel = occ == k
+                dfeat[fs[sel]] += do[rs[sel]].float()
         return None, dfeat.to(torch.bfloat16).view(ctx.feat_shape), None, None, None
 
 

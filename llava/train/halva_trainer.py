@@ -295,7 +295,7 @@ class HalvaTrainer:
     def _save_checkpoint(self, model=None, trial=None, metrics=None):
         """checkpoint-<global_step>/ : adapter weights in the output format (adapter_model.bin + non_lora_trainables.bin +
         config.json), or only mm_projector.bin when tune_mm_mlp_adapter; plus everything needed to continue bit-for-bit:
-        fp32 master weights, AdamW moments, step/epoch position, torch RNG state at the start of the epoch."""
+        fp32 master weights, AdamW moments, step / epoch / micro-batch position (an epoch's batch order follows from seed + epoch)."""
         a = self.args
         folder = os.path.join(a.output_dir, "%s-%d" % (self.CKPT_PREFIX, self.state.global_step))
         if self.dist.rank == 0:
@@ -391,9 +391,11 @@ class HalvaTrainer:
         for epoch in range(n_epochs):
             if resume is not None and epoch < resume["epoch_index"]:
                 continue
-            if resume is not None and epoch == resume["epoch_index"] and resume["epoch_rng_state"] is not None:
-                torch.set_rng_state(resume["epoch_rng_state"])          # the sampler below then draws the same order again
-            rng = torch.get_rng_state()
+            # the order of an epoch is a function of (seed, epoch index) alone: the global torch generator the reference's sampler
+            # draws from (generator=None, halva_trainer.py:146-150) is re-seeded per epoch, so a resumed run re-derives the same
+            # batches without having to replay the random stream of the epochs before it
+            torch.manual_seed(getattr(a, "seed", 42) + epoch)
+            rng = None
             loader = self.get_train_dataloader()
             n_micro = len(loader)
             steps_per_epoch = max(1, n_micro // accum)
@@ -430,6 +432,10 @@ class HalvaTrainer:
                 self.state.global_step += 1
                 self.state.epoch = epoch + (i + 1) / n_micro
                 self._pos = {"epoch": epoch, "micro": i + 1, "total": total_micro, "rng": rng}
+                if os.environ.get("HALVA_TRAIN_DEBUG"):
+                    print("debug step %d epoch %d micro %d ids-sum %d master-sum %.9f grad-state %s" % (
+                        self.state.global_step, epoch, i, int(batch["input_ids"].sum()), float(self._flat.master.double().sum()),
+                        [float(v["exp_avg"].double().sum()) for v in self.optimizer.opt.state.values()]), flush=True)
                 if self.state.global_step % max(1, int(getattr(a, "logging_steps", 1))) == 0:
                     mean = dp.mean_scalar(running / seen, self.dist)
                     self.log({"loss": round(mean, 6), "step": self.state.global_step, "epoch": round(self.state.epoch, 4),

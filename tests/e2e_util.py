@@ -66,12 +66,31 @@ def build(root):
                 vocab_size=cfg["vocab_size"])
 
 
+def warm_vocab(tok, paths):
+    """The stand-in tokenizer numbers pieces in first-seen order: fix that order by walking the fixture dataset once in index
+    order, so that token ids do not depend on which sample a run visits first - two runs, or a resumed run, then see the same ids.
+    The vocabulary is frozen afterwards: an unseen piece raises."""
+    import llava.train.train_halva as TH
+    from llava import conversation as conv_lib
+    from transformers import CLIPImageProcessor
+    conv_lib.default_conversation = conv_lib.conv_templates["v1"]
+    args = TH.DataArguments(data_path=paths["data"], ref_data_path=paths["ref"], image_folder=paths["images"], image_aspect_ratio="pad")
+    args.image_processor = CLIPImageProcessor.from_pretrained(paths["vision"])
+    args.is_multimodal, args.mm_use_im_start_end = True, False
+    keep, tok.pad_token = tok.pad_token, tok.unk_token
+    ds = TH.make_supervised_data_module(tok, args)["train_dataset"]
+    for i in range(len(ds)):
+        ds[i]
+    tok.pad_token = keep
+    tok.frozen = True
+
+
 class _Tok(FakeLlamaTokenizer):
     unk_token = "<unk>"
     pad_token = None
 
 
-def patch_tokenizer(monkeypatch, max_vocab):
+def patch_tokenizer(monkeypatch, max_vocab, warm_paths=None):
     """transformers 5.x no longer ships the legacy slow Llama tokenizer the reference's span walk relies on: use the
     deterministic stand-in (tests/golden/fake_tokenizer.py) for the end-to-end tests."""
     import transformers
@@ -80,6 +99,8 @@ def patch_tokenizer(monkeypatch, max_vocab):
         t = _Tok(model_max_length=model_max_length)
         t.padding_side = padding_side
         t.max_vocab = max_vocab
+        if warm_paths is not None:
+            warm_vocab(t, warm_paths)
         return t
     monkeypatch.setattr(transformers.AutoTokenizer, "from_pretrained", staticmethod(from_pretrained))
 

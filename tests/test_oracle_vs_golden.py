@@ -200,3 +200,14 @@ def test_compute_loss(name):
             A, Bm = lora[mod + ".A"], lora[mod + ".B"]
             np.testing.assert_allclose(A.grad.numpy(), (s * Bm.detach().T @ dW).numpy(), atol=3e-5, err_msg=k)
             np.testing.assert_allclose(Bm.grad.numpy(), (s * dW @ A.detach().T).numpy(), atol=3e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["dpa_step_d64_init", "dpa_step_d128_init", "dpa_step_d64"])
+def test_bf16_floor_constants(name):
+    """The GPU step test bounds the product's phrase-margin error by the bf16 noise floor of the reference arithmetic itself
+    (this oracle re-run with bf16 tensors).  The committed constants must not be inflated: at most 2x a live measurement."""
+    import test_dpa_step_gpu as G
+    z = load_npz(name + ".npz")
+    _, _, live = G._bf16_floor(name, z)
+    assert live > 1e-3                                    # bf16 alone already breaks 1e-3 absolute on the margins
+    assert G.MARGIN_FLOOR[name] <= 2.0 * live, (G.MARGIN_FLOOR[name], live)
