@@ -27,9 +27,6 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
-#ifndef DKV_BQ
-#define DKV_BQ 64       // query rows staged per barrier in the dK/dV kernel
-#endif
 
 #ifdef HALVA_STAMP
 #define STAMP(i)                                                                                   \
@@ -75,6 +72,8 @@ struct SdpaParams {
     int T, H;
     int nblk, npairs;     // row blocks per (sequence, head) pair; number of pairs (S * H)
     unsigned long long* dbg;   // diagnostic builds only
+    char* ds_ws;          // backward: dS = P o (dP - delta) as bf16 in the dK/dV kernel's register layout (see ds_chunk), or nullptr
+    int ds_nkb, ds_nt;    // key blocks of 128 / query steps of 64 per (sequence, head) in ds_ws
     float scale;          // softmax scale
 };
 
@@ -795,221 +794,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void sdpa_bwd_dq_kernel
 }
 
 // ===================================================================================================
-// backward, part 2: dK, dV.  A workgroup owns 128 keys (32 per wave, K/V fragments in registers) and streams
-// 32-row tiles of Q and dO (one dual-use LDS image each) from the diagonal to the end of the sequence.
-// ===================================================================================================
-template <int D, bool CAUSAL, bool SLOW_TR>
-__device__ __forceinline__ void sdpa_bwd_dkv_block(const SdpaParams& p, char* smem, int s, int hd, int kb) {
-    // BQ query rows are staged per barrier and consumed as BQ/32 sub-tiles of 32 rows: the longer compute phase per
-    // staging step covers the L2/HBM latency of the next Q/dO tile with ONE tile in flight.
-    constexpr int BQ = DKV_BQ, SUB = BQ / 32, KS = D / 16, DT = D / 32;
-    constexpr int TILE_BYTES = BQ * D * 2;
-    char* q_lds = smem;                       // [2][BQ][D]
-    char* do_lds = smem + 2 * TILE_BYTES;     // [2][BQ][D]
-    float* lse_lds = reinterpret_cast<float*>(smem + 4 * TILE_BYTES);   // [2][BQ]
-    float* dlt_lds = lse_lds + 2 * BQ;                                  // [2][BQ]
+// backward, part 2: dK, dV, two-role form.  A workgroup owns 128 keys and streams 64-row tiles of Q and dO (one dual-use LDS image
+// each) from the diagonal to the end of the sequence.  Keeping K, V, dK and dV of a 32-key strip in one wave needs 362 registers,
+// i.e. one wave per SIMD; that form (round 1) was replaced by the split below and is gone.
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-    const int start = p.seq_start ? p.seq_start[s] : 0;
-    const int len = p.seq_len ? p.seq_len[s] : p.T;
-    const int64_t seq_row0 = (int64_t)s * p.T;
-    const int gk = kb * 128 + 32 * wave + (lane & 31);   // this lane's key row (padded index)
-    const int kl = gk - start;
-    const bool k_in_T = gk < p.T;
-    const bool k_valid = k_in_T && kl >= 0 && kl < len;
-    bf16_t* dkrow = p.dk + (seq_row0 + gk) * p.ld_qkv + hd * D;
-    bf16_t* dvrow = p.dv + (seq_row0 + gk) * p.ld_qkv + hd * D;
-
-    // query range (local indices) this key block needs
-    const int kblk_min = kb * 128 - start;                 // local index of the block's first key row
-    int q_begin = 0;
-    if (CAUSAL) q_begin = max(0, kblk_min) / BQ * BQ;
-    const bool block_has_keys = (kblk_min < len) && (kblk_min + 128 > 0);
-    // branch points: queries >= br.b never look at keys in [br.a, br.b); a key block wholly inside that range stops at br.b
-    const Branch br = load_branch(p, s);
-    const int q_stop = (kblk_min >= br.a && kblk_min + 127 < br.b) ? min(len, br.b) : len;
-    const int ntiles = (block_has_keys && q_stop > q_begin) ? (q_stop - q_begin + BQ - 1) / BQ : 0;
-    const bool key_hidden = kl >= br.a && kl < br.b;       // per lane: this key is invisible to branch-B queries
-    if (ntiles == 0) {
-        if (k_in_T) {
-            store_rows_zero<D>(dkrow, lane);
-            store_rows_zero<D>(dvrow, lane);
-        }
-        return;
-    }
-
-    const bf16_t* qp = p.q + hd * D;
-    const bf16_t* dop = p.d_o + hd * D;
-    s16x8 kf[KS], vf[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        if (k_valid) {
-            kf[ks] = *reinterpret_cast<const s16x8*>(p.k + (seq_row0 + gk) * p.ld_qkv + hd * D + 16 * ks + 8 * h);
-            vf[ks] = *reinterpret_cast<const s16x8*>(p.v + (seq_row0 + gk) * p.ld_qkv + hd * D + 16 * ks + 8 * h);
-        } else {
-            kf[ks] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            vf[ks] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-    }
-    f32x16 dkacc[DT], dvacc[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            dkacc[dt][r] = 0.f;
-            dvacc[dt][r] = 0.f;
-        }
-    const float sc = p.scale * kLog2e;
-    const int wk_min = kblk_min + 32 * wave;   // smallest local key index of this wave
-    const bool wave_has_pad_keys = __any(!k_valid);
-
-    Stage<D, BQ> qst, dst;
-    const int64_t qrow0 = seq_row0 + start;
-    const float* lse_g = p.lse + ((int64_t)s * p.H + hd) * p.T + start;
-    const float* dlt_g = p.delta + ((int64_t)s * p.H + hd) * p.T + start;
-    // row statistics of the next tile: the RAW values are fetched (clamped index, no arithmetic on them until the LDS store
-    // after the compute phase - vmcnt retires in order, so touching them early would also wait for the tile loads)
-    float st_lse = 0.f, st_dlt = 0.f;
-    auto load_stats = [&](int q0) {
-        if (threadIdx.x < BQ) {
-            const int ql = min(q0 + (int)threadIdx.x, len - 1);
-            st_lse = lse_g[ql];
-            st_dlt = dlt_g[ql];
-        }
-    };
-    auto store_stats = [&](int buf) {
-        if (threadIdx.x < BQ) {
-            lse_lds[buf * BQ + threadIdx.x] = st_lse * kLog2e;
-            dlt_lds[buf * BQ + threadIdx.x] = st_dlt;
-        }
-    };
-    __syncthreads();      // the previous key block of this workgroup may still be reading its last tile
-    load_stats(q_begin);
-    qst.load_clamped(qp, p.ld_qkv, qrow0, q_begin, len);
-    dst.load_clamped(dop, p.ld_do, qrow0, q_begin, len);
-    qst.store(q_lds);
-    dst.store(do_lds);
-    store_stats(0);
-    __syncthreads();
-
-#ifdef HALVA_STAMP
-    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_prev;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
-#endif
-    for (int it = 0; it < ntiles; ++it) {
-        STAMP(5);
-        const int qt0 = q_begin + it * BQ;
-        const char* qt = q_lds + (it & 1) * TILE_BYTES;
-        const char* dot = do_lds + (it & 1) * TILE_BYTES;
-        const float* lse_t = lse_lds + (it & 1) * BQ;
-        const float* dlt_t = dlt_lds + (it & 1) * BQ;
-        if (it + 1 < ntiles) {
-            load_stats(qt0 + BQ);
-            qst.load_clamped(qp, p.ld_qkv, qrow0, qt0 + BQ, len);
-            dst.load_clamped(dop, p.ld_do, qrow0, qt0 + BQ, len);
-        }
-        STAMP(0);
-#pragma unroll
-        for (int sub = 0; sub < SUB; ++sub) {
-            const int q0 = qt0 + 32 * sub;
-            const bool q_in_b = q0 >= br.b;                 // uniform: br.b is a multiple of 64, sub-tiles are 32 rows
-            const bool wave_hidden = q_in_b && wk_min >= br.a && wk_min + 31 < br.b;
-            const bool active = (q0 < len) && (!CAUSAL || (q0 + 31 >= wk_min)) && !wave_hidden;
-            if (!active) continue;
-            // S[q][key] and dP[q][key]: key on the lane, q on the accumulator rows
-            f32x16 sa, dpa;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sa[r] = 0.f;
-                dpa[r] = 0.f;
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                sa = mfma32(frag_rows<D>(qt, 32 * sub, ks, lane), kf[ks], sa);
-                dpa = mfma32(frag_rows<D>(dot, 32 * sub, ks, lane), vf[ks], dpa);
-            }
-#ifdef HALVA_STAMP
-            asm volatile("" : "+v"(sa[15]), "+v"(dpa[15]));
-#endif
-            STAMP(1);
-            if ((q0 + 32 > len) || (CAUSAL && q0 < wk_min + 31) || wave_has_pad_keys ||
-                (q_in_b && wk_min < br.b && wk_min + 31 >= br.a)) {      // wave-uniform
-                const bool lane_off = !k_valid || (q_in_b && key_hidden);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ql = q0 + acc_row(r, h);
-                    if (ql >= len || (CAUSAL && kl > ql) || lane_off) sa[r] = -INFINITY;      // -> P = 0
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {      // registers 4g..4g+3 hold query rows 8g + 4h + (0..3): one 16-byte read each
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_t + 32 * sub + 8 * g + 4 * h);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dlt_t + 32 * sub + 8 * g + 4 * h);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 4 * g + j;
-                    const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], sc, -l4[j]));
-                    sa[r] = pr;                          // P
-                    dpa[r] = pr * (dpa[r] - d4[j]);      // dZ
-                }
-            }
-            STAMP(2);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const s16x8 pb = acc_to_frag(sa, ks);
-                const s16x8 zb = acc_to_frag(dpa, ks);
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    dvacc[dt] = mfma32(frag_cols<D, SLOW_TR>(dot, 32 * sub + 16 * ks, 32 * dt, lane), pb, dvacc[dt]);
-                    dkacc[dt] = mfma32(frag_cols<D, SLOW_TR>(qt, 32 * sub + 16 * ks, 32 * dt, lane), zb, dkacc[dt]);
-                }
-            }
-        }
-#ifdef HALVA_STAMP
-        asm volatile("" : "+v"(dkacc[0][15]), "+v"(dvacc[DT - 1][15]));
-#endif
-        STAMP(3);
-        if (it + 1 < ntiles) {
-            qst.store(q_lds + ((it + 1) & 1) * TILE_BYTES);
-            dst.store(do_lds + ((it + 1) & 1) * TILE_BYTES);
-            store_stats((it + 1) & 1);
-        }
-        STAMP(4);
-        __syncthreads();
-    }
-#ifdef HALVA_STAMP
-    if (p.dbg && lane == 0 && kb == 0 && s == 0 && hd < 4) {
-        for (int i = 0; i < 6; ++i) p.dbg[(hd * 4 + wave) * 8 + i] = stamp_acc[i];
-        p.dbg[(hd * 4 + wave) * 8 + 6] = ntiles;
-    }
-#endif
-    if (k_in_T) {
-        store_rows_T<D>(dkrow, dkacc, k_valid ? p.scale : 0.f, true, lane);
-        store_rows_T<D>(dvrow, dvacc, k_valid ? 1.f : 0.f, true, lane);
-    }
-}
-
-template <int D, bool CAUSAL, bool SLOW_TR>
-__global__ __launch_bounds__(256, 1) void sdpa_bwd_dkv_kernel(const SdpaParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int s, hd, b;
-    if (CAUSAL) {      // key block b is visited by (nblk - b) query blocks: pair b with nblk-1-b
-        map_block(blockIdx.x, (p.nblk + 1) / 2, p.H, p.npairs, false, s, hd, b);
-        sdpa_bwd_dkv_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, b);
-        if (b != p.nblk - 1 - b) sdpa_bwd_dkv_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, p.nblk - 1 - b);
-    } else {
-        map_block(blockIdx.x, p.nblk, p.H, p.npairs, false, s, hd, b);
-        sdpa_bwd_dkv_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, b);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// backward, part 2, two-role form.  The one-wave-per-SIMD kernel above keeps K, V, dK and dV of its 32 keys in 362 registers.
-// Here the two waves of a SIMD split that state: wave w (0..3, "V side") owns K fragments and dV of key strip w, wave w+4
+// The two waves of a SIMD split that state: wave w (0..3, "V side") owns K fragments and dV of key strip w, wave w+4
 // ("K side") owns V fragments and dK of the SAME strip, so both fit the 256-register budget of two waves per SIMD and one's
 // MFMAs run beside the other's vector work.  Per 32-row sub-tile:
 //   V side:  S = Q K^T  ->  P = exp2(S*sc - lse) (masks applied here)  ->  P to LDS (bf16, accumulator layout)  ->  dV^T += dO^T P
 //   K side:  dP = dO V^T  ->  P from LDS  ->  dZ = P o (dP - delta)  ->  dK^T += Q^T dZ
+// With a dS workspace (SdpaParams::ds_ws) the K side also stores dZ = dS - which it holds as packed bf16 anyway, as the B operand of
+// dK^T += Q^T dZ - for the dQ kernel that follows (sdpa_bwd_dq2): four 1-KiB stores per step and wave, each lane's 16 bytes next to its
+// neighbour's.  dS is then formed ONCE in the whole backward (5 matrix products per (query, key) tile pair instead of 7).
 // The K side runs one staged step behind the V side, so the workgroup barrier of the step (needed for the Q/dO ring anyway) is the
 // only synchronisation; the Q/dO ring has 3 slots (steps t-1, t and the one being fetched), P has 2 (by step parity).
 // ---------------------------------------------------------------------------------------------------
@@ -1134,6 +930,9 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
             const char* cols_tile = ROLE ? qt : dot;       // dV^T += dO^T P  |  dK^T += Q^T dZ
             const bool q_in_b = qt0 >= br.b;               // br.b and qt0 are multiples of 64: uniform over the step
             const bool hidden = q_in_b && wk_min >= br.a && wk_min + 31 < br.b;
+            // this (key block, query step, strip)'s 4 KiB of the dS workspace
+            char* ds_step = (ROLE && p.ds_ws) ? p.ds_ws + ((((int64_t)s * p.H + hd) * p.ds_nkb + kb) * p.ds_nt + qt0 / BQ) * 16384 + strip * 4096
+                                              : nullptr;
             // Both sub-tiles are always computed; a step that is not whole and unmasked (sequence tail, causal diagonal, pad keys, the
             // rows of branch B meeting keys of branch A) turns the affected scores into -inf on the V side, which makes P - and with
             // it dZ on the K side - exactly zero there.  A strip entirely hidden from this step's rows skips the step.
@@ -1203,6 +1002,9 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
                     *reinterpret_cast<u32x4*>(pt) = w0[0];
                     *reinterpret_cast<u32x4*>(pt + 16) = w0[1];
                     if (!interior) mask_scores(x1, qt0 + 32);
+                } else if (ds_step) {      // nontemporal: written once, read once by another kernel - keep Q / dO / K / V in L2
+                    __builtin_nontemporal_store(w0[0], reinterpret_cast<u32x4*>(ds_step + lane * 16));
+                    __builtin_nontemporal_store(w0[1], reinterpret_cast<u32x4*>(ds_step + 1024 + lane * 16));
                 }
                 STAMP(2);
                 SLOT();
@@ -1221,6 +1023,9 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
                 if (!ROLE) {
                     *reinterpret_cast<u32x4*>(pt + 2048) = w1[0];
                     *reinterpret_cast<u32x4*>(pt + 2048 + 16) = w1[1];
+                } else if (ds_step) {
+                    __builtin_nontemporal_store(w1[0], reinterpret_cast<u32x4*>(ds_step + 2048 + lane * 16));
+                    __builtin_nontemporal_store(w1[1], reinterpret_cast<u32x4*>(ds_step + 3072 + lane * 16));
                 }
                 // ---- block 4: second product of sub-tile 1
 #pragma unroll
@@ -1233,11 +1038,11 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
 #endif
         STAMP(3);
         if (t + 1 < ntiles) store_stats(slot_next);
-        stage_tile_dma_wait();
+        if (dma_wave) stage_tile_dma_wait();      // (the K side has only its dS stores in flight: nothing of this step waits for them)
         STAMP(4);
         slot = (slot == 2) ? 0 : slot + 1;
         slot_next = (slot_next == 2) ? 0 : slot_next + 1;
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // not __syncthreads(): its fence would drain the dS stores
     }
 #ifdef HALVA_STAMP
     if (p.dbg && lane == 0 && kb == 0 && s == 0 && hd < 4) {
@@ -1271,6 +1076,172 @@ __global__ __launch_bounds__(512) void sdpa_bwd_dkv2_kernel(const SdpaParams p) 
     else sdpa_bwd_dkv2_role<D, CAUSAL, SLOW_TR, 1>(p, smem, wave - 4);      // (raising these waves' s_setprio changes nothing)
 }
 
+// ===================================================================================================
+// backward with a dS workspace: delta / zero-fill pass, then dK/dV (+ dS store), then dQ = dS K
+// ===================================================================================================
+// delta[s, h, t] = sum_d dO o O for every valid query row (both later kernels read it), and zeros into dq of the PADDED rows (the dQ
+// kernel below walks a sequence in its own coordinates and only writes its valid rows).  One wave per (row, 4 heads); HBM-bound.
+template <int D>
+__global__ __launch_bounds__(256) void sdpa_bwd_delta_kernel(const SdpaParams p, int S) {
+    constexpr int HPW = 512 / D;                       // heads per wave pass: 64 lanes x 8 elements
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)S * p.T) return;
+    const int s = (int)(row / p.T), t = (int)(row % p.T);
+    const int start = p.seq_start ? p.seq_start[s] : 0;
+    const int len = p.seq_len ? p.seq_len[s] : p.T;
+    const bool valid = t >= start && t < start + len;
+    const int sub = lane / (D / 8), e = (lane % (D / 8)) * 8;      // head within the pass, first element
+    for (int h0 = 0; h0 < p.H; h0 += HPW) {
+        const int hd = h0 + sub;
+        if (hd >= p.H) continue;
+        if (!valid) {
+            *reinterpret_cast<u32x4*>(p.dq + row * p.ld_qkv + hd * D + e) = u32x4{0u, 0u, 0u, 0u};
+            continue;
+        }
+        const u32x4 ov = *reinterpret_cast<const u32x4*>(p.o_in + row * p.ld_o + hd * D + e);
+        const u32x4 dv = *reinterpret_cast<const u32x4*>(p.d_o + row * p.ld_do + hd * D + e);
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc += bf16_lo(ov[i]) * bf16_lo(dv[i]) + bf16_hi(ov[i]) * bf16_hi(dv[i]);
+#pragma unroll
+        for (int o = D / 16; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane % (D / 8) == 0) p.delta[((int64_t)s * p.H + hd) * p.T + t] = acc;
+    }
+}
+
+// dQ = scale * dS K with dS read back from the workspace the dK/dV kernel filled.  A workgroup takes 256 query rows of one (sequence,
+// head) in SEQUENCE coordinates (row 0 = seq_start: the grid of query steps the producer used), a wave 32 of them = one 32-row half of
+// a producer step; per 64-key tile (GLOBAL key coordinates = the producer's 128-key blocks) a wave multiplies
+//     dQ^T[128 x 32] += K^T[128 x 64] dS^T[64 x 32]          (16 MFMAs: A = K^T by transposed reads of the shared K tile,
+//                                                             B = dS^T by transposed reads of the wave's own 4 KiB of dS)
+// The producer's layout is, per (key block, step, 32-key strip, 32-row half, register half j): 64 lanes x 16 bytes, lane (key n, h')
+// holding the query rows 16 j + 8 g + 4 h' + (0..3), g = 0, 1: the 8-byte unit (one key, four consecutive queries) is exactly what
+// ds_read_b64_tr_b16 gathers from, so the image is copied to LDS byte for byte (LDS-DMA) and transposed by the read.
+// HBM-bound: 2 bytes per (query, key) pair, the same pairs the producer wrote.
+__device__ __forceinline__ int ds_piece_off(int key, int qgroup) {      // byte offset of (key 0..31, queries 4 G .. 4 G + 3) in a strip's 2 KiB
+    return 1024 * (qgroup >> 2) + 16 * (key + 32 * (qgroup & 1)) + 8 * ((qgroup >> 1) & 1);
+}
+template <int D, bool SLOW_TR>
+__device__ __forceinline__ void sdpa_bwd_dq2_block(const SdpaParams& p, char* smem, int s, int hd, int qb, int wave, int lane) {
+    constexpr int NW = 8, BN = 64, DT = D / 32, BM = 32 * NW, RING = 3;
+    constexpr int TILE_BYTES = BN * D * 2;
+    char* k_lds = smem;                                            // [RING][BN][D]
+    char* ds_lds = smem + RING * TILE_BYTES + wave * (RING * 4096);  // per wave: [RING][2 strips][2 KiB]
+    const int h = lane >> 5;
+    const int start = p.seq_start ? p.seq_start[s] : 0;
+    const int len = p.seq_len ? p.seq_len[s] : p.T;
+    const int64_t seq_row0 = (int64_t)s * p.T;
+    const int lq0 = qb * BM;                             // first local row of the block
+    if (lq0 >= len) return;                              // workgroup-uniform
+    const int wr0 = lq0 + 32 * wave;                     // this wave's first local row
+    const int lq = wr0 + (lane & 31);
+    const bool q_valid = lq < len;
+    const bool wave_live = wr0 < len;
+    const Branch br = load_branch(p, s);
+    const bool wave_in_b = wr0 >= br.b;
+    // global key tiles that hold a key some row of the block may see: local key index kv0g - start <= last row of the block
+    const int first_tile = max(0, start) / BN;
+    const int last_key_local = min(len, lq0 + BM) - 1;                 // causal: keys <= row
+    const int ntile_end = (start + last_key_local) / BN + 1;           // exclusive, global tile index
+    f32x16 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+    const bf16_t* kp = p.k + hd * D;
+    const int64_t krow0 = seq_row0 + start;
+    const int step = wr0 / 64, sub = (wr0 / 32) & 1;
+    const char* ds_pair = p.ds_ws + ((int64_t)s * p.H + hd) * p.ds_nkb * p.ds_nt * 16384;
+    const unsigned ds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ds_lds;
+    // a tile is skipped by this wave when none of its rows sees any of its keys (tiles are walked upwards: once skipped, always skipped);
+    // a 32-key strip when the branch mask hides it wholly (the producer then wrote nothing for it: its bytes are fetched but not used)
+    auto tile_live = [&](int kt) { return wave_live && (kt * BN - start) <= wr0 + 31; };
+    auto strip_hidden = [&](int kt, int si) {
+        const int k0 = kt * BN + 32 * si - start;
+        return wave_in_b && k0 >= br.a && k0 + 31 < br.b;
+    };
+    // requests of one tile by this wave: its 2 chunks of the shared K tile, and - while the tile is live for it - its own 4 KiB of dS
+    auto stage = [&](int kt, int slot) {
+        stage_tile_dma<D, NW>(k_lds + slot * TILE_BYTES, kp, p.ld_qkv, krow0, kt * BN - start, len, wave, lane);
+        if (tile_live(kt)) {
+            const char* src = ds_pair + ((int64_t)(kt >> 1) * p.ds_nt + step) * 16384 + 2 * (kt & 1) * 4096 + sub * 2048;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                 // strip c >> 1, register half c & 1
+                const unsigned dst = ds_dst + slot * 4096 + c * 1024;
+                const unsigned voff = lane * 16;
+                const char* rows = src + (c >> 1) * 4096 + (c & 1) * 1024;
+                unsigned keep;
+                // nt: these bytes are read once, by this CU only - they must not evict the K tiles the XCD's workgroups share in L2
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rows) : "memory");
+            }
+        }
+    };
+    // per-lane byte offsets of the transposed reads of dS^T (see frag_cols for the lane roles): key 8 jj + 4 hb + q4, query group 4 (g & 1) + pp
+    const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3, hb = g >> 1;
+    const int ds_rd0 = ds_piece_off(4 * hb + q4, 4 * (g & 1) + pp);           // jj = 0; jj = 1 adds 8 keys = 128 bytes
+    // TWO tiles in flight (HBM-bound kernel: the queue must not run dry while a tile is multiplied): ring of three slots, counted waits
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the previous row block's readers are done
+    stage(first_tile, 0);
+    if (first_tile + 1 < ntile_end) stage(first_tile + 1, 1);
+#pragma unroll 1
+    for (int kt = first_tile; kt < ntile_end; ++kt) {
+        const int slot = (kt - first_tile) % RING;
+        // tile kt has landed: everything but the requests of tile kt + 1 (2 pieces, 6 while that tile is live for this wave)
+        if (kt + 1 < ntile_end) {
+            if (tile_live(kt + 1)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // ... for every wave; and tile kt - 1 has been read by all
+        if (kt + 2 < ntile_end) stage(kt + 2, (slot + 2) % RING);             // into the slot of tile kt - 1
+        if (tile_live(kt)) {
+            const char* ktile = k_lds + slot * TILE_BYTES;
+            const char* dst_t = ds_lds + slot * 4096;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {               // 16 keys each: strip ks >> 1, half ks & 1
+                if (strip_hidden(kt, ks >> 1)) continue;
+                s16x8 zb;
+                if (SLOW_TR) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int key = 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3), qq = lane & 31;
+                        zb[j] = *reinterpret_cast<const short*>(dst_t + (ks >> 1) * 2048 + ds_piece_off(key, qq >> 2) + (qq & 3) * 2);
+                    }
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const char* a = dst_t + (ks >> 1) * 2048 + ds_rd0 + 16 * (16 * (ks & 1) + 8 * jj);
+                        const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)a);
+                        zb[4 * jj + 0] = t[0];
+                        zb[4 * jj + 1] = t[1];
+                        zb[4 * jj + 2] = t[2];
+                        zb[4 * jj + 3] = t[3];
+                    }
+                }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) acc[dt] = mfma32(frag_cols<D, SLOW_TR>(ktile, 16 * ks, 32 * dt, lane), zb, acc[dt]);
+            }
+        }
+    }
+    if (q_valid) store_rows_T<D>(p.dq + (seq_row0 + start + lq) * p.ld_qkv + hd * D, acc, p.scale, true, lane);
+}
+
+template <int D, bool SLOW_TR>
+__global__ __launch_bounds__(512) void sdpa_bwd_dq2_kernel(const SdpaParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int s, hd, b;
+    map_block(blockIdx.x, (p.nblk + 1) / 2, p.H, p.npairs, false, s, hd, b);
+    const int npass = (b != p.nblk - 1 - b) ? 2 : 1;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) sdpa_bwd_dq2_block<D, SLOW_TR>(p, smem, s, hd, pass ? b : p.nblk - 1 - b, wave, lane);
+}
+
+// HALVA_SDPA_SLOW_TR=1 (tests): scalar transposed reads instead of ds_read_b64_tr_b16.  Read on every call - a test flips it inside
+// one process - but it is a plain getenv, no allocation; everything else launch-related is cached per kernel below.
 bool slow_tr_requested() {
     const char* e = getenv("HALVA_SDPA_SLOW_TR");
     return e && e[0] == '1';
@@ -1282,7 +1253,11 @@ int launch_one(KernelT kern, SdpaParams p, bool causal, int rows_per_block, int 
     p.nblk = (p.T + rows_per_block - 1) / rows_per_block;
     p.npairs = S * p.H;
     const int wg_per_pair = causal ? (p.nblk + 1) / 2 : p.nblk;
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static size_t lds_set = 0;      // one static per template instantiation = per kernel: the attribute is set once (and again only to grow)
+    if (lds > lds_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set = lds;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)(wg_per_pair * p.npairs)), dim3(threads), lds, st, p);
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) {
@@ -1310,19 +1285,23 @@ int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st) {
     p.dbg = halva_dbg_buffer();
 #endif
     const size_t lds_dq = 4 * 64 * D * 2;
-    const size_t lds_dkv = 4 * DKV_BQ * D * 2 + 4 * DKV_BQ * sizeof(float);
+    const size_t lds_dkv = 6 * 64 * D * 2 + 6 * 64 * sizeof(float) + 2 * 4 * 2 * 2048;
     const bool slow = slow_tr_requested();
-    // HALVA_DKV2=0 selects the older one-wave-per-SIMD dK/dV kernel (kept for A/B runs and the slow-transpose debug path)
+    if (p.ds_ws != nullptr && D == 128) {      // dS formed once: delta (+ zero-fill of padded dq rows) -> dK/dV (+ dS store) -> dQ = dS K
+        const int64_t rows = (int64_t)S * p.T;
+        hipLaunchKernelGGL((sdpa_bwd_delta_kernel<D>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, S);
+        int rc2 = slow ? launch_one(sdpa_bwd_dkv2_kernel<D, CAUSAL, true>, p, CAUSAL, 128, 512, lds_dkv, S, st, "sdpa_bwd_dkv2")
+                       : launch_one(sdpa_bwd_dkv2_kernel<D, CAUSAL, false>, p, CAUSAL, 128, 512, lds_dkv, S, st, "sdpa_bwd_dkv2");
+        if (rc2 != HALVA_OK) return rc2;
+        const size_t lds_dq2 = 3 * 64 * D * 2 + 8 * 3 * 4096;
+        return slow ? launch_one(sdpa_bwd_dq2_kernel<D, true>, p, true, 256, 512, lds_dq2, S, st, "sdpa_bwd_dq2")
+                    : launch_one(sdpa_bwd_dq2_kernel<D, false>, p, true, 256, 512, lds_dq2, S, st, "sdpa_bwd_dq2");
+    }
     const int rc = slow ? launch_one(sdpa_bwd_dq_kernel<D, CAUSAL, true, 8>, p, CAUSAL, 256, 512, lds_dq, S, st, "sdpa_bwd_dq")
                         : launch_one(sdpa_bwd_dq_kernel<D, CAUSAL, false, 8>, p, CAUSAL, 256, 512, lds_dq, S, st, "sdpa_bwd_dq");
     if (rc != HALVA_OK) return rc;
-    static const bool two_role = !(getenv("HALVA_DKV2") && atoi(getenv("HALVA_DKV2")) == 0);
-    if (two_role && !slow) {
-        const size_t lds2 = 6 * 64 * D * 2 + 6 * 64 * sizeof(float) + 2 * 4 * 2 * 2048;
-        return launch_one(sdpa_bwd_dkv2_kernel<D, CAUSAL, false>, p, CAUSAL, 128, 512, lds2, S, st, "sdpa_bwd_dkv2");
-    }
-    return slow ? launch_one(sdpa_bwd_dkv_kernel<D, CAUSAL, true>, p, CAUSAL, 128, 256, lds_dkv, S, st, "sdpa_bwd_dkv")
-                : launch_one(sdpa_bwd_dkv_kernel<D, CAUSAL, false>, p, CAUSAL, 128, 256, lds_dkv, S, st, "sdpa_bwd_dkv");
+    return slow ? launch_one(sdpa_bwd_dkv2_kernel<D, CAUSAL, true>, p, CAUSAL, 128, 512, lds_dkv, S, st, "sdpa_bwd_dkv2")
+                : launch_one(sdpa_bwd_dkv2_kernel<D, CAUSAL, false>, p, CAUSAL, 128, 512, lds_dkv, S, st, "sdpa_bwd_dkv2");
 }
 
 }  // namespace
@@ -1379,9 +1358,25 @@ extern "C" int halva_sdpa_causal_bwd_ld(const void* qkv, const void* out, int64_
                                  scale, stream);
 }
 
+extern "C" int64_t halva_sdpa_bwd_ws_bytes(int S, int T, int H, int D) {
+    if (D != 128) return 0;                                      // the dS path is the head_dim-128 instantiation; others use the 3-product dQ kernel
+    return (int64_t)S * H * ((T + 127) / 128) * ((T + 63) / 64) * 16384;
+}
+
 extern "C" int halva_sdpa_branch_bwd(const void* qkv, const void* out, int64_t ld_out, const void* dout, int64_t ld_dout,
                                      const float* lse, void* dqkv, float* delta_ws, const int32_t* seq_start, const int32_t* seq_len,
                                      const int32_t* br_a, const int32_t* br_b, int S, int T, int H, int D, float scale, void* stream) {
+    return halva_sdpa_branch_bwd_ws(qkv, out, ld_out, dout, ld_dout, lse, dqkv, delta_ws, nullptr, 0, seq_start, seq_len, br_a, br_b, S, T, H, D,
+                                    scale, stream);
+}
+
+extern "C" int halva_sdpa_branch_bwd_ws(const void* qkv, const void* out, int64_t ld_out, const void* dout, int64_t ld_dout,
+                                        const float* lse, void* dqkv, float* delta_ws, void* ds_ws, int64_t ds_ws_bytes,
+                                        const int32_t* seq_start, const int32_t* seq_len, const int32_t* br_a, const int32_t* br_b, int S,
+                                        int T, int H, int D, float scale, void* stream) {
+    HALVA_CHECK_ARG(ds_ws == nullptr || ds_ws_bytes >= halva_sdpa_bwd_ws_bytes(S, T, H, D),
+                    "sdpa_branch_bwd_ws: workspace of %lld bytes, %lld needed", (long long)ds_ws_bytes,
+                    (long long)halva_sdpa_bwd_ws_bytes(S, T, H, D));
     HALVA_CHECK_ARG((br_a == nullptr) == (br_b == nullptr), "sdpa_branch_bwd: br_a and br_b go together");
     HALVA_CHECK_ARG(ld_out >= (int64_t)H * D && ld_out % 8 == 0 && ld_dout >= (int64_t)H * D && ld_dout % 8 == 0,
                     "sdpa_causal_bwd: bad row strides %lld / %lld", (long long)ld_out, (long long)ld_dout);   // reserved for an atomics-based dQ variant; the shipped dQ kernel needs no scratch
@@ -1410,6 +1405,9 @@ extern "C" int halva_sdpa_branch_bwd(const void* qkv, const void* out, int64_t l
     p.ld_do = ld_dout;
     p.T = T;
     p.H = H;
+    p.ds_ws = D == 128 ? (char*)ds_ws : nullptr;
+    p.ds_nkb = (T + 127) / 128;
+    p.ds_nt = (T + 63) / 64;
     p.scale = scale > 0.f ? scale : 1.f / sqrtf((float)D);
     return D == 128 ? launch_bwd<128, true>(p, S, (hipStream_t)stream) : launch_bwd<64, true>(p, S, (hipStream_t)stream);
 }

@@ -27,6 +27,7 @@ SIGNATURES = {
     "halva_sdpa_causal_bwd_ld": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "halva_sdpa_branch_fwd": [_P, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "halva_sdpa_branch_bwd": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "halva_sdpa_branch_bwd_ws": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "halva_rope_qk": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
     "halva_swiglu_fwd": [_P, _P, _L, _I, _P],
     "halva_swiglu_bwd": [_P, _P, _P, _L, _I, _P],
@@ -79,6 +80,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
         fn.restype = c_int
         fn.argtypes = args
+    lib.halva_sdpa_bwd_ws_bytes.restype = c_int64
+    lib.halva_sdpa_bwd_ws_bytes.argtypes = [c_int, c_int, c_int, c_int]
     _lib = lib
     return lib
 

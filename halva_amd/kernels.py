@@ -4,6 +4,7 @@ Each Function names the reference call it stands in for; numerics follow the ven
 (reference llava/model/language_model/modelling_llama.py) - see include/halva_hip.h for the per-kernel contract.
 """
 import math
+import os
 
 import torch
 
@@ -151,6 +152,22 @@ class _RopeQK(torch.autograd.Function):
 
 
 sdpa_bwd_probe = None      # a list: every causal-SDPA backward launch appends (start event, end event, S, T, H, D, branched)
+# dS workspace of the attention backward (include/halva_hip.h:halva_sdpa_branch_bwd_ws): one buffer per device, grown on demand and
+# reused by every layer (it carries nothing between calls).  HALVA_SDPA_DS_WS=0 runs the split backward without it.
+SDPA_DS_WS = os.environ.get("HALVA_SDPA_DS_WS", "1") != "0"
+_sdpa_ws = {}
+
+
+def _sdpa_workspace(dev, S, T, H, D):
+    if not SDPA_DS_WS:
+        return None, 0
+    need = int(hip.load().halva_sdpa_bwd_ws_bytes(S, T, H, D))
+    if need == 0:
+        return None, 0
+    ws = _sdpa_ws.get(dev)
+    if ws is None or ws.numel() < need:
+        _sdpa_ws[dev] = ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    return ws, need
 
 
 class _SdpaCausal(torch.autograd.Function):
@@ -192,8 +209,9 @@ class _SdpaCausal(torch.autograd.Function):
         if probe is not None:          # bench.py: HIP events around the launch, on the stream it goes to
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        call("halva_sdpa_branch_bwd", ptr(qkv), ptr(out), width, ptr(dout), dout.shape[-1], ptr(lse), ptr(dqkv), ptr(delta),
-             ptr(seq_start), ptr(seq_len), ptr(br_a), ptr(br_b), S, T, H, D, 0.0, stream_ptr())
+        ws, ws_bytes = _sdpa_workspace(qkv.device, S, T, H, D)
+        call("halva_sdpa_branch_bwd_ws", ptr(qkv), ptr(out), width, ptr(dout), dout.shape[-1], ptr(lse), ptr(dqkv), ptr(delta),
+             ptr(ws), ws_bytes, ptr(seq_start), ptr(seq_len), ptr(br_a), ptr(br_b), S, T, H, D, 0.0, stream_ptr())
         if probe is not None:
             e1.record()
             probe.append((e0, e1, S, T, H, D, ctx.branch is not None))

@@ -73,8 +73,9 @@ int halva_swiglu_bwd_ld(const void* dout, int64_t lddo, const void* gu, void* dg
  * together with unpad_input / pad_input (llava/train/llama_flash_attn_monkey_patch.py:71-91).
  * qkv: [S, T, 3, H, D] packed (RoPE already applied); out: [S, T, H, D]; lse: [S, H, T] f32 (natural log).
  * Padded query rows get zeros (pad_input semantics).  scale = 1/sqrt(D) when <= 0.
- * bwd: dqkv [S, T, 3, H, D] bf16 is fully written (zeros on padded rows); delta_ws: [S, H, T] f32 and
- * dq_ws: [S, T, H, D] f32 scratch owned by the caller (dq_ws must be zero-filled by the caller). */
+ * bwd: dqkv [S, T, 3, H, D] bf16 is fully written (zeros on padded rows); delta_ws: [S, H, T] f32 scratch owned by the
+ * caller (written by the dQ launch, read by the dK/dV launch).  dq_ws is IGNORED (may be NULL): the argument survives from an
+ * atomics-based dQ design that was never shipped; dQ has its own kernel and needs no scratch. */
 int halva_sdpa_causal_fwd(const void* qkv, void* out, float* lse, const int32_t* seq_start, const int32_t* seq_len,
                           int S, int T, int H, int D, float scale, void* stream);
 int halva_sdpa_causal_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
@@ -100,6 +101,17 @@ int halva_sdpa_branch_fwd(const void* qkv, void* out, int64_t ld_out, float* lse
 int halva_sdpa_branch_bwd(const void* qkv, const void* out, int64_t ld_out, const void* dout, int64_t ld_dout, const float* lse,
                           void* dqkv, float* delta_ws, const int32_t* seq_start, const int32_t* seq_len, const int32_t* br_a,
                           const int32_t* br_b, int S, int T, int H, int D, float scale, void* stream);
+/* The same backward with a caller-owned workspace for dS = P o (dP - delta) (bf16, halva_sdpa_bwd_ws_bytes(S, T, H, D) bytes; 0 for
+ * head dims the workspace path does not serve).  With it the backward forms dS once - three launches: delta (+ zeros into dq of padded
+ * rows), dK/dV (which stores dS in its register layout), dQ = scale * dS K (which reads it back, HBM-bound) - five matrix products per
+ * (query, key) tile pair instead of the seven of the split backward above (S and dP are otherwise formed in both kernels).  Same
+ * results to bf16 rounding of dS (which the split backward applies as well before its dQ/dK products); bitwise reproducible.
+ * ds_ws == NULL: identical to halva_sdpa_branch_bwd.  The workspace holds no state between calls. */
+int64_t halva_sdpa_bwd_ws_bytes(int S, int T, int H, int D);
+int halva_sdpa_branch_bwd_ws(const void* qkv, const void* out, int64_t ld_out, const void* dout, int64_t ld_dout, const float* lse,
+                             void* dqkv, float* delta_ws, void* ds_ws, int64_t ds_ws_bytes, const int32_t* seq_start,
+                             const int32_t* seq_len, const int32_t* br_a, const int32_t* br_b, int S, int T, int H, int D, float scale,
+                             void* stream);
 /* ---- non-causal self-attention, bf16, head_dim 64, forward only (the CLIP tower runs under no_grad:
  * llava/model/multimodal_encoder/clip_encoder.py:37-49; replaces HF CLIPAttention's softmax(QK^T*scale)V).
  * qkv: [N, S, 3, H, D] packed; out [N, S, H, D]. */
