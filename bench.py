@@ -106,15 +106,15 @@ def sdpa_roofline(dev, S=8, T=2048, H=32, D=128, iters=10):
     fwd_flop = 2.0 * T * T * D * H * S
     bwd_flop = 2.5 * fwd_flop
     traffic = None          # HBM bytes per launch from the committed PMC passes of the same kernels at the same shape
-    pmc = os.path.join(ROOT, "profiles", "r01_sdpa_pmc.json")
+    pmc = os.path.join(ROOT, "profiles", "r02_sdpa_pmc.json")
     if os.path.exists(pmc):
         with open(pmc) as f:
             j = json.load(f)
         if j.get("shape") == {"S": S, "T": T, "H": H, "D": D}:
             traffic = j.get("sdpa_causal_bwd_hbm_bytes_per_launch")
-    return {"bound": "mfma", "kernel": "sdpa_causal_bwd (dQ + dK/dV launches, D=128)", "achieved": round(bwd_flop / tb / 1e12, 2),
+    return {"bound": "mfma", "kernel": "sdpa_causal_bwd (one C-ABI call = delta + dK/dV(+dS store) + dQ=dS.K launches, D=128)", "achieved": round(bwd_flop / tb / 1e12, 2),
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(bwd_flop / tb / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-            "traffic_source": "profiles/r01_sdpa_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bytes = (2*FETCH+WRITE)*1024)",
+            "traffic_source": "profiles/r02_sdpa_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bytes = (2*FETCH+WRITE)*1024)",
             "launch_ms": round(tb * 1e3, 3), "shape": {"S": S, "T": T, "H": H, "D": D},
             "fwd": {"achieved": round(fwd_flop / tf / 1e12, 2), "frac": round(fwd_flop / tf / 1e12 / PEAK_BF16_TFLOPS, 4),
                     "launch_ms": round(tf * 1e3, 3)}}
@@ -149,12 +149,12 @@ def in_step_roofline(probe, layout, micro):
         k[1] += t
     out = dict(micro)
     step_traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_sdpa_pmc.json")
+    pmc = os.path.join(ROOT, "profiles", "r02_sdpa_pmc.json")
     if os.path.exists(pmc):
         with open(pmc) as f:
             step_traffic = json.load(f).get("in_step", {}).get("sdpa_causal_bwd_hbm_bytes_per_launch")
     out.update({"traffic": step_traffic,
-                "traffic_source": "profiles/r01_sdpa_pmc.json:in_step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --steps 1`, "
+                "traffic_source": "profiles/r02_sdpa_pmc.json:in_step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --steps 1`, "
                                   "average over the step's sdpa_bwd_dq + sdpa_bwd_dkv2 dispatches, bytes = (2*FETCH+WRITE)*1024)",
                 "achieved": round(flop / ms / 1e9, 2), "frac": round(flop / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
                 "launch_ms": round(ms / len(probe), 3), "launches": len(probe),
@@ -237,11 +237,11 @@ def spawn_ranks(n, argv):
     s.close()
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % max(ndev, 1) if share else r), WORLD_SIZE=str(n),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         if share:
-            env["HALVA_DIST_BACKEND"] = "gloo"
+            env["HALVA_SHARE_GPU"] = "1"
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
     rc = 0
     live = list(procs)

@@ -23,6 +23,15 @@ import torch.distributed as dist
 BUCKET_ELEMS = 64 * 1024 * 1024        # 256 MB of fp32 per collective
 
 
+def local_device_index():
+    """GPU of this rank: LOCAL_RANK, or LOCAL_RANK modulo the visible devices with HALVA_SHARE_GPU=1 (several ranks on one GPU:
+    the 1-GPU test boxes; implies the gloo backend - RCCL cannot put two ranks on one device)."""
+    local = max(0, int(os.environ.get("LOCAL_RANK", "0")))
+    if os.environ.get("HALVA_SHARE_GPU") == "1":
+        return local % max(1, torch.cuda.device_count())
+    return local
+
+
 class DistContext:
     def __init__(self, rank=0, world=1, local_rank=0, group=None):
         self.rank, self.world, self.local_rank, self.group = rank, world, local_rank, group
@@ -34,11 +43,11 @@ class DistContext:
         for several ranks sharing one GPU (HALVA_DIST_BACKEND overrides)."""
         world = int(os.environ.get("WORLD_SIZE", "1"))
         rank = int(os.environ.get("RANK", "0"))
-        local = int(os.environ.get("LOCAL_RANK", "0"))
+        local = local_device_index()
         if world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            backend = os.environ.get("HALVA_DIST_BACKEND") or backend
+            backend = os.environ.get("HALVA_DIST_BACKEND") or ("gloo" if os.environ.get("HALVA_SHARE_GPU") == "1" else backend)
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
             if backend == "nccl":
@@ -65,6 +74,20 @@ def _allreduce_sum_async(t, ctx):
         return fin
     h = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=ctx.group, async_op=True)
     return h.wait
+
+
+def broadcast_(t, ctx, src=0):
+    """Every rank ends up with rank `src`'s values of `t` (replica initialisation: what DeepSpeed's engine does for the reference at
+    start-up - randomly initialised LoRA factors must not differ between the replicas)."""
+    if ctx.world == 1:
+        return t
+    if t.is_cuda and _is_gloo(ctx):
+        host = t.detach().cpu()
+        dist.broadcast(host, src=src, group=ctx.group)
+        t.copy_(host)
+    else:
+        dist.broadcast(t, src=src, group=ctx.group)
+    return t
 
 
 def allreduce_mean_(flat, ctx):

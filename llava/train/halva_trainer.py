@@ -222,6 +222,9 @@ class HalvaTrainer:
             return
         a = self.args
         self._flat = dpa.FlatTrainables(dpa.trainable_named_parameters(self.model))
+        if self.dist.world > 1:      # replicas start from rank 0's trainable tensors (the LoRA A factors are random)
+            dp.broadcast_(self._flat.master, self.dist)
+            self._flat.flat.copy_(self._flat.master)
         dpa.bind_model(self._flat, self.model)
         dpa.set_grad_sink(self.model, True)
         self._engine = dpa.DPAEngine(self.model, self.ref_model, self.loss_alpha,

@@ -558,7 +558,8 @@ def setup_llava(model_args, data_args, training_args):
         raise NotImplementedError("4/8-bit loading (bitsandbytes) is not part of the MI355X DPA path; use --bits 16")
     if not training_args.bf16:
         raise NotImplementedError("the MI355X DPA path computes in bf16 (--bf16 True, as src/hallava_7b.sh:48)")
-    dev = torch.device("cuda", max(0, int(os.environ.get("LOCAL_RANK", "0"))))
+    from halva_amd.dp import local_device_index
+    dev = torch.device("cuda", local_device_index())
     model = LlavaLlamaForCausalLM.from_pretrained(model_args.model_name_or_path, cache_dir=training_args.cache_dir, device=dev)
     model.config._name_or_path = model_args.model_name_or_path
     model.config.use_cache = False
@@ -601,6 +602,7 @@ def train(argv=None):
     model_args, data_args, training_args = parse_args_into_dataclasses((ModelArguments, DataArguments, TrainingArguments), argv)
     local_rank = training_args.local_rank if training_args.local_rank >= 0 else int(os.environ.get("LOCAL_RANK", "-1"))
     assert model_args.version in ["v1", "vicuna_v1"], "This code supports v1 and vicuna_v1 conversation template."
+    torch.manual_seed(training_args.seed)      # the adapter's random initialisation follows --seed (and is rank 0's on every replica)
     ref_model_args, ref_data_args, ref_training_args = (copy.deepcopy(x) for x in (model_args, data_args, training_args))
     rank0_print("Loading online model")
     model, tokenizer = setup_llava(model_args, data_args, training_args)

@@ -34,8 +34,10 @@ def _launch(world, out, backend, share_gpu):
     port = _free_port()
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if share_gpu else str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HALVA_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if share_gpu:
+            env["HALVA_SHARE_GPU"] = "1"
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out], env=env))
     codes = []
     for p in procs:
@@ -112,3 +114,50 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_pairs"] == 4 and rec["value"] > 0
     assert rec["grad_allreduce"]["buckets_issued_inside_backward"] >= 1
+
+
+def test_deepspeed_shim_two_ranks_train_like_one_rank_with_accumulation(tmp_path):
+    """`deepspeed --num_gpus 2 train_halva.py ...` (the reference's launch line, src/hallava_7b.sh:30, through bin/deepspeed): two rank
+    processes, each taking every second batch of the sampler (llava/train/halva_trainer.py:261-272), gradients averaged inside the
+    last backward of every step.  One rank with --gradient_accumulation_steps 2 consumes the same batches per optimizer step (the
+    reference's sampler is built for world_size * accumulation = 2 either way), so both runs must end with the same adapter."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import e2e_util
+    paths = e2e_util.build(str(tmp_path))
+    runner = os.path.join(str(tmp_path), "run_train.py")
+    with open(runner, "w") as f:
+        f.write("import sys\nsys.path[:0] = [%r, %r, %r]\n"
+                "import e2e_util, pytest\nfrom _pytest.monkeypatch import MonkeyPatch\n"
+                "paths = dict(vocab_size=%d, data=%r, ref=%r, images=%r, vision=%r)\n"
+                "e2e_util.patch_tokenizer(MonkeyPatch(), paths['vocab_size'], warm_paths=paths)\n"
+                "import llava.train.train_halva as TH\nTH.train(sys.argv[1:])\n"
+                % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden"), paths["vocab_size"], paths["data"], paths["ref"],
+                   paths["images"], paths["vision"]))
+
+    def argv(out, accum):
+        return ("--lora_enable True --lora_r 8 --lora_alpha 16 --mm_projector_lr 0 --loss_alpha 0.4 --model_name_or_path %s --version v1 "
+                "--data_path %s --ref_data_path %s --image_folder %s --vision_tower %s --mm_projector_type mlp2x_gelu "
+                "--mm_vision_select_layer -2 --mm_use_im_start_end False --mm_use_im_patch_token False --image_aspect_ratio pad "
+                "--group_by_modality_length True --bf16 True --output_dir %s --num_train_epochs 2 --per_device_train_batch_size 1 "
+                "--gradient_accumulation_steps %d --learning_rate 1e-3 --warmup_ratio 0.03 --lr_scheduler_type cosine --logging_steps 1 "
+                "--save_strategy no --model_max_length 64" % (paths["ckpt"], paths["data"], paths["ref"], paths["images"], paths["vision"], out,
+                                                               accum)).split()
+    env = dict(os.environ, HALVA_SHARE_GPU="1" if torch.cuda.device_count() < 2 else "0", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out2, out1 = os.path.join(str(tmp_path), "dp2"), os.path.join(str(tmp_path), "dp1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "deepspeed"), "--num_gpus", "2", runner] + argv(out2, 1), env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "deepspeed"), "--num_gpus", "1", runner] + argv(out1, 2), env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    s2, s1 = (json.load(open(os.path.join(o, "trainer_state.json"))) for o in (out2, out1))
+    assert s2["global_step"] == s1["global_step"] == 6                       # 6 samples / (1 per rank x 2 ranks) x 2 epochs
+    l2, l1 = ([x["loss"] for x in st["log_history"] if "loss" in x] for st in (s2, s1))
+    assert max(abs(a - b) for a, b in zip(l2, l1)) < 2e-3, (l2, l1)         # mean over ranks == mean over the accumulated micro-batches
+    a2, a1 = (torch.load(os.path.join(o, "adapter_model.bin")) for o in (out2, out1))
+    assert set(a2) == set(a1)
+    for k in a1:
+        assert float((a2[k].float() - a1[k].float()).norm()) <= 2e-2 * float(a1[k].float().norm()) + 1e-6, k

@@ -82,6 +82,9 @@ def _worker(rank, world, port, out):
     red.finish()
     assert torch.allclose(_Flat.grad, torch.full((100,), 1.5))
     assert dp.max_scalar(float(rank), ctx) == 1.0
+    b = torch.full((5,), float(rank + 7))
+    dp.broadcast_(b, ctx)
+    assert torch.equal(b, torch.full((5,), 7.0))
     # 3. the trainer's loader shards the sampler's global batch list disjointly and completely
     from llava.train.halva_trainer import HalvaTrainer
 

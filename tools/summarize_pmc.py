@@ -2,7 +2,7 @@
 """rocprofv3 --pmc counter_collection.csv files -> per-kernel, per-launch averages of every counter (json on stdout).
 usage: summarize_pmc.py <dir with */*counter_collection.csv> [kernel-name substring ...]"""
 import csv, glob, json, sys
-root, keys = sys.argv[1], sys.argv[2:] or ["sdpa_fwd", "sdpa_bwd_dq", "sdpa_bwd_dkv"]
+root, keys = sys.argv[1], sys.argv[2:] or ["sdpa_fwd", "sdpa_bwd_dq", "sdpa_bwd_dkv", "sdpa_bwd_delta"]
 acc = {}
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     per = {}

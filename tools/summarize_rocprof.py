@@ -6,7 +6,7 @@ rows = list(csv.DictReader(open(src)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 def cat(n):
     for key, lab in (("sdpa_bwd_dkv", "sdpa_bwd_dkv (HIP)"), ("sdpa_bwd_dq", "sdpa_bwd_dq (HIP)"), ("sdpa_fwd_kernel<128", "sdpa_fwd causal D128 (HIP)"),
-                     ("sdpa_fwd_kernel<64", "sdpa_fwd full D64 CLIP (HIP)"), ("sdpa_delta", "sdpa_delta (HIP)")):
+                     ("sdpa_fwd_kernel<64", "sdpa_fwd full D64 CLIP (HIP)"), ("sdpa_bwd_delta", "sdpa_bwd_delta (HIP)")):
         if key in n: return lab
     if "anonymous namespace" in n:
         for k in ("swiglu_bwd", "swiglu_fwd", "rmsnorm_bwd", "rmsnorm_fwd", "rope_qk", "splice_rows", "token_logp_fwd", "token_logp_bwd", "kl_rows",

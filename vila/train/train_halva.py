@@ -240,7 +240,8 @@ def setup_model(model_args, data_args, training_args):
     if getattr(config, "resume_path", None) is not None:
         config.resume_path = name
     prepare_config_for_training(config, model_args, training_args, data_args)
-    dev = torch.device("cuda", max(0, int(os.environ.get("LOCAL_RANK", "0"))))
+    from halva_amd.dp import local_device_index
+    dev = torch.device("cuda", local_device_index())
     model = LlavaLlamaModel(config=config, attn_implementation="flash_attention_2", model_max_length=training_args.model_max_length,
                             cache_dir=training_args.cache_dir, device=dev)
     model.llm.config.use_cache = False
