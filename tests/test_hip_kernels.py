@@ -187,6 +187,49 @@ def test_sdpa_causal_fwd_bwd(T, lens, starts, H, D, slow_tr):
         os.environ["HALVA_SDPA_SLOW_TR"] = "0"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [128, 64])
+def test_sdpa_exponent_reference_moves_when_later_keys_dominate(D):
+    """The forward keeps ONE exponent reference per row (its first tile's maximum) and only moves it when a later score exceeds it
+    by 64 in log2 units - a path ordinary activations never take.  Keys whose scores grow by ~90 then ~135 nats from one 64-key
+    tile to the next force it twice per row; the result must still match the fp32 softmax (and the backward, which recomputes P
+    from the saved log-sum-exp, must agree as well)."""
+    T, H, S = 256, 2, 1
+    g = torch.Generator().manual_seed(11)
+    u = torch.randn(H, D, generator=g)
+    u = u / u.norm(dim=-1, keepdim=True) * math.sqrt(D)                       # |u|^2 = D: score(q=u, k=c*u) = c * sqrt(D)
+    c = torch.tensor([0.1, 3.0, 8.0, 20.0]).repeat_interleave(64) * (11.3 / math.sqrt(D))      # ~1, 34, 90, 226 nats
+    qkv = torch.zeros(S, T, 3, H, D)
+    w = torch.randn(T, H, D, generator=g)                                     # per key: a direction orthogonal to u, as long as u
+    w = w - (w * u[None]).sum(-1, keepdim=True) / D * u[None]                 # (keys that are all parallel would make dq a
+    w = w / w.norm(dim=-1, keepdim=True) * math.sqrt(D)                       #  difference of large equal terms: ill-conditioned in bf16)
+    qkv[0, :, 0] = u[None] + 0.05 * torch.randn(T, H, D, generator=g)
+    qkv[0, :, 1] = c[:, None, None] * (u[None] + w)
+    qkv[0, :, 2] = torch.randn(T, H, D, generator=g)
+    qkv = bf(qkv)
+    dout = bf(torch.randn(S, T, H, D, generator=g))
+    ident_cos = torch.ones(T, D // 2, dtype=torch.bfloat16, device=DEV)
+    ident_sin = torch.zeros(T, D // 2, dtype=torch.bfloat16, device=DEV)
+    qg = qkv.to(DEV).view(S, T, 3 * H * D).clone().requires_grad_(True)
+    ss = torch.zeros(S, dtype=torch.int32, device=DEV)
+    sl = torch.full((S,), T, dtype=torch.int32, device=DEV)
+    out = K().attention(qg * 1, ident_cos, ident_sin, ss, sl, H, D)
+    out.backward(dout.to(DEV).view(S, T, H * D))
+    r = qkv.float().requires_grad_(True)
+    ref = _attn_ref(r, [0], [T])
+    ref.backward(dout.float())
+    o = out.view(S, T, H, D).cpu().float()
+    assert torch.isfinite(o).all()
+    scores = (r[0, :, 0].detach().permute(1, 0, 2) @ r[0, :, 1].detach().permute(1, 2, 0)) / math.sqrt(D)
+    assert float(scores[:, 200, 128:192].max() - scores[:, 200, :64].max()) > 64 * math.log(2)      # the jump really exceeds the threshold
+    assert rel_err(o, ref) < 1e-2, "fwd"
+    assert float((o - ref.detach()).abs().max()) < 3e-2
+    dq = qg.grad.view(S, T, 3, H, D).cpu().float()
+    assert torch.isfinite(dq).all()
+    for i, name in enumerate("dq dk dv".split()):
+        assert rel_err(dq[:, :, i], r.grad[:, :, i]) < 2e-2, name
+
+
 def _branch_ref(qkv, starts, lens, br_a, br_b):
     """fp32 dense-mask reference of the branched attention: causal inside [start, start+len), rows >= br_b do not see rows in
     [br_a, br_b) (local indices); padded rows produce zeros."""
