@@ -247,20 +247,30 @@ struct TileDma {
 // (s_waitcnt vmcnt(0) as the builtin, not asm: the compiler then also knows that nothing of its own is pending afterwards)
 __device__ __forceinline__ void stage_tile_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
-// Write a [D x 32] transposed accumulator (lane = row of the output, registers = columns d) as bf16 rows:
-// out_row[d] for d = 32*dt + 8*g + 4*h + (0..3) -> 8-byte stores.
+// Write a [D x 32] transposed accumulator (lane = row of the output, registers = columns d) as bf16 rows.  A lane holds the columns
+// 32*dt + 8*g + 4*h + (0..3) of its row (h = lane / 32: the two lanes of a row sit 32 apart), i.e. 8-byte pieces: 16 stores per lane,
+// and the store tail of a row block is bound by the NUMBER of store instructions (measured: ~5 600 cycles for a V-side wave of the
+// dK/dV kernel, ~10 000 for the K-side wave that finishes last).  v_permlane32_swap trades the pieces of two neighbouring groups
+// between the two lanes of a row, after which each holds 16 contiguous bytes: 8 stores per lane, same bytes, same addresses.
 template <int D>
 __device__ __forceinline__ void store_rows_T(bf16_t* row_ptr, const f32x16 (&acc)[D / 32], float mul, bool valid, int lane) {
-    if (!valid) return;
+    if (!valid) return;      // (both lanes of a row take the same side: the swap below never pairs an active lane with an inactive one)
     const int h = lane >> 5;
 #pragma unroll
     for (int dt = 0; dt < D / 32; ++dt) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            u32x2 w;
-            w[0] = pack_bf16x2(acc[dt][4 * g + 0] * mul, acc[dt][4 * g + 1] * mul);
-            w[1] = pack_bf16x2(acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
-            *reinterpret_cast<u32x2*>(row_ptr + 32 * dt + 8 * g + 4 * h) = w;
+        for (int gp = 0; gp < 2; ++gp) {
+            unsigned w[2][2];      // [group 2gp, 2gp+1][word]
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int g = 2 * gp + k;
+                w[k][0] = pack_bf16x2(acc[dt][4 * g + 0] * mul, acc[dt][4 * g + 1] * mul);
+                w[k][1] = pack_bf16x2(acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
+            }
+            // upper lanes' group-2gp words <-> lower lanes' group-(2gp+1) words
+            const auto x = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+            const auto y = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+            *reinterpret_cast<u32x4*>(row_ptr + 32 * dt + 16 * gp + 8 * h) = u32x4{x[0], y[0], x[1], y[1]};
         }
     }
 }
@@ -810,7 +820,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void sdpa_bwd_dq_kernel
 // only synchronisation; the Q/dO ring has 3 slots (steps t-1, t and the one being fetched), P has 2 (by step parity).
 // ---------------------------------------------------------------------------------------------------
 template <int D, bool CAUSAL, bool SLOW_TR, int ROLE>
-__device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* smem, int s, int hd, int kb, int strip) {
+__device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* smem, int s, int hd, int kb, int strip, int start, int len,
+                                                    const Branch br) {
     constexpr int BQ = 64, SUB = 2, KS = D / 16, DT = D / 32;
     constexpr int TILE_BYTES = BQ * D * 2;
     char* q_lds = smem;                                    // [3][BQ][D]
@@ -820,8 +831,10 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
     char* p_lds = reinterpret_cast<char*>(dlt_lds + 3 * BQ);            // [2 parity][4 strips][SUB][64 lanes][2][16 B]
 
     const int lane = threadIdx.x & 63, h = lane >> 5;
-    const int start = p.seq_start ? p.seq_start[s] : 0;
-    const int len = p.seq_len ? p.seq_len[s] : p.T;
+#ifdef HALVA_STAMP
+    unsigned long long blk_t[8];
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk_t[0])::"memory");
+#endif
     const int64_t seq_row0 = (int64_t)s * p.T;
     const int gk = kb * 128 + 32 * strip + (lane & 31);
     const int kl = gk - start;
@@ -833,7 +846,6 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
     int q_begin = 0;
     if (CAUSAL) q_begin = max(0, kblk_min) / BQ * BQ;
     const bool block_has_keys = (kblk_min < len) && (kblk_min + 128 > 0);
-    const Branch br = load_branch(p, s);
     const int q_stop = (kblk_min >= br.a && kblk_min + 127 < br.b) ? min(len, br.b) : len;
     const int ntiles = (block_has_keys && q_stop > q_begin) ? (q_stop - q_begin + BQ - 1) / BQ : 0;
     const bool key_hidden = kl >= br.a && kl < br.b;
@@ -847,6 +859,11 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
     s16x8 sf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) sf[ks] = k_valid ? *reinterpret_cast<const s16x8*>(stat + 16 * ks + 8 * h) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef HALVA_STAMP
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk_t[5])::"memory");      // scalars known, stationary loads issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk_t[6])::"memory");      // ... and back
+#endif
     f32x16 acc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -862,21 +879,25 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
     const float* lse_g = p.lse + ((int64_t)s * p.H + hd) * p.T + start;
     const float* dlt_g = p.delta + ((int64_t)s * p.H + hd) * p.T + start;
     float st_lse = 0.f, st_dlt = 0.f;
+    // the row statistics of a tile are fetched by ONE wave that requests no tiles (K side, strip 0): on a tile-requesting wave the wait
+    // for these two loads in the prologue also waited for the stationary operand and held back the first tile request - a second
+    // memory round trip in front of the loop
+    const bool stats_wave = ROLE == 1 && strip == 0;
     auto load_stats = [&](int q0) {
-        if (threadIdx.x < BQ) {
-            const int ql = min(q0 + (int)threadIdx.x, len - 1);
+        if (stats_wave) {
+            const int ql = min(q0 + lane, len - 1);
             st_lse = lse_g[ql];
             st_dlt = dlt_g[ql];
         }
     };
     auto store_stats = [&](int buf) {
-        if (threadIdx.x < BQ) {
-            lse_lds[buf * BQ + threadIdx.x] = st_lse * kLog2e;
-            dlt_lds[buf * BQ + threadIdx.x] = st_dlt;
+        if (stats_wave) {
+            lse_lds[buf * BQ + lane] = st_lse * kLog2e;
+            dlt_lds[buf * BQ + lane] = st_dlt;
         }
     };
-    __syncthreads();      // the previous key block of this workgroup may still be reading the rings
     load_stats(q_begin);
+    __syncthreads();      // the previous key block of this workgroup may still be reading the rings
     // The four V-side waves fetch the tiles: they finish a step's arithmetic ahead of their K-side partners (measured against
     // all eight waves taking a share: -0.5 %).
     constexpr int NDMA = 4;
@@ -889,6 +910,9 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
         qdma.init(qp, p.ld_qkv, qrow0, q_begin + BQ, dma_id, lane);      // stand on tile 1
         dodma.init(dop, p.ld_do, qrow0, q_begin + BQ, dma_id, lane);
     }
+#ifdef HALVA_STAMP
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk_t[7])::"memory");      // first tile requested
+#endif
     store_stats(0);
     stage_tile_dma_wait();
     __syncthreads();
@@ -896,6 +920,9 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
 #ifdef HALVA_STAMP
     unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+#ifdef HALVA_STAMP
+    blk_t[4] = stamp_prev;            // loop start
 #endif
     int slot = ROLE ? 2 : 0;          // ring slot of step t - ROLE (the K side's first pass, t = 0, is idle)
     int slot_next = 1;                // ring slot the fetch of step t + 1 goes to
@@ -1050,21 +1077,31 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
         for (int i = 0; i < 6; ++i) p.dbg[(hd * 8 + wave) * 8 + i] = stamp_acc[i];
         p.dbg[(hd * 8 + wave) * 8 + 6] = ntiles;
     }
+    blk_t[1] = stamp_prev;      // (the loop's last stamp)
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk_t[2])::"memory");
 #endif
     if (k_in_T) store_rows_T<D>(outrow, acc, k_valid ? (ROLE ? p.scale : 1.f) : 0.f, true, lane);
+#ifdef HALVA_STAMP
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk_t[3])::"memory");
+    if (p.dbg && lane == 0 && s == 0 && hd == 0) {      // whole-block anatomy: [entry, loop end, before the stores, after the stores]
+        const int wave = strip + 4 * ROLE;
+        for (int i = 0; i < 8; ++i) p.dbg[1024 + (kb * 8 + wave) * 8 + i] = blk_t[i];
+    }
+#endif
 }
 
 template <int D, bool CAUSAL, bool SLOW_TR, int ROLE>
 __device__ __forceinline__ void sdpa_bwd_dkv2_role(const SdpaParams& p, char* smem, int strip) {
     int s, hd, b;
-    if (CAUSAL) {      // key block b is visited by (nblk - b) query blocks: pair b with nblk-1-b
-        map_block(blockIdx.x, (p.nblk + 1) / 2, p.H, p.npairs, false, s, hd, b);
-        sdpa_bwd_dkv2_block<D, CAUSAL, SLOW_TR, ROLE>(p, smem, s, hd, b, strip);
-        if (b != p.nblk - 1 - b) sdpa_bwd_dkv2_block<D, CAUSAL, SLOW_TR, ROLE>(p, smem, s, hd, p.nblk - 1 - b, strip);
-    } else {
-        map_block(blockIdx.x, p.nblk, p.H, p.npairs, false, s, hd, b);
-        sdpa_bwd_dkv2_block<D, CAUSAL, SLOW_TR, ROLE>(p, smem, s, hd, b, strip);
-    }
+    map_block(blockIdx.x, CAUSAL ? (p.nblk + 1) / 2 : p.nblk, p.H, p.npairs, false, s, hd, b);
+    // the sequence's geometry is read ONCE per workgroup (both key blocks belong to the same sequence): in a block's prologue these
+    // scalar loads are a memory round trip of their own in front of everything else
+    const int start = p.seq_start ? p.seq_start[s] : 0;
+    const int len = p.seq_len ? p.seq_len[s] : p.T;
+    const Branch br = load_branch(p, s);
+    sdpa_bwd_dkv2_block<D, CAUSAL, SLOW_TR, ROLE>(p, smem, s, hd, b, strip, start, len, br);
+    // under the causal mask key block b is visited by (nblk - b) query blocks: pair b with nblk-1-b
+    if (CAUSAL && b != p.nblk - 1 - b) sdpa_bwd_dkv2_block<D, CAUSAL, SLOW_TR, ROLE>(p, smem, s, hd, p.nblk - 1 - b, strip, start, len, br);
 }
 
 template <int D, bool CAUSAL, bool SLOW_TR>
