@@ -457,50 +457,101 @@ __device__ __forceinline__ void fwd_tile(const char* kt, const char* vt, const s
     STAMP(4);
 }
 
+// Geometry of one 256-row block of one (sequence, head) for this lane / wave.
+struct FwdGeom {
+    int g0, gq, ql, ntiles, skip_lo, skip_hi, wq_min, wq_max;
+    bool q_in_T, q_valid;
+    __device__ __forceinline__ int first_tile() const { return skip_lo > 0 ? 0 : skip_hi; }      // == ntiles when the block has no tile
+};
+template <bool CAUSAL>
+__device__ __forceinline__ FwdGeom fwd_geom(const SdpaParams& p, int qb, int start, int len, const Branch& br, int wave, int lane) {
+    constexpr int BN = 64, BM = 256;
+    FwdGeom g;
+    g.g0 = qb * BM;
+    g.gq = g.g0 + 32 * wave + (lane & 31);
+    g.ql = g.gq - start;
+    g.q_in_T = g.gq < p.T;
+    g.q_valid = g.q_in_T && g.ql >= 0 && g.ql < len;
+    int kv_end = len;
+    if (CAUSAL) kv_end = min(len, g.g0 + BM - start);
+    g.ntiles = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
+    g.wq_min = g.g0 + 32 * wave - start;
+    g.wq_max = g.wq_min + 31;
+    // A row block wholly in branch B does not even stage the key tiles that lie wholly inside [a, b): the tile range is walked
+    // in (up to) two segments [0, skip_lo) and [skip_hi, ntiles), each a plain double-buffered loop (one barrier per tile).
+    g.skip_lo = g.skip_hi = g.ntiles;
+    if (g.g0 - start >= br.b) {
+        g.skip_lo = min(g.ntiles, (br.a + BN - 1) / BN);
+        g.skip_hi = max(g.skip_lo, min(g.ntiles, br.b / BN));
+    }
+    return g;
+}
+
 #ifndef FWD_DMA
 #define FWD_DMA 1
 #endif
+// One row block.  `qf` (the Q fragments) belongs to the caller so that a block can fetch its SUCCESSOR's operands: when the tile loop
+// of a block has passed its last barrier the LDS ring is free and the Q registers are dead, so the next block's Q rows and first K/V
+// tile are requested THEN - in front of this block's store tail - instead of in the next block's prologue (measured per block,
+// s_memtime: 7 000-8 800 cycles from the Q request to the first tile in LDS, 3 000-4 700 for the store tail, against ~4 300 per tile).
+//   qb_next    : the block this workgroup runs next (-1: none)          prefetched : this block's operands were requested by its predecessor
+//   first_in_wg: nothing of this workgroup has touched the LDS ring yet
 template <int D, bool CAUSAL, bool SLOW_TR>
-__device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, int s, int hd, int qb) {
-    constexpr int NW = 8, BN = 64, KS = D / 16, DT = D / 32, BM = 32 * NW, NT = 64 * NW;
+__device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, int s, int hd, int qb, int qb_next, bool prefetched,
+                                               bool first_in_wg, s16x8 (&qf)[D / 16], int start, int len, const Branch br) {
+    constexpr int NW = 8, BN = 64, KS = D / 16, DT = D / 32, NT = 64 * NW;
     constexpr int TILE_BYTES = BN * D * 2;
     char* k_lds = smem;                    // [2][BN][D]
     char* v_lds = smem + 2 * TILE_BYTES;   // [2][BN][D]
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-    const int start = p.seq_start ? p.seq_start[s] : 0;
-    const int len = p.seq_len ? p.seq_len[s] : p.T;
-    const int g0 = qb * BM;
     const int64_t seq_row0 = (int64_t)s * p.T;
-    const int gq = g0 + 32 * wave + (lane & 31);
-    const int ql = gq - start;
-    const bool q_in_T = gq < p.T;
-    const bool q_valid = q_in_T && ql >= 0 && ql < len;
-
-    int kv_end = len;
-    if (CAUSAL) kv_end = min(len, g0 + BM - start);
-    const int ntiles = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
+    const FwdGeom g = fwd_geom<CAUSAL>(p, qb, start, len, br, wave, lane);
+    const int gq = g.gq, ql = g.ql, ntiles = g.ntiles, skip_lo = g.skip_lo, skip_hi = g.skip_hi, wq_min = g.wq_min, wq_max = g.wq_max;
+    const bool q_in_T = g.q_in_T, q_valid = g.q_valid;
 
     const bf16_t* kp = p.k + hd * D;
     const bf16_t* vp = p.v + hd * D;
     bf16_t* orow = p.o + (seq_row0 + gq) * p.ld_o + hd * D;
+    // K/V tiles arrive by LDS-DMA (no staging registers, no ds_write pass); the slow-transpose debug build keeps register staging
+    constexpr bool DMA = !SLOW_TR && FWD_DMA;
+    const int wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // used for the DMA addresses only
+    const int64_t krow0 = seq_row0 + start;
+    auto request_q = [&](const FwdGeom& gg) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (gg.q_valid)
+                qf[ks] = *reinterpret_cast<const s16x8*>(p.q + hd * D + (seq_row0 + gg.gq) * p.ld_qkv + 16 * ks + 8 * h);
+            else
+                qf[ks] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    };
+    auto request_first_tile = [&](const FwdGeom& gg) {      // DMA builds only; the caller vouches that nobody reads slot 0 any more
+        const int t = gg.first_tile();
+        if (t < gg.ntiles) {
+            stage_tile_dma<D, NW>(k_lds, kp, p.ld_qkv, krow0, t * BN, len, wave_u, lane);
+            stage_tile_dma<D, NW>(v_lds, vp, p.ld_qkv, krow0, t * BN, len, wave_u, lane);
+        }
+    };
+    auto prefetch_next = [&]() {
+        if (DMA && qb_next >= 0) {
+            const FwdGeom gn = fwd_geom<CAUSAL>(p, qb_next, start, len, br, wave, lane);
+            request_q(gn);
+            request_first_tile(gn);
+        }
+    };
+    const bool pre = DMA && prefetched;
 
     if (ntiles == 0) {
         if (q_in_T) {
             store_rows_zero<D>(orow, lane);
             if (h == 0 && p.lse) p.lse[((int64_t)s * p.H + hd) * p.T + gq] = 0.f;
         }
+        if (!pre && !first_in_wg) __syncthreads();      // (a predecessor's readers; a prefetching predecessor has passed its last barrier)
+        prefetch_next();
         return;
     }
-
-    s16x8 qf[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        if (q_valid)
-            qf[ks] = *reinterpret_cast<const s16x8*>(p.q + hd * D + (seq_row0 + gq) * p.ld_qkv + 16 * ks + 8 * h);
-        else
-            qf[ks] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
+    if (!pre) request_q(g);
 
     f32x16 oacc[DT];
 #pragma unroll
@@ -509,35 +560,27 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
     float m_ref = -INFINITY, l_run = 0.f;
     const float sc = p.scale * kLog2e;
-    const int wq_min = g0 + 32 * wave - start, wq_max = wq_min + 31;
-
-    const Branch br = load_branch(p, s);
     const bool wave_in_b = wq_min >= br.b;             // wave-uniform (br.b is a multiple of 64, strips are 32 rows)
-    // K/V tiles arrive by LDS-DMA (no staging registers, no ds_write pass); the slow-transpose debug build keeps register staging
-    constexpr bool DMA = !SLOW_TR && FWD_DMA;
-    const int wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // used for the DMA addresses only
     Stage<D, BN, NT> kst, vst;
     TileDma<D, NW> kdma, vdma;
-    const int64_t krow0 = seq_row0 + start;
 #ifdef HALVA_STAMP
-    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_prev;
+    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_prev, blk_t[4];
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+    blk_t[0] = stamp_prev;      // (Q requested, scalars known)
+    blk_t[1] = 0;
 #endif
-    // A row block wholly in branch B does not even stage the key tiles that lie wholly inside [a, b): the tile range is walked
-    // in (up to) two segments [0, skip_lo) and [skip_hi, ntiles), each a plain double-buffered loop (one barrier per tile).
-    int skip_lo = ntiles, skip_hi = ntiles;
-    if (g0 - start >= br.b) {
-        skip_lo = min(ntiles, (br.a + BN - 1) / BN);
-        skip_hi = max(skip_lo, min(ntiles, br.b / BN));
-    }
+    bool first_seg = true;
 #pragma unroll 1
     for (int seg = 0; seg < 2; ++seg) {
         const int t0 = seg ? skip_hi : 0, t1 = seg ? ntiles : skip_lo;
         if (t0 >= t1) continue;
-        __syncthreads();      // earlier readers of the LDS slots (previous segment / previous row block) are done
+        const bool staged = pre && first_seg;      // tile t0 was requested by the previous block
+        if (!staged && !(first_in_wg && first_seg)) __syncthreads();      // earlier readers of the LDS slots (previous segment / row block) are done
         if (DMA) {
-            stage_tile_dma<D, NW>(k_lds, kp, p.ld_qkv, krow0, t0 * BN, len, wave_u, lane);
-            stage_tile_dma<D, NW>(v_lds, vp, p.ld_qkv, krow0, t0 * BN, len, wave_u, lane);
+            if (!staged) {
+                stage_tile_dma<D, NW>(k_lds, kp, p.ld_qkv, krow0, t0 * BN, len, wave_u, lane);
+                stage_tile_dma<D, NW>(v_lds, vp, p.ld_qkv, krow0, t0 * BN, len, wave_u, lane);
+            }
             kdma.init(kp, p.ld_qkv, krow0, (t0 + 1) * BN, wave_u, lane);
             vdma.init(vp, p.ld_qkv, krow0, (t0 + 1) * BN, wave_u, lane);
             stage_tile_dma_wait();
@@ -547,7 +590,11 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
             kst.store(k_lds);
             vst.store(v_lds);
         }
+        first_seg = false;
         __syncthreads();
+#ifdef HALVA_STAMP
+        if (blk_t[1] == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk_t[1])::"memory");      // first tile in LDS
+#endif
 #pragma unroll 1
         for (int it = t0; it < t1; ++it) {
             const int kv0 = it * BN;
@@ -590,14 +637,21 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
         for (int i = 0; i < 6; ++i) p.dbg[wave * 8 + i] = stamp_acc[i];
         p.dbg[wave * 8 + 6] = ntiles;
     }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk_t[2])::"memory");      // tile loop done
 #endif
-
+    // every wave has passed the last tile's barrier: the ring is free and Q is dead - fetch the next block's operands in front of the stores
+    prefetch_next();
     const float l_tot = xhalf_sum(l_run);
     const float inv = (q_valid && l_tot > 0.f) ? 1.f / l_tot : 0.f;
     if (q_in_T) {
         store_rows_T<D>(orow, oacc, inv, true, lane);
         if (h == 0 && p.lse) p.lse[((int64_t)s * p.H + hd) * p.T + gq] = q_valid ? (m_ref + log2f(l_tot)) * kLn2 : 0.f;
     }
+#ifdef HALVA_STAMP
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk_t[3])::"memory");      // rows stored
+    if (p.dbg && lane == 0 && s == 0 && hd == 0)
+        for (int i = 0; i < 4; ++i) p.dbg[2048 + (qb * 8 + wave) * 4 + i] = blk_t[i];
+#endif
 }
 
 // Under the causal mask row block b needs (b+1) units of work; one workgroup takes blocks b and nblk-1-b so every
@@ -606,13 +660,18 @@ template <int D, bool CAUSAL, bool SLOW_TR>
 __global__ __launch_bounds__(512) void sdpa_fwd_kernel(const SdpaParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int s, hd, b;
+    map_block(blockIdx.x, CAUSAL ? (p.nblk + 1) / 2 : p.nblk, p.H, p.npairs, false, s, hd, b);
+    // the sequence's geometry is read once per workgroup
+    const int start = p.seq_start ? p.seq_start[s] : 0;
+    const int len = p.seq_len ? p.seq_len[s] : p.T;
+    const Branch br = load_branch(p, s);
+    s16x8 qf[D / 16];
     if (CAUSAL) {
-        map_block(blockIdx.x, (p.nblk + 1) / 2, p.H, p.npairs, false, s, hd, b);
-        sdpa_fwd_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, p.nblk - 1 - b);
-        if (b != p.nblk - 1 - b) sdpa_fwd_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, b);
+        const int first = p.nblk - 1 - b, second = (b != first) ? b : -1;
+        sdpa_fwd_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, first, second, false, true, qf, start, len, br);
+        if (second >= 0) sdpa_fwd_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, second, -1, true, false, qf, start, len, br);
     } else {
-        map_block(blockIdx.x, p.nblk, p.H, p.npairs, false, s, hd, b);
-        sdpa_fwd_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, b);
+        sdpa_fwd_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, b, -1, false, true, qf, start, len, br);
     }
 }
 
@@ -819,9 +878,37 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void sdpa_bwd_dq_kernel
 // The K side runs one staged step behind the V side, so the workgroup barrier of the step (needed for the Q/dO ring anyway) is the
 // only synchronisation; the Q/dO ring has 3 slots (steps t-1, t and the one being fetched), P has 2 (by step parity).
 // ---------------------------------------------------------------------------------------------------
+// Geometry of one 128-key block for this lane (key = lane % 32 of strip `strip`).
+struct DkvGeom {
+    int gk, kl, kblk_min, q_begin, q_stop, ntiles;
+    bool k_in_T, k_valid;
+};
+template <bool CAUSAL>
+__device__ __forceinline__ DkvGeom dkv_geom(const SdpaParams& p, int kb, int strip, int start, int len, const Branch& br, int lane) {
+    constexpr int BQ = 64;
+    DkvGeom g;
+    g.gk = kb * 128 + 32 * strip + (lane & 31);
+    g.kl = g.gk - start;
+    g.k_in_T = g.gk < p.T;
+    g.k_valid = g.k_in_T && g.kl >= 0 && g.kl < len;
+    g.kblk_min = kb * 128 - start;
+    g.q_begin = 0;
+    if (CAUSAL) g.q_begin = max(0, g.kblk_min) / BQ * BQ;
+    const bool block_has_keys = (g.kblk_min < len) && (g.kblk_min + 128 > 0);
+    g.q_stop = (g.kblk_min >= br.a && g.kblk_min + 127 < br.b) ? min(len, br.b) : len;
+    g.ntiles = (block_has_keys && g.q_stop > g.q_begin) ? (g.q_stop - g.q_begin + BQ - 1) / BQ : 0;
+    return g;
+}
+
+// `sf` (the stationary K or V fragments) and `st` (the row statistics in flight) belong to the caller so that a key block can fetch its
+// SUCCESSOR's operands: once the step loop has passed its last barrier the Q/dO ring is free and the stationary registers are dead, so
+// the next block's K/V rows, first Q/dO tile and first statistics are requested then - in front of this block's store tail - instead
+// of in the next block's prologue (measured per block, s_memtime: 10 000-12 000 cycles from entry to the first step, of which three
+// memory round trips one behind the other; a step is ~3 850).
+//   kb_next: the key block this workgroup runs next (-1: none)      prefetched: this block's operands were requested by its predecessor
 template <int D, bool CAUSAL, bool SLOW_TR, int ROLE>
-__device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* smem, int s, int hd, int kb, int strip, int start, int len,
-                                                    const Branch br) {
+__device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* smem, int s, int hd, int kb, int kb_next, bool prefetched,
+                                                    int strip, int start, int len, const Branch br, s16x8 (&sf)[D / 16], float (&st)[2]) {
     constexpr int BQ = 64, SUB = 2, KS = D / 16, DT = D / 32;
     constexpr int TILE_BYTES = BQ * D * 2;
     char* q_lds = smem;                                    // [3][BQ][D]
@@ -834,51 +921,22 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
 #ifdef HALVA_STAMP
     unsigned long long blk_t[8];
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk_t[0])::"memory");
+    blk_t[5] = blk_t[6] = blk_t[7] = blk_t[0];
 #endif
     const int64_t seq_row0 = (int64_t)s * p.T;
-    const int gk = kb * 128 + 32 * strip + (lane & 31);
-    const int kl = gk - start;
-    const bool k_in_T = gk < p.T;
-    const bool k_valid = k_in_T && kl >= 0 && kl < len;
+    const DkvGeom g = dkv_geom<CAUSAL>(p, kb, strip, start, len, br, lane);
+    const int gk = g.gk, kl = g.kl, kblk_min = g.kblk_min, q_begin = g.q_begin, ntiles = g.ntiles;
+    const bool k_in_T = g.k_in_T, k_valid = g.k_valid;
     bf16_t* outrow = (ROLE ? p.dk : p.dv) + (seq_row0 + gk) * p.ld_qkv + hd * D;
-
-    const int kblk_min = kb * 128 - start;
-    int q_begin = 0;
-    if (CAUSAL) q_begin = max(0, kblk_min) / BQ * BQ;
-    const bool block_has_keys = (kblk_min < len) && (kblk_min + 128 > 0);
-    const int q_stop = (kblk_min >= br.a && kblk_min + 127 < br.b) ? min(len, br.b) : len;
-    const int ntiles = (block_has_keys && q_stop > q_begin) ? (q_stop - q_begin + BQ - 1) / BQ : 0;
     const bool key_hidden = kl >= br.a && kl < br.b;
-    if (ntiles == 0) {
-        if (k_in_T) store_rows_zero<D>(outrow, lane);
-        return;
-    }
-
-    // this wave's stationary operand: K fragments (V side) or V fragments (K side)
-    const bf16_t* stat = (ROLE ? p.v : p.k) + (seq_row0 + gk) * p.ld_qkv + hd * D;
-    s16x8 sf[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) sf[ks] = k_valid ? *reinterpret_cast<const s16x8*>(stat + 16 * ks + 8 * h) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
-#ifdef HALVA_STAMP
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk_t[5])::"memory");      // scalars known, stationary loads issued
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk_t[6])::"memory");      // ... and back
-#endif
-    f32x16 acc[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
-    const float sc = p.scale * kLog2e;
-    const int wk_min = kblk_min + 32 * strip;
-    const bool wave_has_pad_keys = __any(!k_valid);
 
     const bf16_t* qp = p.q + hd * D;
     const bf16_t* dop = p.d_o + hd * D;
     const int64_t qrow0 = seq_row0 + start;
     const float* lse_g = p.lse + ((int64_t)s * p.H + hd) * p.T + start;
     const float* dlt_g = p.delta + ((int64_t)s * p.H + hd) * p.T + start;
-    float st_lse = 0.f, st_dlt = 0.f;
+    float& st_lse = st[0];
+    float& st_dlt = st[1];
     // the row statistics of a tile are fetched by ONE wave that requests no tiles (K side, strip 0): on a tile-requesting wave the wait
     // for these two loads in the prologue also waited for the stationary operand and held back the first tile request - a second
     // memory round trip in front of the loop
@@ -896,17 +954,59 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
             dlt_lds[buf * BQ + lane] = st_dlt;
         }
     };
-    load_stats(q_begin);
-    __syncthreads();      // the previous key block of this workgroup may still be reading the rings
     // The four V-side waves fetch the tiles: they finish a step's arithmetic ahead of their K-side partners (measured against
     // all eight waves taking a share: -0.5 %).
     constexpr int NDMA = 4;
     constexpr bool dma_wave = ROLE == 0;
     const int dma_id = strip;
+    // this wave's stationary operand: K fragments (V side) or V fragments (K side)
+    auto request_stationary = [&](const DkvGeom& gg) {
+        const bf16_t* stat = (ROLE ? p.v : p.k) + (seq_row0 + gg.gk) * p.ld_qkv + hd * D;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            sf[ks] = gg.k_valid ? *reinterpret_cast<const s16x8*>(stat + 16 * ks + 8 * h) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    };
+    auto request_first_tile = [&](const DkvGeom& gg) {      // the caller vouches that nobody reads ring slot 0 any more
+        if (dma_wave && gg.ntiles > 0) {
+            stage_tile_dma<D, NDMA>(q_lds, qp, p.ld_qkv, qrow0, gg.q_begin, len, dma_id, lane);
+            stage_tile_dma<D, NDMA>(do_lds, dop, p.ld_do, qrow0, gg.q_begin, len, dma_id, lane);
+        }
+    };
+    auto prefetch_next = [&]() {
+        if (kb_next >= 0) {
+            const DkvGeom gn = dkv_geom<CAUSAL>(p, kb_next, strip, start, len, br, lane);
+            if (gn.ntiles > 0) {
+                request_stationary(gn);
+                load_stats(gn.q_begin);
+            }
+            request_first_tile(gn);
+        }
+    };
+
+    if (ntiles == 0) {
+        if (k_in_T) store_rows_zero<D>(outrow, lane);
+        prefetch_next();      // (no step loop ran here, and a predecessor - if any - has passed its last barrier: the rings are free)
+        return;
+    }
+    if (!prefetched) {
+        request_stationary(g);
+        load_stats(q_begin);
+    }
+#ifdef HALVA_STAMP
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk_t[5])::"memory");      // scalars known, stationary loads issued
+#endif
+    f32x16 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+    const float sc = p.scale * kLog2e;
+    const int wk_min = kblk_min + 32 * strip;
+    const bool wave_has_pad_keys = __any(!k_valid);
+
+    if (!prefetched) request_first_tile(g);      // (not prefetched = first block of the workgroup: nobody is reading the rings)
     TileDma<D, NDMA> qdma, dodma;
     if (dma_wave) {
-        stage_tile_dma<D, NDMA>(q_lds, qp, p.ld_qkv, qrow0, q_begin, len, dma_id, lane);
-        stage_tile_dma<D, NDMA>(do_lds, dop, p.ld_do, qrow0, q_begin, len, dma_id, lane);
         qdma.init(qp, p.ld_qkv, qrow0, q_begin + BQ, dma_id, lane);      // stand on tile 1
         dodma.init(dop, p.ld_do, qrow0, q_begin + BQ, dma_id, lane);
     }
@@ -1080,6 +1180,8 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
     blk_t[1] = stamp_prev;      // (the loop's last stamp)
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk_t[2])::"memory");
 #endif
+    // every wave has passed the last step's barrier: the rings are free and the stationary fragments dead
+    prefetch_next();
     if (k_in_T) store_rows_T<D>(outrow, acc, k_valid ? (ROLE ? p.scale : 1.f) : 0.f, true, lane);
 #ifdef HALVA_STAMP
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk_t[3])::"memory");
@@ -1099,9 +1201,12 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_role(const SdpaParams& p, char* sm
     const int start = p.seq_start ? p.seq_start[s] : 0;
     const int len = p.seq_len ? p.seq_len[s] : p.T;
     const Branch br = load_branch(p, s);
-    sdpa_bwd_dkv2_block<D, CAUSAL, SLOW_TR, ROLE>(p, smem, s, hd, b, strip, start, len, br);
+    s16x8 sf[D / 16];
+    float st[2] = {0.f, 0.f};
     // under the causal mask key block b is visited by (nblk - b) query blocks: pair b with nblk-1-b
-    if (CAUSAL && b != p.nblk - 1 - b) sdpa_bwd_dkv2_block<D, CAUSAL, SLOW_TR, ROLE>(p, smem, s, hd, p.nblk - 1 - b, strip, start, len, br);
+    const int second = (CAUSAL && b != p.nblk - 1 - b) ? p.nblk - 1 - b : -1;
+    sdpa_bwd_dkv2_block<D, CAUSAL, SLOW_TR, ROLE>(p, smem, s, hd, b, second, false, strip, start, len, br, sf, st);
+    if (second >= 0) sdpa_bwd_dkv2_block<D, CAUSAL, SLOW_TR, ROLE>(p, smem, s, hd, second, -1, true, strip, start, len, br, sf, st);
 }
 
 template <int D, bool CAUSAL, bool SLOW_TR>
