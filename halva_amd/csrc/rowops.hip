@@ -2,6 +2,7 @@
 // SwiGLU fwd/bwd and the splice row gather.  All bf16 I/O with 16-byte (8 x bf16) accesses per lane,
 // one 64-lane wave per row for the reductions (shuffle only, no LDS, no barrier).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -39,7 +40,7 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
 template <int MAXC>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ w,
                                                           u32x4* __restrict__ y, float* __restrict__ rstd, int64_t rows,
-                                                          int nchunk, int64_t ldy_chunks, float eps, float inv_d) {
+                                                          int nchunk, int64_t ldy_chunks, float eps, float inv_d, int module_rounding) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const u32x4* __restric
             unpack8(buf[i], f);
             unpack8(w[c], g);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = g[j] * (f[j] * r);
+            for (int j = 0; j < 8; ++j) f[j] = g[j] * (module_rounding ? bf16_round(f[j] * r) : f[j] * r);
             yr[c] = pack8(f);
         }
     }
@@ -235,7 +236,11 @@ extern "C" int halva_rmsnorm_fwd_ld(const void* x, const void* w, void* y, int64
     const int blocks = (int)((rows + kWavesPerBlock - 1) / kWavesPerBlock);
 #define FWD(C)                                                                                                           \
     hipLaunchKernelGGL(rmsnorm_fwd_kernel<C>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, (const u32x4*)w, \
-                       (u32x4*)y, rstd, rows, d / 8, ldy / 8, eps, 1.f / d)
+                       (u32x4*)y, rstd, rows, d / 8, ldy / 8, eps, 1.f / d, module_rounding)
+    // HALVA_RMSNORM_MODULE_ROUNDING=1: round x * rstd to bf16 BEFORE the multiplication with the weight, exactly as the module does on a
+    // bf16 device (modelling_llama.py:69-70: `self.weight * hidden_states.to(input_dtype)`), for bf16-vs-bf16 comparisons with the
+    // reference's GPU numerics.  Default 0: one rounding of the fp32 value (what the fp32 CPU path parity is defined against computes).
+    static const int module_rounding = [] { const char* e = getenv("HALVA_RMSNORM_MODULE_ROUNDING"); return (e && e[0] == '1') ? 1 : 0; }();
     RMSNORM_DISPATCH(d, FWD);
 #undef FWD
     HALVA_CHECK_LAUNCH("rmsnorm_fwd");

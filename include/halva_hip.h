@@ -38,6 +38,8 @@ const char* halva_last_error(void);
 /* ---- Llama RMSNorm.  replaces LlamaRMSNorm.forward (llava/model/language_model/modelling_llama.py:65-70)
  * y = bf16(w * x_f32 * rsqrt(mean(x_f32^2) + eps)) - the module's fp32 value, rounded once (its intermediate cast to the input
  * dtype is a no-op on the fp32 CPU path that parity is defined against); rstd[rows] (f32) is saved for the backward.
+ * With HALVA_RMSNORM_MODULE_ROUNDING=1 in the environment (read once per process) the forward instead rounds x * rstd to bf16 before
+ * the multiplication with w - bit for bit what the module computes on a bf16 device - for comparisons with the reference's GPU numerics.
  * bwd gives dx only (norm weights are frozen on the LoRA DPA path; llava/train/train_halva.py:1085-1101). */
 int halva_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int d, float eps, void* stream);
 int halva_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, int64_t rows, int d,

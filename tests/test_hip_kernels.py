@@ -71,6 +71,37 @@ def test_rmsnorm(rows, d):
     assert rel_err(xg.grad, xr.grad) < 6e-3          # bf16 output rounding of dx (2^-9 relative per element)
 
 
+def test_rmsnorm_module_rounding_flag_reproduces_the_bf16_module_bit_for_bit():
+    """HALVA_RMSNORM_MODULE_ROUNDING=1 (read once per process, hence the child process): y = w * bf16(x * rstd), the value
+    LlamaRMSNorm.forward (modelling_llama.py:65-70) produces on a bf16 device, instead of the default single rounding."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from halva_amd import kernels as K
+g = torch.Generator().manual_seed(5)
+x = (torch.randn(257, 4096, generator=g) * 3).to(torch.bfloat16)
+w = (1 + 0.2 * torch.randn(4096, generator=g)).to(torch.bfloat16)
+y = K.rmsnorm(x.cuda(), w.cuda(), 1e-5).cpu()
+xf = x.float()
+n = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)).to(torch.bfloat16)      # the module's cast back to the input dtype
+spec = (w * n)                                                                            # bf16 x bf16 -> bf16
+once = (w.float() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5))).to(torch.bfloat16)
+print("RESULT", float((y != spec).float().mean()), float((y != once).float().mean()), float((y.float() - spec.float()).abs().max()))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ, HALVA_RMSNORM_MODULE_ROUNDING=flag)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[flag] = [float(v) for v in [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1].split()[1:]]
+    # (rsqrt on the device and on the host may differ in the last bit of f32: a handful of elements sit on a bf16 rounding edge)
+    assert out["1"][0] < 2e-4, out          # flag on: the module's two-rounding value, bit for bit
+    assert out["0"][1] < 2e-4, out          # default: the single rounding
+    assert out["0"][0] > 5e-3 and out["1"][1] > 5e-3, out      # ... and the two really differ on this input
+
+
 @pytest.mark.parametrize("rows,d,width", [(37, 4096, 4480), (9, 5120, 5120)])
 def test_rmsnorm_fork_sums_the_residual_gradient_in_the_kernel(rows, d, width):
     """(norm(x), x) as one autograd node: forward equals rmsnorm, backward is BIT-identical to autograd's accumulation of the norm's
