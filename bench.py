@@ -403,7 +403,10 @@ def main():
                 lin = 2 * ((27.06 + 1.31) + (27.06 + 2.62))
                 att = 2 * (1.10 + 2.75)
                 tf_exec = tf_pair - lin * (1 - row_ratio) - att * (1 - pair_ratio)
-        rec = {"metric": "paired-samples/sec (DPA step) LLaVA-1.5-7B @336px", "value": round(pairs_per_s, 4),
+        metric = {"7b": "paired-samples/sec (DPA step) LLaVA-1.5-7B @336px",
+                  "13b": "paired-samples/sec (DPA step) LLaVA-1.5-13B @336px (extra workload, not the BASELINE metric)",
+                  "vila13b": "paired-samples/sec (DPA step) VILA-13B @384px T=4096 (extra workload, not the BASELINE metric)"}[args.model]
+        rec = {"metric": metric, "value": round(pairs_per_s, 4),
                "unit": "paired-samples/sec", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16", "data": "synthetic (BASELINE.md section 3), random-init weights",
