@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-kernel durations of the SDPA microbench; usage: tools/prof_sdpa.sh <tag> (env passes through, e.g. HALVA_DKV2=1)
+# per-kernel durations of the SDPA microbench; usage: tools/prof_sdpa.sh <tag> (env passes through, e.g. HALVA_HIP_LIB=<another build> for an A/B in one gpurun call)
 R=$PWD; tag=${1:-run}
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_sdpa_$tag -o p --output-format csv -- python3 $R/tools/bench_sdpa.py > /dev/null 2>&1

@@ -15,10 +15,9 @@ lib = hip.load(); lib.halva_dbg_buffer.restype = ctypes.c_void_p
 buf = (ctypes.c_uint64 * 4096)()
 ctypes.CDLL("libamdhip64.so").hipMemcpy(buf, ctypes.c_void_p(lib.halva_dbg_buffer()), 4096 * 8, 2)
 a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8)
-# two-role kernel (default): waves 0-3 = V side, 4-7 = K side; HALVA_DKV2=0: the one-wave-per-SIMD kernel (4 waves, its own phases)
-names = (["tile requests", "block 1", "block 2", "blocks 3-4", "stats + dma wait", "barrier"] if os.environ.get("HALVA_DKV2", "1") != "0"
-         else ["issue loads", "S,dP mfma", "softmax valu", "dV,dK mfma", "lds store", "barrier"])
-NW = 4 if os.environ.get("HALVA_DKV2", "1") == "0" else 8
+# two-role kernel: waves 0-3 = V side, 4-7 = K side
+names = ["tile requests", "block 1", "block 2", "blocks 3-4", "stats + dma wait", "barrier"]
+NW = 8
 for w in range(NW):
     r = a[w]; nt = int(r[6])
     if nt: print("wave %d tiles(64 rows) %d  " % (w, nt) + "  ".join("%s %.0f" % (n, r[i] / nt) for i, n in enumerate(names)) + "  total/tile %.0f" % (sum(r[:6]) / nt))
