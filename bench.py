@@ -298,7 +298,7 @@ def main():
     if not args.pairs_per_gpu:
         args.pairs_per_gpu = 8 if vila else 16
     if not args.pairs_per_group:
-        args.pairs_per_group = {"7b": 8, "13b": 4, "vila13b": 2}[args.model]
+        args.pairs_per_group = {"7b": 16, "13b": 4, "vila13b": 2}[args.model]      # 7B: the whole 16-pair batch as ONE group (288 GB of HBM)
     if vila:
         from halva_amd.vila_model import build_random_vila
         policy = build_random_vila(geo, SIGLIP_SO400M_384, lora_r=128, lora_alpha=256, seed=1234, device=dev, max_len=seq)
@@ -343,8 +343,23 @@ def main():
         opt.step()
         return loss
 
-    for _ in range(args.warmup):
-        last = step()
+    try:
+        for _ in range(args.warmup):
+            last = step()
+    except torch.cuda.OutOfMemoryError:
+        # The 7B default keeps the whole 16-pair batch as one group (265 of the 288 GiB).  Should this box have less free (another
+        # tenant, a larger runtime footprint), halve the groups BEFORE anything is timed: every timed step then runs the smaller setting.
+        if args.pairs_per_group <= 1:
+            raise
+        args.pairs_per_group = max(1, args.pairs_per_group // 2)
+        eng.pairs_per_group, eng.ref_rows_per_group = args.pairs_per_group, 2 * args.pairs_per_group
+        flat.zero_grad()
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        print("bench: out of memory in the warm-up; continuing with %d pairs per group" % args.pairs_per_group, file=sys.stderr)
+        for _ in range(max(1, args.warmup)):
+            last = step()
     if os.environ.get("HALVA_BENCH_TORCH_PROFILE"):      # diagnostic: where do the non-GEMM, non-HIP kernels of a step come from
         from torch.profiler import profile, ProfilerActivity
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
