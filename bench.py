@@ -289,6 +289,8 @@ def main():
         raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d" % (args.gpus, ctx.world))
     torch.cuda.set_device(ctx.local_rank)
     dev = torch.device("cuda", ctx.local_rank)
+    if os.environ.get("HALVA_BENCH_MEM_FRACTION"):      # diagnostic: cap this process's share of the HBM (exercises the out-of-memory fall-back)
+        torch.cuda.set_per_process_memory_fraction(float(os.environ["HALVA_BENCH_MEM_FRACTION"]), ctx.local_rank)
 
     geo = dict(LLAMA_7B if args.model == "7b" else LLAMA_13B)
     if args.layers:
@@ -343,19 +345,22 @@ def main():
         opt.step()
         return loss
 
+    oom = False
     try:
         for _ in range(args.warmup):
             last = step()
     except torch.cuda.OutOfMemoryError:
+        oom = True      # (handled below: inside the handler the traceback still pins the failed step's tensors)
+    if oom:
         # The 7B default keeps the whole 16-pair batch as one group (265 of the 288 GiB).  Should this box have less free (another
         # tenant, a larger runtime footprint), halve the groups BEFORE anything is timed: every timed step then runs the smaller setting.
         if args.pairs_per_group <= 1:
-            raise
+            raise SystemExit("bench.py: out of memory with one pair per group")
         args.pairs_per_group = max(1, args.pairs_per_group // 2)
         eng.pairs_per_group, eng.ref_rows_per_group = args.pairs_per_group, 2 * args.pairs_per_group
-        flat.zero_grad()
         import gc
         gc.collect()
+        flat.zero_grad()
         torch.cuda.empty_cache()
         print("bench: out of memory in the warm-up; continuing with %d pairs per group" % args.pairs_per_group, file=sys.stderr)
         for _ in range(max(1, args.warmup)):
