@@ -40,7 +40,8 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
 template <int MAXC>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ w,
                                                           u32x4* __restrict__ y, float* __restrict__ rstd, int64_t rows,
-                                                          int nchunk, int64_t ldy_chunks, float eps, float inv_d, int module_rounding) {
+                                                          int nchunk, int64_t ldy_chunks, float eps, float inv_d, int module_rounding,
+                                                          u32x4* __restrict__ x_copy) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const u32x4* __restric
         const int c = lane + 64 * i;
         if (c < nchunk) {
             buf[i] = xr[c];
+            if (x_copy) x_copy[row * nchunk + c] = buf[i];      // the residual stream's own buffer (see halva_rmsnorm_fwd_fork_ld)
             float f[8];
             unpack8(buf[i], f);
 #pragma unroll
@@ -228,7 +230,13 @@ extern "C" int halva_rmsnorm_fwd(const void* x, const void* w, void* y, float* r
 
 extern "C" int halva_rmsnorm_fwd_ld(const void* x, const void* w, void* y, int64_t ldy, float* rstd, int64_t rows, int d,
                                     float eps, void* stream) {
+    return halva_rmsnorm_fwd_fork_ld(x, w, y, ldy, rstd, nullptr, rows, d, eps, stream);
+}
+
+extern "C" int halva_rmsnorm_fwd_fork_ld(const void* x, const void* w, void* y, int64_t ldy, float* rstd, void* x_copy, int64_t rows,
+                                         int d, float eps, void* stream) {
     HALVA_CHECK_ARG(x && w && y && rstd, "rmsnorm_fwd: null pointer");
+    HALVA_CHECK_ARG(x_copy != x, "rmsnorm_fwd_fork: x_copy must not alias x");
     HALVA_CHECK_ARG(ldy >= d && ldy % 8 == 0, "rmsnorm_fwd: output row stride %lld must be >= d and a multiple of 8", (long long)ldy);
     HALVA_CHECK_ARG(d > 0 && d % 8 == 0 && d <= 8 * 64 * kMaxChunks, "rmsnorm_fwd: d=%d must be a multiple of 8 and <= %d", d,
                     8 * 64 * kMaxChunks);
@@ -236,7 +244,7 @@ extern "C" int halva_rmsnorm_fwd_ld(const void* x, const void* w, void* y, int64
     const int blocks = (int)((rows + kWavesPerBlock - 1) / kWavesPerBlock);
 #define FWD(C)                                                                                                           \
     hipLaunchKernelGGL(rmsnorm_fwd_kernel<C>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, (const u32x4*)w, \
-                       (u32x4*)y, rstd, rows, d / 8, ldy / 8, eps, 1.f / d, module_rounding)
+                       (u32x4*)y, rstd, rows, d / 8, ldy / 8, eps, 1.f / d, module_rounding, (u32x4*)x_copy)
     // HALVA_RMSNORM_MODULE_ROUNDING=1: round x * rstd to bf16 BEFORE the multiplication with the weight, exactly as the module does on a
     // bf16 device (modelling_llama.py:69-70: `self.weight * hidden_states.to(input_dtype)`), for bf16-vs-bf16 comparisons with the
     // reference's GPU numerics.  Default 0: one rounding of the fp32 value (what the fp32 CPU path parity is defined against computes).

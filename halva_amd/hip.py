@@ -20,6 +20,7 @@ SIGNATURES = {
     "halva_rmsnorm_bwd": [_P, _P, _P, _P, _P, _L, _I, _P],
     "halva_rmsnorm_fwd_ld": [_P, _P, _P, _L, _P, _L, _I, _F, _P],
     "halva_rmsnorm_bwd_ld": [_P, _L, _P, _P, _P, _P, _L, _I, _P],
+    "halva_rmsnorm_fwd_fork_ld": [_P, _P, _P, _L, _P, _P, _L, _I, _F, _P],
     "halva_rmsnorm_bwd_res_ld": [_P, _L, _P, _P, _P, _P, _P, _L, _I, _P],
     "halva_swiglu_fwd_ld": [_P, _P, _L, _L, _I, _P],
     "halva_swiglu_bwd_ld": [_P, _L, _P, _P, _L, _I, _P],

@@ -58,9 +58,11 @@ def rmsnorm(x, w, eps, out_width=None):
 
 
 class _RMSNormFork(torch.autograd.Function):
-    """The residual fork of a decoder layer as ONE node: returns (rmsnorm(x), x).  The second output is what the residual
+    """The residual fork of a decoder layer as ONE node: returns (rmsnorm(x), x').  The second output is what the residual
     connection must consume (modelling_llama.py:395-417); its gradient then arrives here together with the norm's and the
-    backward kernel adds it while writing dx - instead of autograd's separate accumulation pass over the hidden state."""
+    backward kernel adds it while writing dx - instead of autograd's separate accumulation pass over the hidden state.
+    x' is a COPY of x written by the same kernel (halva_rmsnorm_fwd_fork_ld): the projection that closes the block accumulates
+    onto it in place (llama._LoraGroupFn, beta = 1 GEMM) instead of first copying the residual into a fresh output buffer."""
 
     @staticmethod
     def forward(ctx, x, w, eps, out_width):
@@ -70,10 +72,11 @@ class _RMSNormFork(torch.autograd.Function):
         width = out_width or d
         y = torch.empty(*x.shape[:-1], width, dtype=x.dtype, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-        call("halva_rmsnorm_fwd_ld", ptr(x), ptr(w), ptr(y), width, ptr(rstd), rows, d, float(eps), stream_ptr())
+        xc = torch.empty_like(x)
+        call("halva_rmsnorm_fwd_fork_ld", ptr(x), ptr(w), ptr(y), width, ptr(rstd), ptr(xc), rows, d, float(eps), stream_ptr())
         ctx.save_for_backward(x, w, rstd)
         ctx.width = width
-        return y, x.view_as(x)
+        return y, xc
 
     @staticmethod
     def backward(ctx, dy, dres):

@@ -67,6 +67,7 @@ def _jsonable(v):
 # memory once more (13.5 GB at 7B, 26 GB at 13B - of 288 GB); HALVA_DGRAD_WT=0 turns it off.
 DGRAD_TRANSPOSED_COPY = os.environ.get("HALVA_DGRAD_WT", "1") != "0"
 WGRAD_KERNEL = os.environ.get("HALVA_WGRAD_KERNEL", "1") != "0"      # LoRA weight gradients through halva_wgrad_accumulate
+RES_INPLACE = os.environ.get("HALVA_RES_INPLACE", "1") != "0"        # residual adds accumulate onto the block's own buffer (A/B: 0)
 K_ = K      # the kernels module under a name that _LoraGroupFn's local `K` (in_features) does not shadow
 
 LORA_TARGETS = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
@@ -85,12 +86,20 @@ class _LoraGroupFn(torch.autograd.Function):
     Base weight frozen: gradients for x, A, B only; with `sink` they are added into the fp32 `main_grad` views."""
 
     @staticmethod
-    def forward(ctx, xa, residual, Wc, WcT, A, scale, sink, K, *Bs):
+    def forward(ctx, xa, residual, Wc, WcT, A, scale, sink, K, res_inplace, *Bs):
+        """res_inplace: `residual` is a buffer of this block's own (the copy kernels._RMSNormFork wrote, or - without autograd - the
+        previous block's output): the product is accumulated ONTO it (beta = 1, C == D) and it is returned, instead of copying it
+        into a fresh output first (what addmm(out=) does when out is another tensor: a [rows, d] device copy per residual add)."""
         width = xa.shape[-1]
         xa2 = xa.view(-1, width)
         N = Wc.shape[0]
-        out = torch.empty(*xa.shape[:-1], N, dtype=xa.dtype, device=xa.device)   # returned as-is (not a view): later
-        y = out.view(-1, N)                                                        # in-place kernels (RoPE) may dirty it
+        res_inplace = bool(res_inplace) and residual is not None and residual.is_contiguous()
+        if res_inplace:
+            out = residual
+            ctx.mark_dirty(residual)
+        else:
+            out = torch.empty(*xa.shape[:-1], N, dtype=xa.dtype, device=xa.device)   # returned as-is (not a view): later
+        y = out.view(-1, N)                                                            # in-place kernels (RoPE) may dirty it
         lora = A is not None
         if lora:
             Gr = A.shape[0]
@@ -102,6 +111,8 @@ class _LoraGroupFn(torch.autograd.Function):
             lhs, rhs = xa2[:, :K], Wc[:, :K]
         if residual is None:
             torch.mm(lhs, rhs.t(), out=y)
+        elif res_inplace:
+            y.addmm_(lhs, rhs.t())
         else:
             torch.addmm(residual.reshape(-1, N), lhs, rhs.t(), out=y)
         ctx.save_for_backward(xa)          # the input itself (its right columns were filled above), not the internal view
@@ -157,7 +168,7 @@ class _LoraGroupFn(torch.autograd.Function):
         else:
             dxa = torch.zeros(dy2.shape[0], xa2.shape[1], dtype=dy2.dtype, device=dy2.device)
             dxa[:, :K].copy_(torch.mm(dy2, Wc[:, :K]))
-        return (dxa.view(xa_shape), dy if has_res else None, None, None, dA, None, None, None, *dBs)
+        return (dxa.view(xa_shape), dy if has_res else None, None, None, dA, None, None, None, None, *dBs)
 
 
 class LoraTarget(nn.Module):
@@ -185,11 +196,16 @@ class RMSNormW(nn.Module):
     def forward(self, x, out_width=None):
         return K.rmsnorm(x, self.weight, self.variance_epsilon, out_width)
 
-    def fork(self, x, out_width=None):
-        """(norm(x), x) for a pre-norm residual block: hand the second result to the residual add (kernels._RMSNormFork)."""
-        if not (torch.is_grad_enabled() and x.requires_grad) or os.environ.get("HALVA_NORM_FORK", "1") == "0":
-            return K.rmsnorm(x, self.weight, self.variance_epsilon, out_width), x
-        return K.rmsnorm_fork(x, self.weight, self.variance_epsilon, out_width)
+    def fork(self, x, out_width=None, own_x=False):
+        """(norm(x), x', private) for a pre-norm residual block: hand x' to the residual add (kernels._RMSNormFork).  `private` says
+        that x' is a buffer the block may accumulate onto in place: the copy the fork kernel wrote (autograd path), or x itself when
+        the caller owns it and nothing will ask for it again (`own_x`, no autograd)."""
+        grad = torch.is_grad_enabled() and x.requires_grad
+        inplace = RES_INPLACE
+        if not grad or os.environ.get("HALVA_NORM_FORK", "1") == "0":
+            return K.rmsnorm(x, self.weight, self.variance_epsilon, out_width), x, (inplace and own_x and not grad)
+        h, xc = K.rmsnorm_fork(x, self.weight, self.variance_epsilon, out_width)
+        return h, xc, inplace
 
 
 class LoraGroup(nn.Module):
@@ -279,7 +295,7 @@ class LoraGroup(nn.Module):
             out[n + ".lora_B.default.weight"] = getattr(self, n).lora_B["default"].weight.data
         return out
 
-    def forward(self, xa, residual=None, use_lora=True):
+    def forward(self, xa, residual=None, use_lora=True, res_inplace=False):
         """xa: [.., in_width] operand buffer whose left `in` columns hold the input (right columns: scratch)."""
         if xa.shape[-1] != self.in_width:
             raise ValueError("LoraGroup expects an operand buffer of width %d, got %d" % (self.in_width, xa.shape[-1]))
@@ -288,8 +304,8 @@ class LoraGroup(nn.Module):
             if self._tail_versions != tuple(B._version for B in Bs):
                 self.refresh_tail()
             return _LoraGroupFn.apply(xa, residual, self.weight_cat, self.weight_cat_t, self.A_cat, self.scale, self.grad_sink,
-                                      self.in_features, *Bs)
-        return _LoraGroupFn.apply(xa, residual, self.weight_cat, None, None, 0.0, False, self.in_features)
+                                      self.in_features, res_inplace, *Bs)
+        return _LoraGroupFn.apply(xa, residual, self.weight_cat, None, None, 0.0, False, self.in_features, res_inplace)
 
 
 class SeqInfo:
@@ -320,16 +336,19 @@ class DecoderLayer(nn.Module):
     def groups(self):
         return (("self_attn", self.qkv), ("self_attn", self.o), ("mlp", self.gate_up), ("mlp", self.down))
 
-    def forward(self, x, info, use_lora=True):
+    def forward(self, x, info, use_lora=True, own_x=False):
+        """own_x: the caller will not look at `x` again (it is the previous layer's output): without autograd the residual adds then
+        run in place on it."""
         # every producer kernel writes straight into the (wider) operand buffer of the projection that follows it
-        # (norm(x), x) come out of one autograd node so that the residual's gradient is added inside the norm's backward kernel
-        h, x = self.input_layernorm.fork(x, self.qkv.in_width)
+        # (norm(x), x') come out of one autograd node so that the residual's gradient is added inside the norm's backward kernel, and
+        # x' is a buffer of the block's own: the o / down projections accumulate onto it (no copy of the residual)
+        h, x, mine = self.input_layernorm.fork(x, self.qkv.in_width, own_x)
         qkv = self.qkv(h, None, use_lora)
         a = K.attention(qkv, info.cos, info.sin, info.seq_start, info.seq_len, self.H, self.D, self.o.in_width, info.branch)
-        x = self.o(a, x, use_lora)
-        h, x = self.post_attention_layernorm.fork(x, self.gate_up.in_width)
+        x = self.o(a, x, use_lora, mine)
+        h, x, mine = self.post_attention_layernorm.fork(x, self.gate_up.in_width, True)      # (x is this block's own by now)
         act = K.swiglu(self.gate_up(h, None, use_lora), self.down.in_width)
-        return self.down(act, x, use_lora)
+        return self.down(act, x, use_lora, mine)
 
 
 class LlamaModel(nn.Module):
@@ -375,7 +394,7 @@ class LlamaModel(nn.Module):
             if self.gradient_checkpointing and torch.is_grad_enabled() and x.requires_grad:
                 x = torch.utils.checkpoint.checkpoint(layer, x, info, use_lora, use_reentrant=False)
             else:
-                x = layer(x, info, use_lora)
+                x = layer(x, info, use_lora, i > 0)      # from layer 1 on `x` is the previous layer's own output
         return self.norm(x)
 
 

@@ -318,8 +318,8 @@ class _BaseOnlyLayer(nn.Module):
         super().__init__()
         self._l = [layer]            # not registered: the tensors belong to the policy model
 
-    def forward(self, x, info, use_lora=False):
-        return self._l[0](x, info, False)
+    def forward(self, x, info, use_lora=False, own_x=False):
+        return self._l[0](x, info, False, own_x)
 
 
 class _FrozenProjectorView(nn.Module):

@@ -119,7 +119,7 @@ def test_rmsnorm_fork_sums_the_residual_gradient_in_the_kernel(rows, d, width):
     ((y * dy).sum() + (xr * dres).sum()).backward()
     xb = x.clone().requires_grad_(True)
     yb = K().rmsnorm(xb, w, 1e-5, width)
-    assert torch.equal(y[:, :d], yb[:, :d]) and torch.equal(xr, x)
+    assert torch.equal(y[:, :d], yb[:, :d]) and torch.equal(xr, x) and xr.data_ptr() != xa.data_ptr()      # a copy: the block accumulates onto it
     ((yb * dy).sum() + (xb * dres).sum()).backward()          # autograd: bf16(dx_norm) + dres, rounded to bf16
     assert torch.equal(xa.grad, xb.grad)
     xc = x.clone().requires_grad_(True)
