@@ -374,6 +374,17 @@ def main():
                  "aten::index", "aten::sigmoid", "aten::contiguous", "aten::_to_copy")
         if os.environ["HALVA_BENCH_TORCH_PROFILE"] == "mm":
             small = ("aten::mm", "aten::addmm", "aten::addmm_")
+        if os.environ["HALVA_BENCH_TORCH_PROFILE"] == "kernels":      # device time of ONE steady-state step by kernel name
+            ks = {}
+            for ev in prof.events():
+                if str(ev.device_type).endswith("CUDA"):
+                    t = ks.setdefault(ev.name[:110], [0.0, 0])
+                    t[0] += ev.device_time_total if hasattr(ev, "device_time_total") else ev.cuda_time_total
+                    t[1] += 1
+            tot = sum(v[0] for v in ks.values())
+            for k, v in sorted(ks.items(), key=lambda kv: -kv[1][0])[:40]:
+                print("%9.2f ms %5.2f%% %6d  %s" % (v[0] / 1e3, 100 * v[0] / tot, v[1], k), file=sys.stderr)
+            print("total device time of the step %.1f ms" % (tot / 1e3), file=sys.stderr)
         rows = [e for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=5) if e.key in small]
         rows.sort(key=lambda e: -e.self_device_time_total)
         for e in rows[:60]:
