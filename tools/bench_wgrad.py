@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from halva_amd import kernels as K
-rows = 27424
+rows = int(os.environ.get("ROWS", 54848))      # the 7B step: 16 pairs as one group (27424: groups of 8)
 def timeit(fn, n=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
