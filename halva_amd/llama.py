@@ -68,6 +68,9 @@ def _jsonable(v):
 DGRAD_TRANSPOSED_COPY = os.environ.get("HALVA_DGRAD_WT", "1") != "0"
 WGRAD_KERNEL = os.environ.get("HALVA_WGRAD_KERNEL", "1") != "0"      # LoRA weight gradients through halva_wgrad_accumulate
 RES_INPLACE = os.environ.get("HALVA_RES_INPLACE", "1") != "0"        # residual adds accumulate onto the block's own buffer (A/B: 0)
+# dgrad through the MERGED weight: the transposed copy holds (W + scale * B A)^T, so dx = dy (W + scale B A) comes out of the one
+# dgrad GEMM complete and the separate dx += (scale * dy B) A pass over [rows, in] is gone (A/B: 0)
+DGRAD_MERGED = os.environ.get("HALVA_DGRAD_MERGED", "1") != "0"
 K_ = K      # the kernels module under a name that _LoraGroupFn's local `K` (in_features) does not shadow
 
 LORA_TARGETS = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
@@ -86,7 +89,7 @@ class _LoraGroupFn(torch.autograd.Function):
     Base weight frozen: gradients for x, A, B only; with `sink` they are added into the fp32 `main_grad` views."""
 
     @staticmethod
-    def forward(ctx, xa, residual, Wc, WcT, A, scale, sink, K, res_inplace, *Bs):
+    def forward(ctx, xa, residual, Wc, WcT, A, scale, sink, K, res_inplace, merged, *Bs):
         """res_inplace: `residual` is a buffer of this block's own (the copy kernels._RMSNormFork wrote, or - without autograd - the
         previous block's output): the product is accumulated ONTO it (beta = 1, C == D) and it is returned, instead of copying it
         into a fresh output first (what addmm(out=) does when out is another tensor: a [rows, d] device copy per residual add)."""
@@ -117,14 +120,14 @@ class _LoraGroupFn(torch.autograd.Function):
             torch.addmm(residual.reshape(-1, N), lhs, rhs.t(), out=y)
         ctx.save_for_backward(xa)          # the input itself (its right columns were filled above), not the internal view
         ctx.params = (Wc, WcT, A, Bs)      # long-lived parameters: kept as objects so `.main_grad` stays reachable
-        ctx.meta = (scale, sink, residual is not None, K, xa.shape)
+        ctx.meta = (scale, sink, residual is not None, K, xa.shape, bool(merged) and WcT is not None)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         (xa,) = ctx.saved_tensors
         Wc, WcT, A, Bs = ctx.params
-        scale, sink, has_res, K, xa_shape = ctx.meta
+        scale, sink, has_res, K, xa_shape, merged = ctx.meta
         xa2 = xa.view(-1, xa.shape[-1])
         N = Wc.shape[0]
         dy2 = dy.reshape(-1, N)
@@ -164,11 +167,12 @@ class _LoraGroupFn(torch.autograd.Function):
                 A.main_grad.add_(gA)
             else:
                 dA = gA
-            dxa[:, :K].addmm_(da, A)                        # + the LoRA path's contribution to dx, in place
+            if not merged:                                  # (merged: WcT's base rows already hold (W + scale B A)^T, LoraGroup.refresh_tail)
+                dxa[:, :K].addmm_(da, A)                    # + the LoRA path's contribution to dx, in place
         else:
             dxa = torch.zeros(dy2.shape[0], xa2.shape[1], dtype=dy2.dtype, device=dy2.device)
             dxa[:, :K].copy_(torch.mm(dy2, Wc[:, :K]))
-        return (dxa.view(xa_shape), dy if has_res else None, None, None, dA, None, None, None, None, *dBs)
+        return (dxa.view(xa_shape), dy if has_res else None, None, None, dA, None, None, None, None, None, *dBs)
 
 
 class LoraTarget(nn.Module):
@@ -267,9 +271,14 @@ class LoraGroup(nn.Module):
 
     def build_dgrad_copy(self):
         """Second, transposed copy of the fused weight ([in + G r, N], +1x the frozen weights' memory): dx = dy Wc then runs
-        as an NT GEMM.  The LoRA tail rows are refreshed together with weight_cat's tail columns."""
+        as an NT GEMM.  The LoRA tail rows are refreshed together with weight_cat's tail columns; with DGRAD_MERGED its base rows
+        hold the merged weight (W + scale B A)^T (refresh_tail)."""
         self.weight_cat_t = self.weight_cat.data.t().contiguous()
         self._tail_versions = None
+
+    @property
+    def dgrad_merged(self):
+        return DGRAD_MERGED and self.weight_cat_t is not None and self.A_cat is not None
 
     def refresh_tail(self):
         """weight_cat[:, in:] = blockdiag(scale * B_g) (bf16; scale = alpha / r is a power of two in the reference recipe)."""
@@ -282,7 +291,14 @@ class LoraGroup(nn.Module):
                 if self.weight_cat_t is not None:
                     self.weight_cat_t[K + g * r:K + (g + 1) * r, off:off + n].copy_(sb.t())
                 off += n
-        self._tail_versions = tuple(B._version for B in self._Bs())
+            if self.dgrad_merged:
+                # rows [0, in) of the transposed copy <- (W + scale * B A)^T = W^T + A_cat^T blockdiag(scale B)^T: one [in x G r] x
+                # [G r x N] GEMM per group and optimizer step (3 TFLOP and 26 GB of traffic over the whole 7B model, ~8 ms) against
+                # a read-modify-write pass over [rows, in] per group and backward (~56 ms per step).  fp32 accumulate, ONE rounding
+                # to bf16 - dx differs from the two-GEMM form by bf16 noise; dA, dB are formed from the same operands as before.
+                G = len(self.names)
+                torch.addmm(self.weight_cat[:, :K].t(), self.A_cat.data.t(), self.weight_cat_t[K:K + G * r], out=self.weight_cat_t[:K])
+        self._tail_versions = tuple(B._version for B in self._Bs()) + (self.A_cat._version,)
 
     def lora_state(self):
         """{peft-style name: tensor} for this group's targets."""
@@ -301,11 +317,11 @@ class LoraGroup(nn.Module):
             raise ValueError("LoraGroup expects an operand buffer of width %d, got %d" % (self.in_width, xa.shape[-1]))
         if self.A_cat is not None and use_lora:
             Bs = self._Bs()
-            if self._tail_versions != tuple(B._version for B in Bs):
+            if self._tail_versions != tuple(B._version for B in Bs) + (self.A_cat._version,):
                 self.refresh_tail()
             return _LoraGroupFn.apply(xa, residual, self.weight_cat, self.weight_cat_t, self.A_cat, self.scale, self.grad_sink,
-                                      self.in_features, res_inplace, *Bs)
-        return _LoraGroupFn.apply(xa, residual, self.weight_cat, None, None, 0.0, False, self.in_features, res_inplace)
+                                      self.in_features, res_inplace, self.dgrad_merged, *Bs)
+        return _LoraGroupFn.apply(xa, residual, self.weight_cat, None, None, 0.0, False, self.in_features, res_inplace, False)
 
 
 class SeqInfo:
