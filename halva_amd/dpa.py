@@ -31,12 +31,15 @@ IGNORE_INDEX = -100
 LOGIT_CHUNK_ROWS = 8192            # 8192 x 32000 bf16 = 0.5 GB of transient logits
 # token log-probs from fp32 logits (the GEMM accumulates in fp32 anyway; this only skips the rounding of its output to bf16)
 LOGITS_F32 = os.environ.get("HALVA_LOGITS_F32", "0") == "1"
+# keep the response rows' bf16 logits from the forward for the backward (rows x vocab x 2 B: 2.9 GB for the 7B step's 45 k response
+# rows - HBM is there) instead of recomputing them with one more lm_head GEMM per chunk; "0" = recompute (round 1's behaviour)
+KEEP_LOGITS = os.environ.get("HALVA_KEEP_LOGITS", "1") != "0"
 
 
 class _LmHeadLogp(torch.autograd.Function):
     """log p(target) for rows of hidden states: lm_head (modelling_llama.py:801-806) fused chunk-wise with
-    log_softmax + gather (halva_trainer.py:406-407).  Backward recomputes the chunk's logits (1 extra lm_head GEMM,
-    2 % of a sequence forward) and turns them in place into dlogits, then dh = dlogits @ W."""
+    log_softmax + gather (halva_trainer.py:406-407).  Backward turns the chunk's logits - kept from the forward (KEEP_LOGITS), or
+    recomputed with one more lm_head GEMM (2 % of a sequence forward) - in place into dlogits, then dh = dlogits @ W."""
 
     @staticmethod
     def forward(ctx, h, W, target):
@@ -45,6 +48,7 @@ class _LmHeadLogp(torch.autograd.Function):
         logp = torch.empty(R, dtype=torch.float32, device=h.device)
         lse = torch.empty(R, dtype=torch.float32, device=h.device)
         st = stream_ptr()
+        kept = [] if (KEEP_LOGITS and not LOGITS_F32 and ctx.needs_input_grad[0]) else None
         for c0 in range(0, R, LOGIT_CHUNK_ROWS):
             c1 = min(R, c0 + LOGIT_CHUNK_ROWS)
             if LOGITS_F32:
@@ -53,8 +57,11 @@ class _LmHeadLogp(torch.autograd.Function):
                 continue
             logits = torch.mm(h[c0:c1], W.t())
             call("halva_token_logp_fwd", ptr(logits), BF16, V, ptr(target[c0:c1]), ptr(logp[c0:c1]), ptr(lse[c0:c1]), c1 - c0, V, st)
+            if kept is not None:
+                kept.append(logits)
         ctx.save_for_backward(h, target, lse)
         ctx.W = W
+        ctx.kept = kept
         return logp
 
     @staticmethod
@@ -65,12 +72,15 @@ class _LmHeadLogp(torch.autograd.Function):
         g = g.contiguous().float()
         dh = torch.empty_like(h)
         st = stream_ptr()
-        for c0 in range(0, h.shape[0], LOGIT_CHUNK_ROWS):
+        kept, ctx.kept = ctx.kept, None
+        for k, c0 in enumerate(range(0, h.shape[0], LOGIT_CHUNK_ROWS)):
             c1 = min(h.shape[0], c0 + LOGIT_CHUNK_ROWS)
-            logits = torch.mm(h[c0:c1], W.t())
+            logits = kept[k] if kept is not None else torch.mm(h[c0:c1], W.t())      # (the same bf16 values either way)
             call("halva_token_logp_bwd", ptr(logits), BF16, V, ptr(target[c0:c1]), ptr(lse[c0:c1]), ptr(g[c0:c1]), ptr(logits),
                  c1 - c0, V, st)
             torch.mm(logits, W, out=dh[c0:c1])
+            if kept is not None:
+                kept[k] = None      # a chunk's 0.5 GB go back as soon as its dh exists
         return dh, None, None
 
 
