@@ -291,6 +291,7 @@ def main():
         raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d" % (args.gpus, ctx.world))
     torch.cuda.set_device(ctx.local_rank)
     dev = torch.device("cuda", ctx.local_rank)
+    dp.barrier(ctx)      # N > 1: RCCL builds its communicator (and allocates its buffers) now, while the HBM is still empty
     if os.environ.get("HALVA_BENCH_MEM_FRACTION"):      # diagnostic: cap this process's share of the HBM (exercises the out-of-memory fall-back)
         torch.cuda.set_per_process_memory_fraction(float(os.environ["HALVA_BENCH_MEM_FRACTION"]), ctx.local_rank)
 
@@ -471,6 +472,7 @@ def main():
                "tflop_per_pair": None if tf_pair is None else {"reference_equivalent": tf_pair, "executed": round(tf_exec, 1)},
                "grad_allreduce": comm,
                "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+               "peak_mem_reserved_gb": round(torch.cuda.max_memory_reserved() / 2 ** 30, 1),
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(rec), flush=True)
     if ctx.world > 1:
