@@ -266,7 +266,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs-per-gpu", type=int, default=0, help="default 16 (7b, 13b) / 8 (vila13b)")
+    ap.add_argument("--pairs-per-gpu", type=int, default=0,
+                    help="pairs per GPU and step.  Default at N = 1: 16 (7b, 13b) / 8 (vila13b) = BASELINE configs[1]; at N > 1: "
+                         "--global-pairs / N (the reference recipe's global batch, configs[2]).  Giving it explicitly at N > 1 "
+                         "selects weak scaling (e.g. 16 per GPU at every N)")
+    ap.add_argument("--global-pairs", type=int, default=64,
+                    help="N > 1 only: pairs per optimizer step over ALL ranks (reference src/hallava_7b.sh:21-22: 4 GPUs x 4 per "
+                         "device x 4 accumulation steps = 64), split evenly over the ranks")
     ap.add_argument("--model", default="7b", choices=["7b", "13b", "vila13b"],
                     help="7b = BASELINE configs[1] (the metric); 13b / vila13b = configs[3] / configs[4] geometry (extra workloads)")
     ap.add_argument("--layers", type=int, default=0, help="debug: override the layer count (result is then marked invalid)")
@@ -293,17 +299,28 @@ def main():
     dev = torch.device("cuda", ctx.local_rank)
     dp.barrier(ctx)      # N > 1: RCCL builds its communicator (and allocates its buffers) now, while the HBM is still empty
     if os.environ.get("HALVA_BENCH_MEM_FRACTION"):      # diagnostic: cap this process's share of the HBM (exercises the out-of-memory fall-back)
-        torch.cuda.set_per_process_memory_fraction(float(os.environ["HALVA_BENCH_MEM_FRACTION"]), ctx.local_rank)
+        # "0.3" = every rank, "1:0.3" = rank 1 only (the collective fall-back must cope with ONE rank running out of memory)
+        spec = os.environ["HALVA_BENCH_MEM_FRACTION"]
+        only, frac = (int(spec.split(":")[0]), float(spec.split(":")[1])) if ":" in spec else (None, float(spec))
+        if only is None or only == ctx.rank:
+            torch.cuda.set_per_process_memory_fraction(frac, ctx.local_rank)
 
     geo = dict(LLAMA_7B if args.model == "7b" else LLAMA_13B)
     if args.layers:
         geo["num_hidden_layers"] = args.layers
     vila = args.model == "vila13b"
     seq = 4096 if vila else 2048
+    weak = bool(args.pairs_per_gpu) or ctx.world == 1      # per-GPU work fixed by the caller (or a single GPU)
     if not args.pairs_per_gpu:
-        args.pairs_per_gpu = 8 if vila else 16
+        if ctx.world == 1:
+            args.pairs_per_gpu = 8 if vila else 16
+        else:      # BASELINE configs[2]: the recipe's global batch (64 pairs per optimizer step) split over the ranks
+            args.pairs_per_gpu = max(1, args.global_pairs // ctx.world)
     if not args.pairs_per_group:
-        args.pairs_per_group = {"7b": 16, "13b": 4, "vila13b": 2}[args.model]      # 7B: the whole 16-pair batch as ONE group (288 GB of HBM)
+        # 7B on one GPU: the whole 16-pair batch as ONE group (265 of 288 GiB).  With N > 1 RCCL's own buffers and its kernels' scratch
+        # share the HBM: groups of 8 pairs (174 GiB, 40 % free) unless the caller says otherwise.
+        args.pairs_per_group = {"7b": 16 if ctx.world == 1 else 8, "13b": 4, "vila13b": 2}[args.model]
+    args.pairs_per_group = min(args.pairs_per_group, args.pairs_per_gpu)
     if vila:
         from halva_amd.vila_model import build_random_vila
         policy = build_random_vila(geo, SIGLIP_SO400M_384, lora_r=128, lora_alpha=256, seed=1234, device=dev, max_len=seq)
@@ -336,38 +353,53 @@ def main():
     reducer = dp.GradReducer.for_flat(flat, ctx) if ctx.world > 1 else None
     comm_probe = []
 
+    exchanged = [True]
+
     def step():
+        exchanged[0] = reducer is None
         flat.zero_grad()
         loss = eng.loss(batch, backward=True, reducer=reducer)
         if reducer is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             reducer.finish()
+            exchanged[0] = True
             e1.record()
             comm_probe.append((e0, e1, reducer.issued_early))
         opt.step()
         return loss
 
-    oom = False
-    try:
-        for _ in range(args.warmup):
+    # Warm-up.  The 7B single-GPU default keeps the whole 16-pair batch as one group (265 of the 288 GiB).  Should a box have less free
+    # (another tenant, a larger runtime footprint, RCCL's buffers), halve the groups BEFORE anything is timed.  With N > 1 the decision
+    # is COLLECTIVE: a rank that runs out of memory mid-step has already handed some gradient buckets to RCCL while the others hand
+    # over all of theirs, so it first completes that exchange (GradReducer.drain: the same collectives, contents discarded), then
+    # every rank joins a MAX all-reduce of the flag after EVERY warm-up step and all of them switch together.
+    oom_fallbacks = 0
+    done, need = 0, args.warmup
+    while done < need:
+        oom = False
+        try:
             last = step()
-    except torch.cuda.OutOfMemoryError:
-        oom = True      # (handled below: inside the handler the traceback still pins the failed step's tensors)
-    if oom:
-        # The 7B default keeps the whole 16-pair batch as one group (265 of the 288 GiB).  Should this box have less free (another
-        # tenant, a larger runtime footprint), halve the groups BEFORE anything is timed: every timed step then runs the smaller setting.
-        if args.pairs_per_group <= 1:
-            raise SystemExit("bench.py: out of memory with one pair per group")
-        args.pairs_per_group = max(1, args.pairs_per_group // 2)
-        eng.pairs_per_group, eng.ref_rows_per_group = args.pairs_per_group, 2 * args.pairs_per_group
-        import gc
-        gc.collect()
-        flat.zero_grad()
-        torch.cuda.empty_cache()
-        print("bench: out of memory in the warm-up; continuing with %d pairs per group" % args.pairs_per_group, file=sys.stderr)
-        for _ in range(max(1, args.warmup)):
-            last = step()
+        except torch.cuda.OutOfMemoryError:
+            oom = True      # (handled below: inside the handler the traceback still pins the failed step's tensors)
+        if oom and reducer is not None and not exchanged[0]:
+            reducer.drain()
+        if dp.max_scalar(1.0 if oom else 0.0, ctx) > 0:
+            if args.pairs_per_group <= 1:
+                raise SystemExit("bench.py: out of memory with one pair per group")
+            args.pairs_per_group = max(1, args.pairs_per_group // 2)
+            eng.pairs_per_group, eng.ref_rows_per_group = args.pairs_per_group, 2 * args.pairs_per_group
+            import gc
+            gc.collect()
+            flat.zero_grad()
+            torch.cuda.empty_cache()
+            oom_fallbacks += 1
+            done, need = 0, max(1, args.warmup)
+            if ctx.rank == 0:
+                print("bench: out of memory in the warm-up (%s); every rank continues with %d pairs per group"
+                      % ("this rank" if oom else "another rank", args.pairs_per_group), file=sys.stderr)
+            continue
+        done += 1
     if os.environ.get("HALVA_BENCH_TORCH_PROFILE"):      # diagnostic: where do the non-GEMM, non-HIP kernels of a step come from
         from torch.profiler import profile, ProfilerActivity
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
@@ -422,7 +454,8 @@ def main():
         comm = {"bytes_per_step": int(flat.grad.numel() * 4), "buckets": len(reducer.buckets) + (reducer.late is not None),
                 "buckets_issued_inside_backward": comm_probe[-1][2],
                 "exposed_ms_per_step": round(sum(a.elapsed_time(b) for a, b, _ in comm_probe) / len(comm_probe), 3),
-                "backend": torch.distributed.get_backend(),
+                "backend": torch.distributed.get_backend(), "world": torch.distributed.get_world_size(),
+                "ranks_on_distinct_gpus": os.environ.get("HALVA_SHARE_GPU") != "1",
                 "note": "exposed = compute-stream time between the end of the last backward and the averaged gradient being ready "
                         "(rank 0); the buckets of the upper layers are reduced while the lower layers are still being differentiated"}
     if ctx.rank == 0:
@@ -444,15 +477,21 @@ def main():
                   "vila13b": "paired-samples/sec (DPA step) VILA-13B @384px T=4096 (extra workload, not the BASELINE metric)"}[args.model]
         rec = {"metric": metric, "value": round(pairs_per_s, 4),
                "unit": "paired-samples/sec", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+               # N > 1 default: the recipe's GLOBAL batch (64 pairs per optimizer step) split over the ranks = total work fixed
+               "scaling": "weak" if weak else "strong", "vs_baseline": None,
                "dtype": "bf16", "data": "synthetic (BASELINE.md section 3), random-init weights",
                "config": {"workload": ("configs[4]: VILA-13B geometry (Llama-13B + SigLIP-so400m-384 + mlp_downsample, 196 image tokens) "
                                        "LoRA(r=128) DPA step, T=%d post-splice, %d pairs per GPU per step (EXTRA workload, not the "
                                        "BASELINE metric)" % (seq, B)) if vila else
-                                      ("configs[%d]: LLaVA-1.5-%s LoRA(r=128) DPA step, 336px, T=2048 post-splice, %d pairs per GPU per "
-                                       "step (fwd+bwd+loss+grad all-reduce+AdamW)" % (1 if args.model == "7b" else 3, args.model.upper(), B)),
+                                      ("configs[%d]: LLaVA-1.5-%s LoRA(r=128) DPA step, 336px, T=2048 post-splice, %s"
+                                       "(fwd+bwd+loss+grad all-reduce+AdamW)"
+                                       % ((1 if ctx.world == 1 else 2) if args.model == "7b" else 3, args.model.upper(),
+                                          "%d pairs per GPU per step " % B if weak else
+                                          "global batch %d pairs per optimizer step over %d GPUs = %d pairs per GPU per step "
+                                          % (B * ctx.world, ctx.world, B))),
                           "pairs_per_gpu": B, "global_pairs": B * ctx.world, "seq_len": seq if not args.resp_len else n_patch + 53 + args.resp_len, "parallelism": "dp%d" % ctx.world,
-                          "pairs_per_group": args.pairs_per_group, "recompute": "none",
+                          "pairs_per_group": args.pairs_per_group, "oom_fallbacks_in_warmup": oom_fallbacks, "recompute": "none",
                           "prefix_sharing": None if eng.last_packing is None else
                           {"rows_run": eng.last_packing[0], "rows_of_the_two_separate_sequences": eng.last_packing[1],
                            "note": "the correct and the hallucinated row of a pair share ONE pass over their common prefix "

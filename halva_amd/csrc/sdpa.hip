@@ -418,6 +418,11 @@ __device__ __forceinline__ void fwd_tile(const char* kt, const char* vt, const s
         FENCE();
     }
     mask_half<MASK, CAUSAL>(s1, kv0 + 32, h, len, ql);
+#ifndef HALVA_FWD_NO_PIN
+    // P0 and its row sums are dead on the rare path below (which recomputes them), so LLVM sinks the whole exponential block out of
+    // the S1 chain into the common successor - behind the chain, where no MFMA covers it.  Pin the values where they are produced.
+    asm volatile("" : "+v"(p0a), "+v"(p0b), "+v"(ps0));
+#endif
     float sum0 = ps0[0] + ps0[1];
     const float tmax = xhalf_max(fmaxf(fmaxf(mx0a, mx0b), half_max(s1))) * sc;
     STAMP(2);

@@ -101,18 +101,35 @@ def allreduce_mean_(flat, ctx):
     return flat
 
 
+_DECODER_LAYER = re.compile(r"(?:^|\.)layers\.(\d+)\.")
+
+
+def _is_projector_name(n):
+    return "mm_projector" in n
+
+
 def layer_boundaries(names, offsets):
-    """({layer index: first flat element of that layer's parameters}, first element of the tail without a layer index) from
-    FlatTrainables' names/offsets ("...layers.<i>....").  The tail is the projector: it sits BEHIND the last layer in the buffer
-    but its gradient is the LAST thing a backward produces (below layer 0), so it can only be exchanged at the end."""
+    """({decoder layer index: first flat element of that layer's parameters}, first element of the tail behind the layers) from
+    FlatTrainables' names/offsets ("...model.layers.<i>....").  The tail is the projector: it sits BEHIND the last layer in the
+    buffer but its gradient is the LAST thing a backward produces (below layer 0), so it can only be exchanged at the end.
+    Only DECODER layers count: VILA's projector tensors are called `mm_projector.layers.{1,2,4}.*` (halva_amd/vila_model.py) and
+    must land in the tail, not in a bucket that is handed to RCCL while their gradient does not exist yet.  The layout is
+    validated: layer offsets strictly increasing with the layer index, every projector tensor inside the tail."""
     first, tail = {}, None
     for n, o in zip(names, offsets):
-        m = re.search(r"layers\.(\d+)\.", n)
+        m = None if _is_projector_name(n) else _DECODER_LAYER.search(n)
         if m:
+            if tail is not None:
+                raise ValueError("flat buffer layout: decoder tensor %r behind the non-layer tail" % n)
             first.setdefault(int(m.group(1)), int(o))
-            tail = None
         elif tail is None:
             tail = int(o)
+    idx = sorted(first)
+    if any(first[a] >= first[b] for a, b in zip(idx, idx[1:])):
+        raise ValueError("flat buffer layout: decoder layers are not laid out in increasing order: %r" % (first,))
+    for n, o in zip(names, offsets):
+        if _is_projector_name(n) and (tail is None or int(o) < tail):
+            raise ValueError("flat buffer layout: projector tensor %r is not inside the late tail" % n)
     return first, tail
 
 
@@ -145,6 +162,7 @@ class GradReducer:
             self.buckets.append((0, hi))
         self._next = 0
         self._fins = []
+        self._open = False                     # between begin() and finish()
         self.issued_early = 0
 
     @classmethod
@@ -156,7 +174,32 @@ class GradReducer:
         return r
 
     def begin(self):
-        self._next, self._fins, self.issued_early = 0, [], 0
+        """Start a step's exchange.  An exchange left open by an attempt that never reached finish() (an exception in the
+        backward, e.g. out of memory) is completed first - see drain(): dropping its handles would let this step's buckets pair
+        with the stale ones on the other ranks."""
+        if self._open:
+            self.drain()
+        self._next, self._fins, self.issued_early, self._open = 0, [], 0, True
+
+    def drain(self):
+        """Complete the exchange of a step that failed on THIS rank before its finish(): hand over every bucket not handed over
+        yet (all of them when the step failed before begin()), in finish()'s order, so that each collective pairs with the one
+        the healthy ranks issue from their backward / finish(); wait for all of them; leave the buffer's contents undefined (no
+        division: the caller zeroes it and repeats the step).  Afterwards every rank has taken part in exactly the collectives
+        of one finish(), i.e. the ranks are in step again and can agree on what to do next (bench.py: MAX of an "out of
+        memory" flag).  Must not be called for a step whose finish() has returned."""
+        if not self._open:
+            self._next, self._fins = 0, []
+        if self.ctx.world > 1:
+            while self._next < len(self.buckets):
+                self._issue(*self.buckets[self._next])
+                self._next += 1
+            if self.late is not None:
+                self._issue(*self.late)
+        fins, self._fins = self._fins, []
+        for f in fins:
+            f()
+        self._open = False
 
     def layer_done(self, i):
         """The backward has produced the gradient of decoder layer i's input: layers >= i are final."""
@@ -177,7 +220,10 @@ class GradReducer:
 
     def finish(self):
         if self.ctx.world == 1:
+            self._open = False
             return self.g
+        if not self._open:                     # a step without begin() (no reducer handed to the backward): exchange everything now
+            self._next, self._fins, self.issued_early = 0, [], 0
         while self._next < len(self.buckets):
             self._issue(*self.buckets[self._next])
             self._next += 1
@@ -186,6 +232,7 @@ class GradReducer:
         for f in self._fins:
             f()
         self._fins = []
+        self._open = False
         self.g.div_(self.ctx.world)
         return self.g
 

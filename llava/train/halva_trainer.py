@@ -324,6 +324,14 @@ class HalvaTrainer:
                 for old in self._checkpoint_dirs()[:-limit]:
                     import shutil
                     shutil.rmtree(old, ignore_errors=True)
+        # An end-of-epoch checkpoint can fall INSIDE an accumulation group (micro-batches are counted across epochs, 4.31's
+        # total_batched_samples): the fp32 accumulator then holds the group's first micro-batches, which the resumed run must not lose.
+        # Every rank's accumulator is its own (nothing has been exchanged yet), so every rank writes its own file.
+        accum = max(1, int(getattr(a, "gradient_accumulation_steps", 1)))
+        if self._pos["total"] % accum != 0:
+            dp.barrier(self.dist)                                 # (rank 0 has created the folder)
+            torch.save({"grad": self._flat.grad.detach().cpu(), "pending_micro": self._pos["total"] % accum},
+                       os.path.join(folder, "halva_pending_grad_rank%d.pt" % self.dist.rank))
         dp.barrier(self.dist)
         return folder
 
@@ -351,7 +359,22 @@ class HalvaTrainer:
         self.optimizer.load_state_dict(st["optimizer"])
         self.state.global_step = int(st["global_step"])
         self.state.log_history = list(st.get("log_history", []))
+        st["_folder"] = folder
         return st
+
+    def _restore_pending_gradient(self, st, accum):
+        """The accumulator of a checkpoint written inside an accumulation group (see _save_checkpoint); call after zero_grad()."""
+        pending = int(st["micro_total"]) % accum
+        if pending == 0:
+            return
+        path = os.path.join(st["_folder"], "halva_pending_grad_rank%d.pt" % self.dist.rank)
+        if not os.path.exists(path):
+            raise FileNotFoundError("%s was written %d micro-batch(es) into an accumulation group but holds no %s: the resumed "
+                                    "optimizer step would miss them" % (st["_folder"], pending, os.path.basename(path)))
+        g = torch.load(path, map_location="cpu", weights_only=False)
+        if int(g["pending_micro"]) != pending or g["grad"].numel() != self._flat.grad.numel():
+            raise RuntimeError("%s does not match the checkpoint's position / trainable tensors" % path)
+        self._flat.grad.copy_(g["grad"])
 
     def _should_save(self, end_of_epoch):
         a = self.args
@@ -391,6 +414,8 @@ class HalvaTrainer:
         done = False
         total_micro = int(resume["micro_total"]) if resume is not None else 0
         self._flat.zero_grad()
+        if resume is not None:
+            self._restore_pending_gradient(resume, accum)
         for epoch in range(n_epochs):
             if resume is not None and epoch < resume["epoch_index"]:
                 continue

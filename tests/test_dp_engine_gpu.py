@@ -116,6 +116,34 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     assert rec["grad_allreduce"]["buckets_issued_inside_backward"] >= 1
 
 
+def test_bench_out_of_memory_on_one_rank_is_a_collective_decision(tmp_path):
+    """Rank 1 alone gets too small a share of the HBM for the requested group size (HALVA_BENCH_MEM_FRACTION=1:<f>) and runs out of
+    memory inside the warm-up step, after rank 0 (and possibly itself) has handed gradient buckets to the backend.  The fall-back must be
+    collective: rank 1 completes the exchange (GradReducer.drain), both ranks see the MAX of the flag, both halve their groups and the
+    run ends with one valid JSON line - no hang, no mismatched collectives.  Reference: one process per GPU, gradients averaged once per
+    optimizer step (src/hallava_7b.sh:30, llava/train/halva_trainer.py:261-272)."""
+    import json
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 2:
+        env["HALVA_BENCH_SHARE_GPU"] = "1"
+    total = torch.cuda.get_device_properties(0).total_memory
+    # two layers of the 7B geometry: weights + optimizer state ~ 3 GiB; a group of 4 pairs needs ~ 9 GiB of activations on top, a
+    # group of 1 pair ~ 2.5 GiB.  11 GiB therefore fails with groups of 4 and fits after the fall-back(s).
+    env["HALVA_BENCH_MEM_FRACTION"] = "1:%.5f" % (11 * 2 ** 30 / total)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--layers", "2",
+                        "--pairs-per-gpu", "4", "--pairs-per-group", "4", "--no-cpu-baseline", "--no-roofline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["config"]["oom_fallbacks_in_warmup"] >= 1, (rec["config"], r.stderr[-2000:])
+    assert rec["config"]["pairs_per_group"] < 4 and rec["n_gpus"] == 2 and rec["value"] > 0
+    assert "another rank" in r.stderr or "this rank" in r.stderr
+
+
 def test_deepspeed_shim_two_ranks_train_like_one_rank_with_accumulation(tmp_path):
     """`deepspeed --num_gpus 2 train_halva.py ...` (the reference's launch line, src/hallava_7b.sh:30, through bin/deepspeed): two rank
     processes, each taking every second batch of the sampler (llava/train/halva_trainer.py:261-272), gradients averaged inside the

@@ -82,6 +82,55 @@ def _worker(rank, world, port, out):
     red.finish()
     assert torch.allclose(_Flat.grad, torch.full((100,), 1.5))
     assert dp.max_scalar(float(rank), ctx) == 1.0
+    # 2c. VILA names its projector tensors `mm_projector.layers.N.*` (halva_amd/vila_model.py): they are NOT decoder layers - they
+    #     must end up in the late tail, never in a bucket that leaves from inside the backward (round-2 advisor finding)
+    class _Vila:
+        names = ["llm.base_model.model.model.layers.0.q.lora_A", "llm.base_model.model.model.layers.1.q.lora_A",
+                 "mm_projector.layers.2.weight", "mm_projector.layers.4.weight", "mm_projector.layers.1.weight",
+                 "mm_projector.layers.1.bias", "mm_projector.layers.2.bias", "mm_projector.layers.4.bias"]
+        offsets = [0, 30, 60, 70, 80, 85, 90, 95, 100]
+        grad = torch.ones(100) * (rank + 1)
+    first, tail = dp.layer_boundaries(_Vila.names, _Vila.offsets[:-1])
+    assert first == {0: 0, 1: 30} and tail == 60
+    red = dp.GradReducer.for_flat(_Vila, ctx, min_bucket=1)
+    assert red.buckets == [(30, 60), (0, 30)] and red.late == (60, 100)
+    red.begin()
+    red.layer_done(1)
+    red.layer_done(0)
+    _Vila.grad[60:] += 1.0               # the projector gradient arrives after the last decoder layer's
+    red.finish()
+    assert torch.allclose(_Vila.grad[:60], torch.full((60,), 1.5)) and torch.allclose(_Vila.grad[60:], torch.full((40,), 2.5))
+    for bad in (["model.layers.1.a", "model.layers.0.a"],                            # layers out of order
+                ["model.layers.0.a", "model.mm_projector.0.weight", "model.layers.1.a"]):     # a decoder tensor behind the tail
+        try:
+            dp.layer_boundaries(bad, list(range(0, 10 * len(bad), 10)))
+            raise AssertionError("layout %r accepted" % (bad,))
+        except ValueError:
+            pass
+    # 2d. a step that fails on ONE rank after it has handed over some buckets (out of memory inside the last backward): that rank
+    #     completes the exchange with drain() - the same collectives the healthy rank issues from its backward / finish() - then both
+    #     agree through a MAX all-reduce and repeat the step; the repeated step's mean is exact (nothing paired with a stale bucket)
+    redf = dp.GradReducer.for_flat(_Flat, ctx, min_bucket=1)
+    for fail_after in (0, 1, 2, "before_begin"):
+        _Flat.grad.fill_(rank + 1.0)
+        failed = rank == 1
+        if not (failed and fail_after == "before_begin"):      # (e.g. out of memory in the first group: begin() never ran)
+            redf.begin()
+            for k, layer in enumerate((1, 0)):
+                if failed and fail_after == k:
+                    break
+                redf.layer_done(layer)
+        if failed:
+            redf.drain()
+        else:
+            redf.finish()
+        assert dp.max_scalar(1.0 if failed else 0.0, ctx) == 1.0
+        _Flat.grad.fill_(rank + 1.0)      # every rank repeats the step
+        redf.begin()
+        redf.layer_done(1)
+        redf.layer_done(0)
+        redf.finish()
+        assert torch.allclose(_Flat.grad, torch.full((100,), 1.5)), fail_after
     b = torch.full((5,), float(rank + 7))
     dp.broadcast_(b, ctx)
     assert torch.equal(b, torch.full((5,), 7.0))
