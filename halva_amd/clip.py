@@ -206,20 +206,50 @@ def build_vision_tower(vision_tower_cfg, **kwargs):
 
 
 class Projector(nn.Sequential):
-    """nn.Sequential(Linear, GELU, Linear) with the reference's parameter names (`mm_projector.0.weight` ...) whose
-    forward runs the fused MFMA kernels (reference multimodal_projector/builder.py:39-46)."""
+    """The reference's projectors with the reference's parameter names (`mm_projector.0.weight` ...): `mlp<N>x_gelu` =
+    nn.Sequential(Linear, (GELU, Linear) x (N-1)) (multimodal_projector/builder.py:39-46); forward runs the fused MFMA GEMMs."""
 
     def forward(self, x):
-        if len(self) == 3 and isinstance(self[0], nn.Linear) and isinstance(self[2], nn.Linear):
-            x = x.to(self[0].weight.dtype)             # the tower hands features back in the images' dtype
-            return K.projector_mlp(x, self[0].weight, self[0].bias, self[2].weight, self[2].bias)
-        raise NotImplementedError("only mlp2x_gelu is on the DPA hot path")
+        lin = [m for m in self if isinstance(m, nn.Linear)]
+        if len(self) != 2 * len(lin) - 1 or any(not isinstance(m, nn.GELU) for m in list(self)[1::2]):
+            raise NotImplementedError("Projector: expected Linear (GELU Linear)*")
+        x = x.to(lin[0].weight.dtype)                  # the tower hands features back in the images' dtype
+        if len(lin) == 2:                              # mlp2x_gelu: the shipped recipe (src/hallava_7b.sh:39)
+            return K.projector_mlp(x, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias)
+        return K.projector_chain(x, lin)
+
+
+class LinearProjector(nn.Linear):
+    """mm_projector_type 'linear' (multimodal_projector/builder.py:36-37): one nn.Linear (parameter names `mm_projector.weight/.bias`)."""
+
+    def forward(self, x):
+        return K.projector_chain(x.to(self.weight.dtype), [self])
+
+
+class IdentityMap(nn.Module):
+    """mm_projector_type 'identity' (multimodal_projector/builder.py:6-16)."""
+
+    def forward(self, x, *args, **kwargs):
+        return x
+
+    @property
+    def config(self):
+        return {"mm_projector_type": "identity"}
 
 
 def build_vision_projector(config, dtype=torch.bfloat16, device="cuda", **kwargs):
+    """reference llava/model/multimodal_projector/builder.py:33-51: 'linear', 'mlp<N>x_gelu', 'identity'; anything else raises
+    the reference's ValueError."""
     kind = getattr(config, "mm_projector_type", "linear")
+    if kind == "linear":
+        return LinearProjector(config.mm_hidden_size, config.hidden_size, dtype=dtype, device=device)
     m = re.match(r"^mlp(\d+)x_gelu$", kind)
-    if not m or int(m.group(1)) != 2:
-        raise ValueError("Unsupported projector type on the MI355X DPA path: %s (the reference script uses mlp2x_gelu)" % kind)
-    return Projector(nn.Linear(config.mm_hidden_size, config.hidden_size, dtype=dtype, device=device), nn.GELU(),
-                     nn.Linear(config.hidden_size, config.hidden_size, dtype=dtype, device=device))
+    if m:
+        depth = int(m.group(1))
+        mods = [nn.Linear(config.mm_hidden_size, config.hidden_size, dtype=dtype, device=device)]
+        for _ in range(1, depth):
+            mods += [nn.GELU(), nn.Linear(config.hidden_size, config.hidden_size, dtype=dtype, device=device)]
+        return Projector(*mods)
+    if kind == "identity":
+        return IdentityMap()
+    raise ValueError("Unknown projector type: %s" % kind)

@@ -26,7 +26,36 @@ __global__ void probe_kernel(int32_t* out) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     for (int i = 0; i < 16; ++i) out[256 + lane * 16 + i] = (int)c[i];
 }
+// In-kernel shader clock: s_memtime counts shader cycles, s_memrealtime a constant 100 MHz reference, so their ratio over a short spin
+// is the clock the CU runs at WHILE whatever else is on the chip runs (MI355X_MICROARCH.md, DVFS give-back item 6: board power and sysfs
+// pp_dpm_sclk are not the test).  One wave per block; out[4 b + {0, 1, 2, 3}] = {shader cycles, 100 MHz ticks, start tick, XCC id}.
+__global__ void clock_probe_kernel(unsigned long long* out, int spin_ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < (unsigned long long)spin_ticks) {
+        __builtin_amdgcn_s_sleep(8);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    out[4 * blockIdx.x + 0] = c1 - c0;
+    out[4 * blockIdx.x + 1] = r1 - r0;
+    out[4 * blockIdx.x + 2] = r0;
+    out[4 * blockIdx.x + 3] = xcc & 0xf;
+}
 }  // namespace
+
+extern "C" int halva_clock_probe(uint64_t* out, int blocks, int spin_ticks, void* stream) {
+    HALVA_CHECK_ARG(out && blocks > 0 && blocks <= 1024 && spin_ticks > 0 && spin_ticks <= 100000000,
+                    "clock_probe: out=%p blocks=%d spin_ticks=%d", (void*)out, blocks, spin_ticks);
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out, spin_ticks);
+    HALVA_CHECK_LAUNCH("clock_probe");
+    return HALVA_OK;
+}
 
 extern "C" int halva_probe_layouts(int32_t* out, int n, void* stream) {
     HALVA_CHECK_ARG(out && n >= 256 + 1024, "probe_layouts: need %d ints", 256 + 1024);

@@ -20,6 +20,8 @@
 // No atomics: dQ has its own kernel, so results are bitwise reproducible.
 #include "common.h"
 
+#include <atomic>
+
 namespace {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -1400,10 +1402,25 @@ int launch_one(KernelT kern, SdpaParams p, bool causal, int rows_per_block, int 
     p.nblk = (p.T + rows_per_block - 1) / rows_per_block;
     p.npairs = S * p.H;
     const int wg_per_pair = causal ? (p.nblk + 1) / 2 : p.nblk;
-    static size_t lds_set = 0;      // one static per template instantiation = per kernel: the attribute is set once (and again only to grow)
-    if (lds > lds_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_set = lds;
+    // The dynamic-LDS limit is a per-(kernel, device) attribute: remembered per device in atomics (one table per template instantiation
+    // = per kernel), set once and again only to grow.  Two host threads racing here both set the same value - harmless; a process
+    // that drives several devices sets it on each.
+    constexpr int kMaxDev = 64;
+    static std::atomic<size_t> lds_set[kMaxDev];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int slot = (dev >= 0 && dev < kMaxDev) ? dev : -1;
+    if (slot < 0 || lds > lds_set[slot].load(std::memory_order_acquire)) {
+        const hipError_t ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) {
+            halva_set_error("%s: hipFuncSetAttribute(%zu B of LDS) failed: %s", name, lds, hipGetErrorString(ea));
+            return HALVA_ERR_LAUNCH;
+        }
+        if (slot >= 0) {
+            size_t cur = lds_set[slot].load(std::memory_order_relaxed);
+            while (cur < lds && !lds_set[slot].compare_exchange_weak(cur, lds, std::memory_order_release)) {
+            }
+        }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(wg_per_pair * p.npairs)), dim3(threads), lds, st, p);
     hipError_t e_ = hipGetLastError();
@@ -1437,6 +1454,7 @@ int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st) {
     if (p.ds_ws != nullptr && D == 128) {      // dS formed once: delta (+ zero-fill of padded dq rows) -> dK/dV (+ dS store) -> dQ = dS K
         const int64_t rows = (int64_t)S * p.T;
         hipLaunchKernelGGL((sdpa_bwd_delta_kernel<D>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, S);
+        HALVA_CHECK_LAUNCH("sdpa_bwd_delta");      // (a failed launch would leave stale delta / unzeroed padded dq rows for the two kernels below)
         int rc2 = slow ? launch_one(sdpa_bwd_dkv2_kernel<D, CAUSAL, true>, p, CAUSAL, 128, 512, lds_dkv, S, st, "sdpa_bwd_dkv2")
                        : launch_one(sdpa_bwd_dkv2_kernel<D, CAUSAL, false>, p, CAUSAL, 128, 512, lds_dkv, S, st, "sdpa_bwd_dkv2");
         if (rc2 != HALVA_OK) return rc2;

@@ -75,6 +75,12 @@ class _LmHeadLogp(torch.autograd.Function):
         kept, ctx.kept = ctx.kept, None
         for k, c0 in enumerate(range(0, h.shape[0], LOGIT_CHUNK_ROWS)):
             c1 = min(h.shape[0], c0 + LOGIT_CHUNK_ROWS)
+            if LOGITS_F32:      # (diagnostic flag) the forward's lse came from fp32 logits: the softmax of the backward must too
+                logits = torch.mm(h[c0:c1], W.t(), out_dtype=torch.float32)
+                call("halva_token_logp_bwd", ptr(logits), F32, V, ptr(target[c0:c1]), ptr(lse[c0:c1]), ptr(g[c0:c1]), ptr(logits),
+                     c1 - c0, V, st)
+                torch.mm(logits.to(torch.bfloat16), W, out=dh[c0:c1])
+                continue
             logits = kept[k] if kept is not None else torch.mm(h[c0:c1], W.t())      # (the same bf16 values either way)
             call("halva_token_logp_bwd", ptr(logits), BF16, V, ptr(target[c0:c1]), ptr(lse[c0:c1]), ptr(g[c0:c1]), ptr(logits),
                  c1 - c0, V, st)
@@ -287,7 +293,7 @@ class DPAEngine:
     def _hidden(self, model, plan, feats):
         m = model.get_model()
         dev = m.embed_tokens.weight.device
-        embeds = K.splice_rows(m.embed_tokens.weight, feats, plan.src.to(dev, non_blocking=True), plan.S, plan.T)
+        embeds = K.splice_rows(m.embed_tokens.weight, feats, plan.src, plan.S, plan.T)
         return model.hidden_states(embeds, None, plan.seq_start, plan.seq_len)
 
     def pair_group_loss(self, batch, plan, idx):
@@ -301,7 +307,7 @@ class DPAEngine:
         if packed is not None and (packed.rows_packed < packed.rows_unpacked or self.share_prefix == "always"):
             # the two rows of a pair run as ONE packed row [prefix | correct rest | pad | hallucinated rest]
             m = pol.get_model()
-            embeds = K.splice_rows(m.embed_tokens.weight, feats, packed.src.to(dev, non_blocking=True), g, packed.T)
+            embeds = K.splice_rows(m.embed_tokens.weight, feats, packed.src, g, packed.T)
             branch = tuple(t.to(dev, non_blocking=True) for t in (packed.br_a, packed.br_b, packed.pos))
             h = pol.hidden_states(embeds, None, torch.zeros(g, dtype=torch.int32), packed.seq_len, branch=branch)
             hid, dense, target = _kept_rows(gp.labels, packed.row_of)

@@ -276,47 +276,70 @@ def swiglu(gu, out_width=None):
 
 
 # ------------------------------------------------------------------------------------------------
+def _splice_bwd_plan(src_host, device):
+    """Host-side plan of the splice backward: a feature row feeds one output row per sequence that shows its image (two when the
+    rows of a pair run unpacked).  Occurrence k of every feature row, for k = 0, 1, ..: (feature rows, output rows) index pairs with
+    UNIQUE targets, so the sum runs in a fixed order (no float atomics - two runs give the same bits) and needs no device->host
+    read-back (the index plan `src` is host data, halva_amd/splice.py)."""
+    import numpy as np
+    src = src_host.numpy().reshape(-1)
+    rows = np.nonzero(src <= -2)[0]
+    if rows.size == 0:
+        return []
+    f = -src[rows].astype(np.int64) - 2
+    order = np.argsort(f, kind="stable")
+    fs, rs = f[order], rows[order]
+    start = np.ones(fs.size, dtype=bool)
+    start[1:] = fs[1:] != fs[:-1]
+    idx = np.arange(fs.size)
+    occ = idx - np.maximum.accumulate(np.where(start, idx, 0))
+    out = []
+    for k in range(int(occ.max()) + 1):
+        sel = occ == k
+        out.append((torch.from_numpy(fs[sel]).to(device, non_blocking=True), torch.from_numpy(rs[sel]).to(device, non_blocking=True)))
+    return out
+
+
 class _SpliceRows(torch.autograd.Function):
     """The text/image splice of prepare_inputs_labels_for_multimodal[_signed] (llava_arch.py:285-374) as one row
     gather driven by a host-computed index plan.  Gradient flows to the image features (mm_projector) only."""
 
     @staticmethod
-    def forward(ctx, embed, feats, src, S, T):
+    def forward(ctx, embed, feats, src, S, T, bwd_plan):
         _chk(embed, torch.bfloat16, "embed_tokens"), _chk(feats, torch.bfloat16, "image_features")
         _chk(src, torch.int32, "src")
         d = embed.shape[1]
         out = torch.empty(S, T, d, dtype=torch.bfloat16, device=embed.device)
         call("halva_splice_rows", ptr(embed), ptr(feats), ptr(src), ptr(out), S * T, d, stream_ptr())
-        ctx.save_for_backward(src)
+        ctx.bwd_plan = bwd_plan
+        if bwd_plan is None:
+            ctx.save_for_backward(src)
         ctx.feat_shape = feats.shape
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (src,) = ctx.saved_tensors
         d = dout.shape[-1]
-        rows = (src <= -2).nonzero().flatten()
+        plan = ctx.bwd_plan
+        if plan is None:      # `src` was handed over as a device tensor: derive the plan from a host copy (one read-back)
+            (src,) = ctx.saved_tensors
+            plan = _splice_bwd_plan(src.cpu(), dout.device)
         dfeat = torch.zeros(ctx.feat_shape, dtype=torch.float32, device=dout.device).view(-1, d)
-        if rows.numel():
-            # a feature row feeds one output row per sequence that shows its image (two when the rows of a pair run unpacked): summed
-            # in a FIXED order - occurrence by occurrence, each pass a plain scatter with unique targets - not with float atomics,
-            # so two runs of the same step give the same bits
-            f = -src[rows].long() - 2
-            order = torch.argsort(f, stable=True)
-            fs, rs = f[order], rows[order]
-            start = torch.ones_like(fs, dtype=torch.bool)
-            start[1:] = fs[1:] != fs[:-1]
-            idx = torch.arange(fs.numel(), device=fs.device)
-            occ = idx - torch.cummax(torch.where(start, idx, torch.zeros_like(idx)), 0).values
-            do = dout.reshape(-1, d)
-            for k in range(int(occ.max()) + 1):
-                sel = occ == k
-                dfeat[fs[sel]] += do[rs[sel]].float()
-        return None, dfeat.to(torch.bfloat16).view(ctx.feat_shape), None, None, None
+        do = dout.reshape(-1, d)
+        for fk, rk in plan:
+            dfeat[fk] += do[rk].float()
+        return None, dfeat.to(torch.bfloat16).view(ctx.feat_shape), None, None, None, None
 
 
 def splice_rows(embed, feats, src, S, T):
-    return _SpliceRows.apply(embed, feats.contiguous(), src, S, T)
+    """`src`: the int32 index plan (halva_amd/splice.py).  Hand it over as the HOST tensor the planner produced: it is uploaded
+    here, and the backward's occurrence plan is built on the host beside it (no device->host synchronisation in the backward)."""
+    bwd_plan = None
+    if not src.is_cuda and embed.is_cuda:
+        if feats.requires_grad and torch.is_grad_enabled():
+            bwd_plan = _splice_bwd_plan(src, embed.device)
+        src = src.to(embed.device, non_blocking=True)
+    return _SpliceRows.apply(embed, feats.contiguous(), src, S, T, bwd_plan)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -375,6 +398,57 @@ class _ProjectorMLP(torch.autograd.Function):
 
 def projector_mlp(x, w1, b1, w2, b2):
     return _ProjectorMLP.apply(x, w1, b1, w2, b2)
+
+
+class _ProjectorChain(torch.autograd.Function):
+    """`linear` and `mlp<N>x_gelu` projectors of any depth (multimodal_projector/builder.py:33-46): Linear (-> GELU -> Linear)*, every
+    Linear one MFMA GEMM with the bias (and, between layers, the GELU) fused into its epilogue.  The input carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        h = _chk(x.reshape(-1, x.shape[-1]).contiguous(), torch.bfloat16, "x")
+        saved = []
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            if i + 1 < len(ws):
+                pre = torch.empty(h.shape[0], w.shape[0], dtype=torch.bfloat16, device=x.device)
+                nxt = gemm(h, w, b, epilogue=1, pre_act=pre)
+                saved += [h, pre]
+            else:
+                nxt = gemm(h, w, b)
+                saved.append(h)
+            h = nxt
+        ctx.save_for_backward(*saved)
+        ctx.params = (ws, bs)
+        return h.view(*x.shape[:-1], ws[-1].shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        ws, bs = ctx.params
+        saved = list(ctx.saved_tensors)
+        d = _chk(dy.reshape(-1, dy.shape[-1]).contiguous(), torch.bfloat16, "dy")
+        M, st = d.shape[0], stream_ptr()
+        pairs = []
+        for i in range(len(ws) - 1, -1, -1):
+            inp = saved[2 * i]
+            dw = gemm(d, inp, trans_a=True, trans_b=True, out_dtype=torch.float32)
+            db = torch.zeros(ws[i].shape[0], dtype=torch.float32, device=dy.device)
+            call("halva_colsum", ptr(d), ptr(db), M, ws[i].shape[0], st)
+            pairs += [(bs[i], db), (ws[i], dw)]
+            if i > 0:
+                dg = gemm(d, ws[i], trans_b=True)
+                d = torch.empty_like(dg)
+                call("halva_gelu_bwd", ptr(dg), ptr(saved[2 * i - 1]), ptr(d), M, dg.shape[1], st)
+        grads = _sink_or_return(pairs[::-1])
+        return (None, *grads)
+
+
+def projector_chain(x, linears):
+    """linears: the nn.Linear modules of the projector in order (GELU between consecutive ones)."""
+    args = []
+    for lin in linears:
+        args += [lin.weight, lin.bias]
+    return _ProjectorChain.apply(x, *args)
 
 
 def _sink_or_return(pairs):

@@ -102,8 +102,7 @@ class LlavaMetaForCausalLM:
                               None if labels is None else _cpu(labels), None if signs is None else _cpu(signs),
                               n_patch=n_patch, max_len=getattr(self.config, "tokenizer_model_max_length", None),
                               padding_side=getattr(self.config, "tokenizer_padding_side", "right"), image_map=image_map)
-        src = plan.src.to(dev, non_blocking=True)
-        embeds = K.splice_rows(model.embed_tokens.weight, image_features.to(torch.bfloat16), src, plan.S, plan.T)
+        embeds = K.splice_rows(model.embed_tokens.weight, image_features.to(torch.bfloat16), plan.src, plan.S, plan.T)
         return embeds, plan
 
     def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels, images):
@@ -130,10 +129,60 @@ class LlavaMetaForCausalLM:
         self._last_plan = plan
         return None, (None if position_ids is None else position_ids), new_mask, past_key_values, embeds, new_labels, new_signs
 
+    def resize_token_embeddings(self, new_num_tokens):
+        """HF PreTrainedModel.resize_token_embeddings for this model's two vocabulary-sized tensors: old rows kept, new rows
+        N(0, initializer_range) as HF initialises them (the callers below overwrite them with the mean of the old rows)."""
+        emb, head = self.get_input_embeddings(), self.get_output_embeddings()
+        old = emb.weight.shape[0]
+        if new_num_tokens == old:
+            return emb
+        std = getattr(self.config, "initializer_range", 0.02)
+        for mod in (emb, head):
+            w = mod.weight.data
+            nw = torch.empty(new_num_tokens, w.shape[1], dtype=w.dtype, device=w.device).normal_(0.0, std)
+            n = min(old, new_num_tokens)
+            nw[:n] = w[:n]
+            mod.weight = nn.Parameter(nw, requires_grad=mod.weight.requires_grad)
+        if hasattr(emb, "num_embeddings"):
+            emb.num_embeddings = new_num_tokens
+        if hasattr(head, "out_features"):
+            head.out_features = new_num_tokens
+        self.config.vocab_size = new_num_tokens
+        return emb
+
     def initialize_vision_tokenizer(self, model_args, tokenizer):
-        if getattr(model_args, "mm_use_im_patch_token", False) or getattr(model_args, "mm_use_im_start_end", False):
-            raise NotImplementedError("mm_use_im_patch_token / mm_use_im_start_end are False on the HALVA path "
-                                      "(src/hallava_7b.sh:42-43); embedding resize is not implemented")
+        """reference llava/model/llava_arch.py:398-440: <im_patch> / <im_start>, <im_end> tokens appended to the vocabulary, the new
+        rows of embed_tokens and lm_head set to the mean of the old ones (or taken from --pretrain_mm_mlp_adapter).  The HALVA
+        scripts pass both flags False (src/hallava_7b.sh:42-43), in which case this is a no-op, as in the reference.  Training the
+        embedding matrix itself (tune_mm_mlp_adapter + mm_use_im_start_end) is not on the DPA path and is refused."""
+        from llava.constants import DEFAULT_IMAGE_PATCH_TOKEN, DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN
+        if getattr(model_args, "mm_use_im_patch_token", False):
+            tokenizer.add_tokens([DEFAULT_IMAGE_PATCH_TOKEN], special_tokens=True)
+            self.resize_token_embeddings(len(tokenizer))
+        if getattr(model_args, "mm_use_im_start_end", False):
+            if getattr(model_args, "tune_mm_mlp_adapter", False):
+                raise NotImplementedError("tune_mm_mlp_adapter with mm_use_im_start_end trains embed_tokens (llava_arch.py:419-423): "
+                                          "the MI355X DPA engine keeps the embedding matrix frozen")
+            num_new = tokenizer.add_tokens([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN], special_tokens=True)
+            self.resize_token_embeddings(len(tokenizer))
+            if num_new > 0:
+                with torch.no_grad():
+                    for w in (self.get_input_embeddings().weight, self.get_output_embeddings().weight):
+                        w[-num_new:] = w[:-num_new].float().mean(dim=0, keepdim=True).to(w.dtype)
+            pre = getattr(model_args, "pretrain_mm_mlp_adapter", None)
+            if pre:
+                ew = torch.load(pre, map_location="cpu")["model.embed_tokens.weight"]
+                assert num_new == 2
+                inp = self.get_input_embeddings().weight
+                with torch.no_grad():
+                    if inp.shape == ew.shape:
+                        inp[-num_new:] = ew[-num_new:].to(inp)
+                    elif ew.shape[0] == num_new:
+                        inp[-num_new:] = ew.to(inp)
+                    else:
+                        raise ValueError("Unexpected embed_tokens_weight shape. Pretrained: %s. Current: %s. Numer of new tokens: %d."
+                                         % (tuple(ew.shape), tuple(inp.shape), num_new))
+        # (mm_use_im_patch_token alone only touches requires_grad flags that are already False here: llava_arch.py:435-440)
 
 
 def _cpu(t):

@@ -370,7 +370,7 @@ class VilaLlavaLlamaModel(nn.Module):
                               n_patch=feats.shape[1], max_len=sp.max_len, padding_side=sp.padding_side,
                               imageless_consumes=False)
         w = self.llm.model.embed_tokens.weight
-        embeds = K.splice_rows(w, feats.to(torch.bfloat16), plan.src.to(w.device, non_blocking=True), plan.S, plan.T)
+        embeds = K.splice_rows(w, feats.to(torch.bfloat16), plan.src, plan.S, plan.T)
         self._last_plan = plan
         return embeds, plan
 

@@ -227,6 +227,10 @@ int halva_phrase_sum_bwd(const float* dacc, const int64_t* labels, const int64_t
 
 /* ---- hardware-layout probes used by the GPU tests (MFMA fragment maps, ds_read_b64_tr_b16). */
 int halva_probe_layouts(int32_t* out, int n, void* stream);
+/* ---- measurement aid (bench.py's clock trace; no reference counterpart): `blocks` one-wave workgroups each spin for `spin_ticks` ticks of
+ * the constant 100 MHz counter and report out[4 b + {0,1,2,3}] = {shader cycles elapsed (s_memtime), 100 MHz ticks elapsed (s_memrealtime),
+ * start tick, XCC id}: shader MHz = 100 * out[4b] / out[4b+1], the clock the chip holds while the step's kernels run beside the probe. */
+int halva_clock_probe(uint64_t* out, int blocks, int spin_ticks, void* stream);
 
 #ifdef __cplusplus
 }

@@ -645,6 +645,62 @@ def gen_llama_layer():
     save_npz("llama_layer.npz", **packs)
 
 
+def gen_peft_names():
+    """The key sets of the run's output files as the REFERENCE's own helpers select them (train_halva.py:116-153 called exactly as
+    train() does at :1230-1240), on the reference's tiny LLaVA wrapped the way peft 0.4.0 wraps it.  peft is not installed here, so
+    the WRAPPING is emulated from its documented module layout (PeftModel.base_model = LoraModel, LoraModel.model = the wrapped
+    network; every target nn.Linear keeps `.weight` and gains `.lora_A.default` / `.lora_B.default` Linear sub-modules) - the
+    selection (which names are LoRA state, which are "non-LoRA trainables", which modules are targets) is the reference's code.
+    `adapter_model_bin` = the names peft's save_pretrained writes for that state dict (adapter name stripped: `.default` removed)."""
+    ds = types.ModuleType("deepspeed")
+    ds.zero = types.SimpleNamespace(GatheredParameters=None)
+    pp = types.ModuleType("deepspeed.runtime.zero.partition_parameters")
+    pp.ZeroParamStatus = types.SimpleNamespace(NOT_AVAILABLE=0)
+    for name, mod in (("deepspeed", ds), ("deepspeed.runtime", types.ModuleType("deepspeed.runtime")),
+                      ("deepspeed.runtime.zero", types.ModuleType("deepspeed.runtime.zero")),
+                      ("deepspeed.runtime.zero.partition_parameters", pp)):
+        sys.modules.setdefault(name, mod)
+    tower = build_vision_tower(9)
+    m = build_llava(10, tower)
+    targets = sorted(TH.find_all_linear_names(m))
+    r = 4
+
+    class LoraLinear(torch.nn.Linear):
+        def __init__(self, base):
+            super().__init__(base.in_features, base.out_features, bias=base.bias is not None)
+            self.weight = base.weight
+            self.lora_A = torch.nn.ModuleDict({"default": torch.nn.Linear(base.in_features, r, bias=False)})
+            self.lora_B = torch.nn.ModuleDict({"default": torch.nn.Linear(r, base.out_features, bias=False)})
+
+    for p in m.parameters():
+        p.requires_grad = False
+    for name, mod in list(m.named_modules()):
+        if isinstance(mod, torch.nn.Linear) and name.split(".")[-1] in targets and not any(
+                k in name for k in ("mm_projector", "vision_tower", "vision_resampler")):
+            parent = m.get_submodule(".".join(name.split(".")[:-1]))
+            setattr(parent, name.split(".")[-1], LoraLinear(mod))
+    for p in m.get_model().mm_projector.parameters():      # llava_arch.py:58-61 (initialize_vision_modules re-enables them)
+        p.requires_grad = True
+
+    class LoraModel(torch.nn.Module):
+        def __init__(self, model):
+            super().__init__()
+            self.model = model
+
+    class Peft(torch.nn.Module):
+        def __init__(self, model):
+            super().__init__()
+            self.base_model = LoraModel(model)
+    pm = Peft(m)
+    lora = TH.get_peft_state_maybe_zero_3(pm.named_parameters(), "none")
+    non_lora = TH.get_peft_state_non_lora_maybe_zero_3(pm.named_parameters())
+    save_json("peft_state_names.json", {
+        "llama_cfg": TINY, "lora_r": r, "target_modules": targets,
+        "lora_state": {k: list(v.shape) for k, v in lora.items()},
+        "adapter_model_bin": {k.replace(".default", ""): list(v.shape) for k, v in lora.items()},
+        "non_lora_trainables": {k: list(v.shape) for k, v in non_lora.items()}})
+
+
 def main():
     torch.set_num_threads(4)
     torch.manual_seed(0)
@@ -663,10 +719,13 @@ def main():
                      model_seed=310)
     gen_llama_layer()
     gen_clip_d64()
+    gen_peft_names()
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "d128":          # only the fixtures added in round 2 (the others reproduce bit for bit)
+    if len(sys.argv) > 1 and sys.argv[1] == "peft":          # only the fixture added in round 3
+        gen_peft_names()
+    elif len(sys.argv) > 1 and sys.argv[1] == "d128":          # only the fixtures added in round 2 (the others reproduce bit for bit)
         torch.set_num_threads(4)
         gen_clip_d64()
         gen_dpa_step_d64("dpa_step_d128_init", std=0.02, lora_std=0.02, TINY64=TINY128, B=4, seed=61, max_len=192, resp_base=118,

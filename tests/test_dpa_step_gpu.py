@@ -40,7 +40,56 @@ REL_TOL = {"dpa_step_d64_init": 1e-3, "dpa_step_d128_init": 1e-3, "dpa_step_d64"
 # max |margin error| of the oracle run in bf16 (measured in the build container by _bf16_floor below; the CPU test
 # tests/test_oracle_vs_golden.py::test_bf16_floor_constants re-measures it and fails if these are more than 2x a live measurement)
 MARGIN_FLOOR = {"dpa_step_d64_init": 3.9e-3, "dpa_step_d128_init": 1.13e-2, "dpa_step_d64": 2.2e-2}
+# Gradients (LoRA factors through the chain rule from the reference's dense dL/dW, projector directly), relative Frobenius error per
+# tensor: the same floor argument.  The oracle re-run in bf16 on the CPU is 1.27e-2 / 1.50e-2 / 2.03e-2 away from the reference's fp32
+# gradients on the three fixtures (max over the tensors; _bf16_grad_floor below re-measures it, tests/test_oracle_vs_golden.py holds
+# the constants to a live measurement); the product is bound by 1.25 x that floor on every fixture (round 2 checked only the stress
+# fixture, at a flat 3e-2).
+GRAD_FLOOR = {"dpa_step_d64_init": 1.27e-2, "dpa_step_d128_init": 1.50e-2, "dpa_step_d64": 2.03e-2}
 _floor_cache = {}
+_gfloor_cache = {}
+
+
+def _ref_factor_grads(z, fac, r, alpha):
+    """{key: (want dA, want dB)} from the reference's dense weight gradients: dA = s B^T dW, dB = s dW A^T."""
+    s = alpha / r
+    out = {}
+    for k in [k for k in z.files if k.startswith("grad.") and "mm_projector" not in k]:
+        mod = k[len("grad."):-len(".weight")]
+        dW = torch.from_numpy(z[k])
+        A, Bm = fac[mod + ".A"], fac[mod + ".B"]
+        out[mod] = (s * Bm.T @ dW, s * dW @ A.T)
+    return out
+
+
+def _bf16_grad_floor(name, z):
+    """max relative gradient error (over the LoRA factors and projector tensors the fixture holds) of the reference arithmetic itself
+    (oracle) run in bf16 on the CPU, against the reference's fp32 gradients."""
+    if name not in _gfloor_cache:
+        from golden_util import meta_of
+        from oracle import dpa as odpa
+        cfg, ccfg = meta_of(z, "llama_cfg"), meta_of(z, "clip_cfg")
+        base, clipW = tensors(z, "base."), tensors(z, "clip.")
+        r, a = z["lora_cfg"]
+        bf = torch.bfloat16
+        fac = tensors(z, "lora.")
+        lora = {k: v.clone().to(bf).requires_grad_(True) for k, v in fac.items()}
+        ref = odpa.TinyLlava(base, cfg, clipW, ccfg, int(z["max_len"]), dtype=bf)
+        pol = odpa.TinyLlava(base, cfg, clipW, ccfg, int(z["max_len"]), lora=fac, lora_scale=float(a / r), dtype=bf)
+        proj = {k: v.clone().to(bf).requires_grad_(True) for k, v in base.items() if "mm_projector" in k}
+        pol.W.update(proj)
+        pol.lora = lora
+        loss, _ = odpa.compute_loss(pol, ref, {k[len("batch."):]: z[k] for k in z.files if k.startswith("batch.")}, float(z["alpha"]))
+        loss.backward()
+        errs = []
+        for mod, (wa, wb) in _ref_factor_grads(z, fac, float(r), float(a)).items():
+            errs.append(float((lora[mod + ".A"].grad.float() - wa).norm() / wa.norm()))
+            errs.append(float((lora[mod + ".B"].grad.float() - wb).norm() / wb.norm()))
+        for k in [k for k in z.files if k.startswith("grad.") and "mm_projector" in k]:
+            want = torch.from_numpy(z[k])
+            errs.append(float((proj[k[len("grad."):]].grad.float() - want).norm() / want.norm()))
+        _gfloor_cache[name] = max(errs)
+    return _gfloor_cache[name]
 
 
 def _bf16_floor(name, z):
@@ -106,25 +155,23 @@ def test_step_matches_reference_golden(ppg, rpg, share, fixture):
     assert abs(got - float(z["out.loss"])) < tol_loss, (got, float(z["out.loss"]))
     assert abs(parts["alignment"] - float(z["out.alignment"])) < tol_align, (parts, float(z["out.alignment"]))
     assert abs(parts["divergence"] - float(z["out.divergence"])) < tol_div, (parts, float(z["out.divergence"]))
-    if fixture != "dpa_step_d64":
-        return
-    # gradients: LoRA factors via the chain rule from the reference's dense dL/dW; projector directly
-    s = alpha / r
-    checked = 0
+    # gradients on EVERY fixture: LoRA factors via the chain rule from the reference's dense dL/dW, projector directly; bound = the
+    # bf16 floor of the reference arithmetic (GRAD_FLOOR) x 1.25
+    bound = 1.25 * GRAD_FLOOR[fixture]
+    want = _ref_factor_grads(z, fac, float(r), float(alpha))
+    checked, worst = 0, 0.0
     for i, layer in enumerate(pol.model.layers):
         for sub, grp in layer.groups():
             for g, n in enumerate(grp.names):
-                key = "grad.model.layers.%d.%s.%s.weight" % (i, sub, n)
-                if key not in z.files:
+                mod = "model.layers.%d.%s.%s" % (i, sub, n)
+                if mod not in want:
                     continue
-                dW = torch.from_numpy(z[key])
-                A = fac["model.layers.%d.%s.%s.A" % (i, sub, n)]
-                Bm = fac["model.layers.%d.%s.%s.B" % (i, sub, n)]
                 gA = grp.A_cat.main_grad[g * r:(g + 1) * r].cpu()
                 gB = getattr(grp, n).lora_B["default"].weight.main_grad.cpu()
-                refA, refB = s * Bm.T @ dW, s * dW @ A.T
-                assert float((gA - refA).norm() / refA.norm()) < 3e-2, key
-                assert float((gB - refB).norm() / refB.norm()) < 3e-2, key
+                refA, refB = want[mod]
+                eA, eB = float((gA - refA).norm() / refA.norm()), float((gB - refB).norm() / refB.norm())
+                assert eA < bound and eB < bound, (fixture, mod, eA, eB, bound)
+                worst = max(worst, eA, eB)
                 checked += 1
     assert checked >= 5
     for k in [k for k in z.files if k.startswith("grad.") and "mm_projector" in k]:
@@ -132,7 +179,11 @@ def test_step_matches_reference_golden(ppg, rpg, share, fixture):
         kind = k.rsplit(".", 1)[1]
         p = getattr(pol.model.mm_projector[idx], kind)
         refg = torch.from_numpy(z[k])
-        assert float((p.main_grad.cpu() - refg).norm() / refg.norm()) < 3e-2, k
+        e = float((p.main_grad.cpu() - refg).norm() / refg.norm())
+        assert e < bound, (fixture, k, e, bound)
+        worst = max(worst, e)
+    print("%s ppg=%s share=%s: max relative gradient error %.2e (bf16 floor of the reference arithmetic %.2e, bound %.2e)"
+          % (fixture, ppg, share, worst, GRAD_FLOOR[fixture], bound))
 
 
 def test_compat_api_matches_golden():

@@ -235,3 +235,86 @@ def test_tile_dma_source_swizzle_inverts_the_lds_tile_layout():
                         for lane in (0, 17, 63):
                             r0, c0 = source_of(wave, lane)
                             assert source_of(wave + nw * i, lane) == (r0 + i * rows_per_i, c0)
+
+
+def test_projector_builder_accepts_every_reference_type():
+    """reference llava/model/multimodal_projector/builder.py:33-51: 'linear', 'mlp<N>x_gelu', 'identity', else ValueError; parameter
+    names as the reference's nn.Linear / nn.Sequential give them (they are the keys of non_lora_trainables.bin)."""
+    import types
+    from halva_amd import clip
+    def names(kind):
+        m = clip.build_vision_projector(types.SimpleNamespace(mm_projector_type=kind, mm_hidden_size=8, hidden_size=16), device="cpu")
+        return [n for n, _ in m.named_parameters()], m
+    assert names("linear")[0] == ["weight", "bias"]
+    assert names("mlp1x_gelu")[0] == ["0.weight", "0.bias"]
+    assert names("mlp2x_gelu")[0] == ["0.weight", "0.bias", "2.weight", "2.bias"]
+    assert names("mlp3x_gelu")[0] == ["0.weight", "0.bias", "2.weight", "2.bias", "4.weight", "4.bias"]
+    ident = names("identity")[1]
+    x = torch.randn(2, 3)
+    assert ident(x) is x and ident.config == {"mm_projector_type": "identity"}
+    with pytest.raises(ValueError):
+        names("resblock")
+
+
+def test_initialize_vision_tokenizer_resizes_and_mean_initialises():
+    """reference llava/model/llava_arch.py:398-440 on a stand-in model: <im_patch> then <im_start>/<im_end> are appended, both
+    vocabulary-sized matrices grow, the two start/end rows become the mean of the rows before them; both flags False = no-op."""
+    import types
+    from halva_amd.llava_model import LlavaMetaForCausalLM
+
+    class Tok:
+        def __init__(self):
+            self.v = ["a%d" % i for i in range(10)]
+        def add_tokens(self, toks, special_tokens=False):
+            new = [t for t in toks if t not in self.v]
+            self.v += new
+            return len(new)
+        def __len__(self):
+            return len(self.v)
+
+    class M(LlavaMetaForCausalLM):
+        def __init__(self):
+            g = torch.Generator().manual_seed(0)
+            self.emb = torch.nn.Embedding(10, 4)
+            self.head = torch.nn.Linear(4, 10, bias=False)
+            self.emb.weight.data = torch.randn(10, 4, generator=g)
+            self.head.weight.data = torch.randn(10, 4, generator=g)
+            self.config = types.SimpleNamespace(vocab_size=10)
+        def get_input_embeddings(self):
+            return self.emb
+        def get_output_embeddings(self):
+            return self.head
+
+    m, tok = M(), Tok()
+    e0, h0 = m.emb.weight.data.clone(), m.head.weight.data.clone()
+    m.initialize_vision_tokenizer(types.SimpleNamespace(mm_use_im_patch_token=False, mm_use_im_start_end=False), tok)
+    assert len(tok) == 10 and m.emb.weight.shape[0] == 10
+    m.initialize_vision_tokenizer(types.SimpleNamespace(mm_use_im_patch_token=True, mm_use_im_start_end=True, tune_mm_mlp_adapter=False,
+                                                        pretrain_mm_mlp_adapter=None), tok)
+    assert len(tok) == 13 and m.emb.weight.shape == (13, 4) and m.head.weight.shape == (13, 4) and m.config.vocab_size == 13
+    assert torch.equal(m.emb.weight.data[:10], e0) and torch.equal(m.head.weight.data[:10], h0)
+    for w in (m.emb.weight.data, m.head.weight.data):
+        assert torch.allclose(w[-2:], w[:-2].mean(0, keepdim=True).expand(2, 4), atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        M().initialize_vision_tokenizer(types.SimpleNamespace(mm_use_im_patch_token=False, mm_use_im_start_end=True,
+                                                              tune_mm_mlp_adapter=True), Tok())
+
+
+def test_output_file_keys_match_the_reference_helpers():
+    """f2 (PEFT-format outputs): the key sets and shapes of adapter_model.bin / non_lora_trainables.bin and the adapter's
+    target_modules, against tests/golden/peft_state_names.json - produced by the REFERENCE's get_peft_state_maybe_zero_3 /
+    get_peft_state_non_lora_maybe_zero_3 / find_all_linear_names (llava/train/train_halva.py:116-169, called as train() does at
+    :1230-1240) on the reference's tiny LLaVA (tests/golden/make_golden.py:gen_peft_names).  peft itself is absent offline: its module
+    wrapping is emulated there, the selection logic is the reference's."""
+    from halva_amd.llava_model import build_random_llava
+    import llava.train.train_halva as TH
+    d = load_json("peft_state_names.json")
+    vis = dict(hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2, image_size=28, patch_size=14, layer_norm_eps=1e-5)
+    m = build_random_llava(d["llama_cfg"], vis, lora_r=d["lora_r"], lora_alpha=8, seed=1, device="cpu", max_len=64)
+    adapter = TH.get_peft_state_maybe_zero_3(m, "none")
+    assert {k: list(v.shape) for k, v in adapter.items()} == d["adapter_model_bin"]
+    assert list(adapter) == list(d["adapter_model_bin"])                       # the same order, too
+    non_lora = TH.get_peft_state_non_lora_maybe_zero_3(m)
+    assert {k: list(v.shape) for k, v in non_lora.items()} == d["non_lora_trainables"]
+    assert sorted(TH.find_all_linear_names(m)) == d["target_modules"]
+    assert {k.replace(".lora_A.weight", ".lora_A.default.weight").replace(".lora_B.weight", ".lora_B.default.weight") for k in adapter} == set(d["lora_state"])

@@ -22,40 +22,13 @@ from model_util import batch_of, build_product_models  # noqa: E402
 STEPS, LR, PROJ_LR, ALPHA = 8, 2e-3, 1e-3, 0.4
 
 
-def _ste_bf16(t):
-    """Value = bf16(t), gradient = identity: the bf16 compute copy of an fp32 master tensor."""
-    return t + (t.detach().bfloat16().float() - t.detach())
-
-
 def _oracle_curve(z, bf16_params=False):
-    from oracle import dpa as odpa
-    cfg, ccfg = meta_of(z, "llama_cfg"), meta_of(z, "clip_cfg")
-    base, clipW = tensors(z, "base."), tensors(z, "clip.")
+    """oracle/curve.py (the restatement of the recipe's optimizer semantics lives with the oracle, with its citations)."""
+    from oracle import curve
     r, a = z["lora_cfg"]
-    max_len = int(z["max_len"])
-    ref = odpa.TinyLlava(base, cfg, clipW, ccfg, max_len)
-    pol_W = {k: v.clone() for k, v in base.items()}
-    proj = [k for k in pol_W if "mm_projector" in k]
-    for k in proj:
-        pol_W[k].requires_grad_(True)
-    lora = {k: v.clone().requires_grad_(True) for k, v in tensors(z, "lora.").items()}
-    pol = odpa.TinyLlava(pol_W, cfg, clipW, ccfg, max_len, lora=lora, lora_scale=float(a / r))
-    pol.W = pol_W
-    opt = torch.optim.AdamW([{"params": list(lora.values()), "lr": LR, "weight_decay": 0.0},
-                             {"params": [pol_W[k] for k in proj], "lr": PROJ_LR, "weight_decay": 0.0}], lr=LR, betas=(0.9, 0.999),
-                            eps=1e-8)
     batch = {k[len("batch."):]: z[k] for k in z.files if k.startswith("batch.")}
-    curve = []
-    for _ in range(STEPS):
-        opt.zero_grad()
-        if bf16_params:
-            pol.W = {k: (_ste_bf16(v) if v.requires_grad else v) for k, v in pol_W.items()}
-            pol.lora = {k: _ste_bf16(v) for k, v in lora.items()}
-        loss, _ = odpa.compute_loss(pol, ref, batch, ALPHA)
-        loss.backward()
-        opt.step()
-        curve.append(float(loss))
-    return curve
+    return curve.training_curve(tensors(z, "base."), tensors(z, "clip."), meta_of(z, "llama_cfg"), meta_of(z, "clip_cfg"),
+                                int(z["max_len"]), tensors(z, "lora."), r, a, batch, ALPHA, STEPS, LR, PROJ_LR, bf16_params=bf16_params)
 
 
 def _product_curve(z, ppg, rpg):

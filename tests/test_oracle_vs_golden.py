@@ -211,3 +211,21 @@ def test_bf16_floor_constants(name):
     _, _, live = G._bf16_floor(name, z)
     assert live > 1e-3                                    # bf16 alone already breaks 1e-3 absolute on the margins
     assert G.MARGIN_FLOOR[name] <= 2.0 * live, (G.MARGIN_FLOOR[name], live)
+    # the same for the gradient bound of the GPU step test (GRAD_FLOOR: the oracle's bf16 gradients vs the reference's fp32 ones)
+    glive = G._bf16_grad_floor(name, z)
+    assert 0.8 * glive <= G.GRAD_FLOOR[name] <= 1.25 * glive, (G.GRAD_FLOOR[name], glive)
+
+
+def test_training_curve_oracle_starts_at_the_reference_loss():
+    """oracle/curve.py: step 0 of both curves (fp32 parameters / the recipe's bf16 parameter copy) is the reference's own compute_loss
+    value on the fixture when nothing has been rounded yet (the fixture's trainable tensors are bf16-representable), and the curve
+    moves.  The later steps restate inherited HF Trainer / DeepSpeed semantics and are not pinned to a reference run (oracle/curve.py)."""
+    from oracle import curve
+    z = load_npz("dpa_step_d64_init.npz")
+    r, a = z["lora_cfg"]
+    batch = {k[len("batch."):]: z[k] for k in z.files if k.startswith("batch.")}
+    for bf16_params in (False, True):
+        c = curve.training_curve(tensors(z, "base."), tensors(z, "clip."), meta_of(z, "llama_cfg"), meta_of(z, "clip_cfg"), int(z["max_len"]),
+                                 tensors(z, "lora."), r, a, batch, float(z["alpha"]), 2, 2e-3, 1e-3, bf16_params=bf16_params)
+        assert abs(c[0] - float(z["out.loss"])) < 1e-5, (bf16_params, c[0], float(z["out.loss"]))
+        assert c[1] < c[0] - 0.05

@@ -36,3 +36,20 @@ S_, T_, H_, D_ = 8, rows // 8, 32, 128
 qkv = torch.randn(S_, T_, 3 * H_ * D_, device=dev).to(torch.bfloat16)
 cos, sin = K.rope_tables(D_, T_, device=dev)
 t = timeit(lambda: K._rope_inplace(qkv, cos, sin, T_, H_, D_, False)); print("rope_qk     %.1f us  %.2f TB/s" % (t * 1e6, 2 * S_ * T_ * 2 * H_ * D_ * 2 / t / 1e12))
+# loss kernels on one lm_head chunk (8192 response rows x 32000 logits, bf16): token_logp reads V*2 B per row (bwd: + writes V*2 B in
+# place); kl_rows reads two logit rows, re-reads them from L2/MALL for the gradient and writes one
+R_, V_ = 8192, 32000
+lg = (torch.randn(R_, V_, device=dev) * 2).to(torch.bfloat16)
+lg2 = (torch.randn(R_, V_, device=dev) * 2).to(torch.bfloat16)
+tgt = torch.randint(0, V_, (R_,), device=dev, dtype=torch.int32)
+from halva_amd.hip import call, ptr, stream_ptr
+BF16 = 0
+logp = torch.empty(R_, device=dev); lse = torch.empty(R_, device=dev); gg = torch.randn(R_, device=dev); kl = torch.empty(R_, device=dev)
+t = timeit(lambda: call("halva_token_logp_fwd", ptr(lg), BF16, V_, ptr(tgt), ptr(logp), ptr(lse), R_, V_, stream_ptr()))
+print("token_logp_fwd %.1f us  %.2f TB/s" % (t * 1e6, R_ * V_ * 2 / t / 1e12))
+work = lg.clone()
+t = timeit(lambda: call("halva_token_logp_bwd", ptr(work), BF16, V_, ptr(tgt), ptr(lse), ptr(gg), ptr(work), R_, V_, stream_ptr()))
+print("token_logp_bwd %.1f us  %.2f TB/s (read + write)" % (t * 1e6, 2 * R_ * V_ * 2 / t / 1e12))
+dp_ = torch.empty_like(lg)
+t = timeit(lambda: call("halva_kl_rows", ptr(lg), ptr(lg2), BF16, V_, None, ptr(kl), ptr(dp_), 1.0, R_, V_, stream_ptr()))
+print("kl_rows (+grad) %.1f us  %.2f TB/s (2 reads + 1 write)" % (t * 1e6, 3 * R_ * V_ * 2 / t / 1e12))

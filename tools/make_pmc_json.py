@@ -14,7 +14,9 @@ def kernels(path):
     return res
 micro, step = kernels(out + "/traffic.json"), kernels(out + "/traffic_step.json")
 bwd = lambda d: sum(v["hbm_bytes_per_launch"] for k, v in d.items() if k.startswith("sdpa_bwd"))
+import os, time
 print(json.dumps({
+    "commit": os.environ.get("HALVA_COMMIT", "unrecorded"), "collected": time.strftime("%Y-%m-%d"),
     "command": "tools/refresh_profiles.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 tools/bench_sdpa.py",
     "shape": {"S": 8, "T": 2048, "H": 32, "D": 128},
     "note": "backward = delta + dK/dV (stores dS) + dQ = dS K launches (one C-ABI call); per-launch averages; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024",
