@@ -373,6 +373,35 @@ __device__ __forceinline__ float half_exp(const f32x16& st, float sc, float m_su
     return ps[0] + ps[1];
 }
 
+// The same for scores that come out of the MFMA chain already scaled and shifted (the chain's initial accumulator holds -m_ref and
+// Q was multiplied by scale * log2(e) once per row block): P = exp2(S'), no per-element multiply-add at all.
+__device__ __forceinline__ void exp_pair0(const f32x16& st, int r, f32x2& ps, s16x8& p_lo, s16x8& p_hi) {
+    const f32x2 e = {__builtin_amdgcn_exp2f(st[r]), __builtin_amdgcn_exp2f(st[r + 1])};
+    ps = ps + e;
+    const unsigned w = pack_bf16x2(e[0], e[1]);
+    if (r < 8) {
+        p_lo[r] = (short)(w & 0xffffu);
+        p_lo[r + 1] = (short)(w >> 16);
+    } else {
+        p_hi[r - 8] = (short)(w & 0xffffu);
+        p_hi[r - 7] = (short)(w >> 16);
+    }
+}
+__device__ __forceinline__ float half_exp0(const f32x16& st, s16x8& p_lo, s16x8& p_hi) {
+    f32x2 ps = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) exp_pair0(st, r, ps, p_lo, p_hi);
+    return ps[0] + ps[1];
+}
+// bf16 fragment * c, rounded to bf16 again (once per row block, on the Q fragments)
+__device__ __forceinline__ s16x8 scale_frag(const s16x8& f, float c) {
+    const u32x4 w = __builtin_bit_cast(u32x4, f);
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(bf16_lo(w[i]) * c, bf16_hi(w[i]) * c);
+    return __builtin_bit_cast(s16x8, o);
+}
+
 // scheduling fence that only LDS reads and scalar ops may cross: pins the MFMA / VALU interleave written in the source
 #define FENCE() __builtin_amdgcn_sched_barrier(0x100 | 0x004)
 
@@ -383,9 +412,20 @@ __device__ __forceinline__ float half_exp(const f32x16& st, float sc, float m_su
 #define STAMP_ARGS
 #define STAMP_PASS
 #endif
+#ifndef HALVA_FWD_CINIT
+#define HALVA_FWD_CINIT 0
+#endif
+// HALVA_FWD_CINIT=1 (measured in round 3, NOT the default): the row constant rides in the MFMA chain.  `qf` holds Q * (scale * log2 e) (bf16, rounded once per row
+// block) and both score chains start from the accumulator `minit` = -m_ref in every register (the query sits on the lane), so a score
+// leaves the matrix pipe as S' = log2(e) * scale * q.k - m_ref and P = exp2(S') costs ONE vector instruction per element instead of a
+// multiply-add plus the exponential (32 fewer vector instructions per wave and tile).  Measured on MI355X: forward 379 -> 372 us (-1.8 %),
+// and REJECTED for its numerics: the extra bf16 rounding of Q * c moves a score by ~2^-9 of its magnitude, i.e. P by up to ~1 % for
+// scores of a few tens - test_sdpa_exponent_reference_moves_when_later_keys_dominate (scores of 90..230 nat) leaves its 1e-2 bound
+// (2.1e-2) and the full-width grouping / prefix-sharing invariance tests see 3x their usual loss noise.  flash-attn keeps the scale
+// in fp32 after the product for the same reason; so does the default build.
 template <int D, bool CAUSAL, bool MASK, bool SLOW_TR>
 __device__ __forceinline__ void fwd_tile(const char* kt, const char* vt, const s16x8 (&qf)[D / 16], f32x16 (&oacc)[D / 32],
-                                          float& m_ref, float& l_run, float sc, int kv0, int len, int ql, int lane STAMP_ARGS) {
+                                          float& m_ref, float& l_run, f32x16& minit, float sc, int kv0, int len, int ql, int lane STAMP_ARGS) {
     constexpr int KS = D / 16, DT = D / 32;
     constexpr float RESCALE_AT = 64.f;     // log2 units: P stays below 2^64, far inside fp32 / bf16 range
     static_assert(KS == 8 || KS == 4, "head_dim 128 or 64");
@@ -394,15 +434,21 @@ __device__ __forceinline__ void fwd_tile(const char* kt, const char* vt, const s
     f32x16 s0, s1;
     s16x8 p0a, p0b, p1a, p1b;
     const f32x2 sc2 = {sc, sc};
+    (void)sc2;
     // ---------------- block A: S0 bare, then S1 with softmax(S0) in its shadow ----------------
+#if HALVA_FWD_CINIT
+    s0 = minit, s1 = minit;
+#else
 #pragma unroll
     for (int r = 0; r < 16; ++r) s0[r] = 0.f, s1[r] = 0.f;
+#endif
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) s0 = mfma32(frag_rows<D>(kt, 0, ks, lane), qf[ks], s0);
     mask_half<MASK, CAUSAL>(s0, kv0, h, len, ql);
     STAMP(1);
     const float msub_a = (m_ref == -INFINITY) ? 0.f : m_ref;
     const f32x2 ms2a = {-msub_a, -msub_a};
+    (void)ms2a;
     f32x2 ps0 = {0.f, 0.f};
     float mx0a = -INFINITY, mx0b = -INFINITY;
     FENCE();
@@ -413,7 +459,11 @@ __device__ __forceinline__ void fwd_tile(const char* kt, const char* vt, const s
 #pragma unroll
         for (int q = 0; q < PPS; ++q) {
             const int r = 2 * (ks * PPS + q);
+#if HALVA_FWD_CINIT
+            exp_pair0(s0, r, ps0, p0a, p0b);
+#else
             exp_pair(s0, r, sc2, ms2a, ps0, p0a, p0b);
+#endif
             if (q & 1 || PPS == 1 ? (ks & 1) : false) mx0b = fmaxf(fmaxf(mx0b, s0[r]), s0[r + 1]);
             else mx0a = fmaxf(fmaxf(mx0a, s0[r]), s0[r + 1]);
         }
@@ -426,7 +476,11 @@ __device__ __forceinline__ void fwd_tile(const char* kt, const char* vt, const s
     asm volatile("" : "+v"(p0a), "+v"(p0b), "+v"(ps0));
 #endif
     float sum0 = ps0[0] + ps0[1];
+#if HALVA_FWD_CINIT
+    const float tmax = xhalf_max(fmaxf(fmaxf(mx0a, mx0b), half_max(s1))) + msub_a;      // scores are relative to msub_a: back to absolute
+#else
     const float tmax = xhalf_max(fmaxf(fmaxf(mx0a, mx0b), half_max(s1))) * sc;
+#endif
     STAMP(2);
     // ---------------- rare: move the exponent reference ----------------
     if (__any(tmax > m_ref + RESCALE_AT)) {
@@ -438,12 +492,26 @@ __device__ __forceinline__ void fwd_tile(const char* kt, const char* vt, const s
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
         m_ref = m_next;
+#if HALVA_FWD_CINIT
+        // both score tiles were formed against the old reference: shift them (and every later chain's initial accumulator) to the new one
+        const float msub_n = (m_ref == -INFINITY) ? 0.f : m_ref;
+        const float adj = msub_a - msub_n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] += adj;
+            s1[r] += adj;
+            minit[r] = -msub_n;
+        }
+        sum0 = half_exp0(s0, p0a, p0b);
+#else
         sum0 = half_exp(s0, sc, (m_ref == -INFINITY) ? 0.f : m_ref, p0a, p0b);
+#endif
     }
     STAMP(3);
     // ---------------- block B: PV(P0) with softmax(S1) in its shadow, then PV(P1) bare ----------------
     const float msub_b = (m_ref == -INFINITY) ? 0.f : m_ref;
     const f32x2 ms2b = {-msub_b, -msub_b};
+    (void)ms2b;
     f32x2 ps1 = {0.f, 0.f};
     FENCE();
 #pragma unroll
@@ -452,7 +520,13 @@ __device__ __forceinline__ void fwd_tile(const char* kt, const char* vt, const s
         oacc[dt] = mfma32(frag_cols<D, SLOW_TR>(vt, 16 * ks, 32 * dt, lane), ks ? p0b : p0a, oacc[dt]);
         FENCE();
 #pragma unroll
-        for (int q = 0; q < 8 / (2 * DT); ++q) exp_pair(s1, 2 * (i * (8 / (2 * DT)) + q), sc2, ms2b, ps1, p1a, p1b);
+        for (int q = 0; q < 8 / (2 * DT); ++q) {
+#if HALVA_FWD_CINIT
+            exp_pair0(s1, 2 * (i * (8 / (2 * DT)) + q), ps1, p1a, p1b);
+#else
+            exp_pair(s1, 2 * (i * (8 / (2 * DT)) + q), sc2, ms2b, ps1, p1a, p1b);
+#endif
+        }
         FENCE();
     }
 #pragma unroll
@@ -567,6 +641,13 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
     float m_ref = -INFINITY, l_run = 0.f;
     const float sc = p.scale * kLog2e;
+    f32x16 minit;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) minit[r] = 0.f;       // -m_ref, or 0 while the row has seen no key (HALVA_FWD_CINIT)
+#if HALVA_FWD_CINIT
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = scale_frag(qf[ks], sc);      // Q * scale * log2(e), once per row block
+#endif
     const bool wave_in_b = wq_min >= br.b;             // wave-uniform (br.b is a multiple of 64, strips are 32 rows)
     Stage<D, BN, NT> kst, vst;
     TileDma<D, NW> kdma, vdma;
@@ -625,9 +706,9 @@ __device__ __forceinline__ void sdpa_fwd_block(const SdpaParams& p, char* smem, 
             const int len_t = (wave_in_b && kv0 < br.a && kv0 + BN > br.a) ? br.a : len;       // tile cut at a
             if ((!CAUSAL || kv0 <= wq_max) && !hidden) {
                 if ((kv0 + BN > len_t) || (CAUSAL && kv0 + BN - 1 > wq_min))      // wave-uniform: boundary tiles only
-                    fwd_tile<D, CAUSAL, true, SLOW_TR>(kt, vt, qf, oacc, m_ref, l_run, sc, kv0, len_t, ql, lane STAMP_PASS);
+                    fwd_tile<D, CAUSAL, true, SLOW_TR>(kt, vt, qf, oacc, m_ref, l_run, minit, sc, kv0, len_t, ql, lane STAMP_PASS);
                 else
-                    fwd_tile<D, CAUSAL, false, SLOW_TR>(kt, vt, qf, oacc, m_ref, l_run, sc, kv0, len_t, ql, lane STAMP_PASS);
+                    fwd_tile<D, CAUSAL, false, SLOW_TR>(kt, vt, qf, oacc, m_ref, l_run, minit, sc, kv0, len_t, ql, lane STAMP_PASS);
             }
             if (DMA) {
                 stage_tile_dma_wait();
@@ -913,6 +994,14 @@ __device__ __forceinline__ DkvGeom dkv_geom(const SdpaParams& p, int kb, int str
 // of in the next block's prologue (measured per block, s_memtime: 10 000-12 000 cycles from entry to the first step, of which three
 // memory round trips one behind the other; a step is ~3 850).
 //   kb_next: the key block this workgroup runs next (-1: none)      prefetched: this block's operands were requested by its predecessor
+#ifndef HALVA_DKV_CINIT
+#define HALVA_DKV_CINIT 1
+#endif
+// HALVA_DKV_CINIT (default): a row constant as the initial accumulator (cdna_hip_programming.md, attention backward), on the K side: the
+// dP = dO V^T chain starts from -delta (exact: the same fp32 additions in another order), so dZ = P * dP' needs no subtraction - 32
+// vector instructions fewer per K-side wave and step, and the 32 registers that held delta during the vector work are free after each
+// chain's first MFMA.  The V side's analogue (S chain from -lse, K pre-multiplied by scale * log2 e so that P = exp2(S')) is NOT
+// taken: like HALVA_FWD_CINIT it needs a second bf16 rounding of an operand, which moves P by up to ~1 % (see fwd_tile).
 template <int D, bool CAUSAL, bool SLOW_TR, int ROLE>
 __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* smem, int s, int hd, int kb, int kb_next, bool prefetched,
                                                     int strip, int start, int len, const Branch br, s16x8 (&sf)[D / 16], float (&st)[2]) {
@@ -958,7 +1047,11 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
     auto store_stats = [&](int buf) {
         if (stats_wave) {
             lse_lds[buf * BQ + lane] = st_lse * kLog2e;
+#if HALVA_DKV_CINIT      // stored NEGATED: the values are the initial accumulator of the K side's dP chain (see below)
+            dlt_lds[buf * BQ + lane] = -st_dlt;
+#else
             dlt_lds[buf * BQ + lane] = st_dlt;
+#endif
         }
     };
     // The four V-side waves fetch the tiles: they finish a step's arithmetic ahead of their K-side partners (measured against
@@ -1076,13 +1169,16 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
                 // Every LDS read is placed by hand one block ahead of its use and nothing may cross a slot boundary: left to itself the
                 // scheduler hoists all reads to the top of the step and the register allocator spills.
 #define SLOT() __builtin_amdgcn_sched_barrier(0)
+                constexpr bool CINIT = HALVA_DKV_CINIT && ROLE == 1;          // K side: the dP chain starts from -delta
                 constexpr int PPS = 8 / KS, PPD = 8 / (2 * DT), NS = KS;      // NS slots per block (KS == 2 * DT)
                 static_assert(KS == 2 * DT, "slot count");
                 const float* stat_t = ROLE ? dlt_t : lse_t;
                 auto pair = [&](const f32x16& x, int r, const f32x4& st, unsigned pw) -> unsigned {
                     const float t0 = st[r & 3], t1 = st[(r & 3) + 1];
+                    (void)t0, (void)t1;
                     if (ROLE == 0)
                         return pack_bf16x2(__builtin_amdgcn_exp2f(__builtin_fmaf(x[r], sc, -t0)), __builtin_amdgcn_exp2f(__builtin_fmaf(x[r + 1], sc, -t1)));
+                    if (CINIT) return pack_bf16x2(bf16_lo(pw) * x[r], bf16_hi(pw) * x[r + 1]);      // x = dP - delta already
                     return pack_bf16x2(bf16_lo(pw) * (x[r] - t0), bf16_hi(pw) * (x[r + 1] - t1));
                 };
                 auto mask_scores = [&](f32x16& x, int q0) {
@@ -1099,6 +1195,26 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
                 u32x4 p0[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, p1[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
                 u32x4 w0[2], w1[2];
                 f32x16 x0, x1;
+                if (CINIT) {
+                // ---- block 1: sub-tile 0's statistics ARE the first chain's initial accumulator (register r <-> query acc_row(r, h)): read
+                //      them with the first row fragments; sub-tile 1's are fetched during the chain
+#pragma unroll
+                for (int j = 0; j < 4; ++j) st0[j] = *reinterpret_cast<const f32x4*>(stat_t + 8 * j + 4 * h);
+#pragma unroll
+                for (int ks = 0; ks < NS; ++ks) fa[ks] = frag_rows<D>(rows_tile, 0, ks, lane);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x0[r] = st0[r >> 2][r & 3];
+                SLOT();
+#pragma unroll
+                for (int ks = 0; ks < NS; ++ks) {
+                    x0 = mfma32(fa[ks], sf[ks], x0);
+                    fb[ks] = frag_rows<D>(rows_tile, 32, ks, lane);
+                    if (ks % (NS / 4) == 0) st1[ks / (NS / 4)] = *reinterpret_cast<const f32x4*>(stat_t + 32 + 8 * (ks / (NS / 4)) + 4 * h);
+                    if (ROLE && ks == NS - 2) p0[0] = *reinterpret_cast<const u32x4*>(pt);
+                    if (ROLE && ks == NS - 1) p0[1] = *reinterpret_cast<const u32x4*>(pt + 16);
+                    SLOT();
+                }
+                } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) x0[r] = 0.f, x1[r] = 0.f;
                 // ---- block 1: first product of sub-tile 0; fetch the second sub-tile's row fragments and sub-tile 0's statistics
@@ -1114,10 +1230,15 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
                     if (ROLE && ks == NS - 1) p0[1] = *reinterpret_cast<const u32x4*>(pt + 16);
                     SLOT();
                 }
+                }
                 if (ROLE == 0 && !interior) mask_scores(x0, qt0);
                 STAMP(1);
                 SLOT();
                 // ---- block 2: first product of sub-tile 1 || vector work of sub-tile 0; fetch sub-tile 0's column fragments
+                if (CINIT) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) x1[r] = st1[r >> 2][r & 3];
+                }
 #pragma unroll
                 for (int ks = 0; ks < NS; ++ks) {
                     x1 = mfma32(fb[ks], sf[ks], x1);
@@ -1127,7 +1248,7 @@ __device__ __forceinline__ void sdpa_bwd_dkv2_block(const SdpaParams& p, char* s
                         const int i = ks * PPS + q;      // pair i: accumulator registers 2i, 2i+1
                         w0[i >> 2][i & 3] = pair(x0, 2 * i, st0[i >> 1], p0[i >> 2][i & 3]);
                     }
-                    if (ks % (NS / 4) == NS / 4 - 1) st1[ks / (NS / 4)] = *reinterpret_cast<const f32x4*>(stat_t + 32 + 8 * (ks / (NS / 4)) + 4 * h);
+                    if (!CINIT && ks % (NS / 4) == NS / 4 - 1) st1[ks / (NS / 4)] = *reinterpret_cast<const f32x4*>(stat_t + 32 + 8 * (ks / (NS / 4)) + 4 * h);
                     if (ROLE && ks == NS / 2 - 1) p1[0] = *reinterpret_cast<const u32x4*>(pt + 2048);
                     if (ROLE && ks == NS - 1) p1[1] = *reinterpret_cast<const u32x4*>(pt + 2048 + 16);
                     SLOT();
@@ -1330,22 +1451,34 @@ __device__ __forceinline__ void sdpa_bwd_dq2_block(const SdpaParams& p, char* sm
     // per-lane byte offsets of the transposed reads of dS^T (see frag_cols for the lane roles): key 8 jj + 4 hb + q4, query group 4 (g & 1) + pp
     const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3, hb = g >> 1;
     const int ds_rd0 = ds_piece_off(4 * hb + q4, 4 * (g & 1) + pp);           // jj = 0; jj = 1 adds 8 keys = 128 bytes
+    // A row block wholly in branch B never needs the key tiles that lie wholly inside [a, b) (the producer wrote no dS for them either):
+    // the walk jumps from tile skip_lo - 1 to tile skip_hi, as the forward's does.  In the bench's packed rows [668 | 1380 | 1380] that
+    // is 21 of the 33..54 tiles of each of the six B blocks - 30 % of this kernel's tile steps, each a 16-KiB K tile and up to 32 KiB
+    // of dS fetched for nothing.  (Branch points come with start == 0: halva_amd/splice.py packs right-padded rows only.)
+    int skip_lo = ntile_end, skip_hi = ntile_end;
+    if (start == 0 && lq0 >= br.b) {
+        skip_lo = min(ntile_end, max(first_tile, (br.a + BN - 1) / BN));
+        skip_hi = max(skip_lo, min(ntile_end, br.b / BN));
+    }
+    const int n_lo = skip_lo - first_tile, n_walk = n_lo + (ntile_end - skip_hi);
+    auto tile_at = [&](int i) { return i < n_lo ? first_tile + i : skip_hi + (i - n_lo); };
     // TWO tiles in flight (HBM-bound kernel: the queue must not run dry while a tile is multiplied): ring of three slots, counted waits
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the previous row block's readers are done
-    stage(first_tile, 0);
-    if (first_tile + 1 < ntile_end) stage(first_tile + 1, 1);
+    if (n_walk > 0) stage(tile_at(0), 0);
+    if (n_walk > 1) stage(tile_at(1), 1);
 #pragma unroll 1
-    for (int kt = first_tile; kt < ntile_end; ++kt) {
-        const int slot = (kt - first_tile) % RING;
-        // tile kt has landed: everything but the requests of tile kt + 1 (2 pieces, 6 while that tile is live for this wave)
-        if (kt + 1 < ntile_end) {
-            if (tile_live(kt + 1)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    for (int i = 0; i < n_walk; ++i) {
+        const int kt = tile_at(i);
+        const int slot = i % RING;
+        // tile i has landed: everything but the requests of tile i + 1 (2 pieces, 6 while that tile is live for this wave)
+        if (i + 1 < n_walk) {
+            if (tile_live(tile_at(i + 1))) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // ... for every wave; and tile kt - 1 has been read by all
-        if (kt + 2 < ntile_end) stage(kt + 2, (slot + 2) % RING);             // into the slot of tile kt - 1
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // ... for every wave; and tile i - 1 has been read by all
+        if (i + 2 < n_walk) stage(tile_at(i + 2), (slot + 2) % RING);         // into the slot of tile i - 1
         if (tile_live(kt)) {
             const char* ktile = k_lds + slot * TILE_BYTES;
             const char* dst_t = ds_lds + slot * 4096;
