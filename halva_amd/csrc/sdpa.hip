@@ -1456,7 +1456,12 @@ __device__ __forceinline__ void sdpa_bwd_dq2_block(const SdpaParams& p, char* sm
     // is 21 of the 33..54 tiles of each of the six B blocks - 30 % of this kernel's tile steps, each a 16-KiB K tile and up to 32 KiB
     // of dS fetched for nothing.  (Branch points come with start == 0: halva_amd/splice.py packs right-padded rows only.)
     int skip_lo = ntile_end, skip_hi = ntile_end;
-    if (start == 0 && lq0 >= br.b) {
+#ifndef HALVA_DQ2_NO_SKIP      // (A/B switch: -DHALVA_DQ2_NO_SKIP walks every tile as round 2 did)
+    if (start == 0 && lq0 >= br.b)
+#else
+    if (false)
+#endif
+    {
         skip_lo = min(ntile_end, max(first_tile, (br.a + BN - 1) / BN));
         skip_hi = max(skip_lo, min(ntile_end, br.b / BN));
     }
