@@ -242,6 +242,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();
     char* ds_wave = ds_out + ((size_t)blockIdx.x * 4 + wave) * 8 * 4096;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (MODE == 2) {
+        // lane parts of the LDS addresses (see gen_step_asm.py): row reads (ks even; odd = ^32), transposed reads (jj = 0; jj = 1 = ^32, +2048), statistics
+        const int r = lane & 31;
+        const int rowrel = 2048 * (r >> 3) + 64 * (r & 7) + 16 * (h ^ ((r >> 2) & 3));
+        const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3, h2 = g >> 1;
+        const int colrel = 64 * (4 * h2 + q4) + 16 * ((2 * (g & 1) + (pp >> 1)) ^ h2) + 8 * (pp & 1);
+        const int statrel = 16 * h;
+        const unsigned long long ds_base = __builtin_amdgcn_readfirstlane((unsigned)((size_t)ds_wave & 0xffffffffu)) |
+                                           ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((size_t)ds_wave >> 32)) << 32);
+        u32x4 kq[KS], vq[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kq[ks] = __builtin_bit_cast(u32x4, st.kf[ks]), vq[ks] = __builtin_bit_cast(u32x4, st.vf[ks]);
+        asm volatile(
+#include "step_asm.inc"
+            : "+a"(st.accV[0]), "+a"(st.accV[1]), "+a"(st.accV[2]), "+a"(st.accV[3]), "+a"(st.accK[0]), "+a"(st.accK[1]), "+a"(st.accK[2]), "+a"(st.accK[3])
+            : "a"(kq[0]), "a"(kq[1]), "a"(kq[2]), "a"(kq[3]), "a"(kq[4]), "a"(kq[5]), "a"(kq[6]), "a"(kq[7]),
+              "a"(vq[0]), "a"(vq[1]), "a"(vq[2]), "a"(vq[3]), "a"(vq[4]), "a"(vq[5]), "a"(vq[6]), "a"(vq[7]),
+              "v"(rowrel), "v"(colrel), "v"(statrel), "s"(ds_base), "s"(sc), "s"(nsteps)
+            :
+#include "step_asm_clobbers.inc"
+        );
+    } else
 #pragma unroll 1
     for (int t = 0; t < nsteps; ++t) {
         const int ti = t & (NTILE - 1);
@@ -293,14 +315,17 @@ int main(int argc, char** argv) {
     const size_t lds = 2 * NTILE * TILE_BYTES + 2 * NTILE * 64 * 4;
     hipFuncSetAttribute((const void*)step_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     std::vector<unsigned long long> hc(nwg * 4);
-    for (int mode = 0; mode < 2; ++mode) {
-        float* out = mode ? out1 : out0;
+    float* out2; hipMalloc(&out2, outn * 4);
+    for (int mode = 0; mode < 3; ++mode) {
+        float* out = mode == 0 ? out0 : mode == 1 ? out1 : out2;
         for (int rep = 0; rep < 3; ++rep) {
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             hipEventRecord(e0);
             if (mode == 0) hipLaunchKernelGGL(step_kernel<0>, dim3(nwg), dim3(256), lds, 0, q, dO, k, v, l, n, out, ds, cyc, nsteps, sc);
-            else hipLaunchKernelGGL(step_kernel<1>, dim3(nwg), dim3(256), lds, 0, q, dO, k, v, l, n, out, ds, cyc, nsteps, sc);
+            else if (mode == 1) hipLaunchKernelGGL(step_kernel<1>, dim3(nwg), dim3(256), lds, 0, q, dO, k, v, l, n, out, ds, cyc, nsteps, sc);
+            else hipLaunchKernelGGL(step_kernel<2>, dim3(nwg), dim3(256), lds, 0, q, dO, k, v, l, n, out, ds, cyc, nsteps, sc);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             hipMemcpy(hc.data(), cyc, hc.size() * 8, hipMemcpyDeviceToHost);
@@ -315,6 +340,13 @@ int main(int argc, char** argv) {
     size_t diff = 0; double mx = 0;
     for (size_t i = 0; i < outn; ++i) { if (memcmp(&h0[i], &h1[i], 4)) ++diff; mx = fmax(mx, fabs(h0[i])); }
     printf("mode 1 vs mode 0: %zu of %zu accumulator values differ bitwise (max |value| %.3f)\n", diff, outn, mx);
+    {
+        std::vector<float> h2(outn);
+        hipMemcpy(h2.data(), out2, outn * 4, hipMemcpyDeviceToHost);
+        size_t d2 = 0; double md = 0;
+        for (size_t i = 0; i < outn; ++i) { if (memcmp(&h0[i], &h2[i], 4)) { ++d2; md = fmax(md, fabs(h0[i] - h2[i])); } }
+        printf("mode 2 (asm) vs mode 0: %zu of %zu accumulator values differ bitwise (max |diff| %.3e)\n", d2, outn, md);
+    }
     // CPU check of wave 0 of workgroup 0 (keys 0..31): dV^T[d][key] and dK^T[d][key] accumulated over the steps
     {
         std::vector<double> dv(D * 32, 0.0), dk(D * 32, 0.0);
