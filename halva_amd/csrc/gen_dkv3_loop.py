@@ -1,0 +1,404 @@
+#!/usr/bin/env python3
+"""Generates sdpa_dkv3_loop.inc: the interior-step loop of sdpa_bwd_dkv3 (sdpa_dkv3.h) as ONE inline-asm block.
+
+A wave owns 32 keys (K / V fragments and the dK^T / dV^T accumulators live in the accumulator file); per 64-row step it runs the four
+products itself - S = Q K^T, dP' = dO V^T - delta, dV^T += dO^T P, dK^T += Q^T dZ: 64 MFMAs - with P = exp2(S sc - lse2) formed in place
+over S and dZ = P dP' in place over dP'.  This script assigns every instruction of the step to an MFMA gap:
+  * A operands travel through a ring of 8 four-register slots; the LDS read(s) for MFMA n are issued in gap n - LOOKAHEAD;
+  * the vector work is spread over the gaps behind the chain it depends on, at most CAP issue units per gap (a transcendental counts 2);
+  * every s_waitcnt lgkmcnt(N) comes from a simulation of the in-order LDS queue over two consecutive iterations (steady state);
+  * tile t+1 is waited for (counted vmcnt + s_barrier) in gap 57 of step t, in front of the reads of step t+1's first MFMAs; behind that
+    barrier every wave has issued its last read of tile t, so its slot (a ring of FOUR) takes the requests of tile t+4 - 8 LDS-DMA pieces
+    per wave and two statistics rows, gaps 58-63: three whole steps of lead; the dS of the step is stored behind its packs;
+  * checks: no vector instruction reads an MFMA result earlier than two MFMAs behind the chain's last one, nothing consumes a v_exp
+    result in the next issue slot, a packed operand is written >= 4 instructions before the MFMA that reads it.
+The stream was developed and timed in experiments/dkv3 (2 419 cycles per step against 3 650 for hipcc's own schedule, bit-identical).
+
+Operands of the asm block (sdpa_dkv3.h):  %0-%3 dV^T, %4-%7 dK^T accumulators ("+a"); %8-%15 K, %16-%23 V fragments ("a");
+%24 row-read, %25 transposed-read, %26 statistics lane offsets, %27 / %28 lane offsets of the Q / dO tile pieces ("v");
+%29 dS pointer of the first step (this wave's strip), %30 scale*log2 e, %31 / %53 / %54 steps of the three phases (masked, plain, masked: the diagonal steps, the interior, the tail - ONE asm block per key
+block and side of the branch point, so that the compiler's reloads around it never wait on tile requests in flight), %32 steps that request a tile, %33 ring slot of the
+first step's tile, %34 wave, %35 / %36 first row of the first tile to request (Q / dO, this head), %37 / %38 bytes between a wave's
+pieces (16 rows), %39 / %40 statistics of the first tile to request (lse2, -delta) ("s");
+%41 / %42 the masks' per-lane bounds ("v"): a score of key kl and row ql = qt0 + 4 h + c (c = the register's row inside the step) survives iff
+unsigned(c - lo) < range with lo = kl - qt0 - 4 h of the first step (the loop subtracts 64 per step) and range = len - kl (0 = lane off);
+%43-%46 / %47-%50 lane offsets of the four Q / dO pieces of a PARTIAL last tile (rows clamped to the sequence), %51 the same for its
+statistics row ("v"), %52 = 1 when the run's last request is that partial tile ("s"); %59 first call of the key block, %60 tiles to request up front (<= 3), %61 which of them is the partial last tile (7: none) ("s");
+%55 - %58: always-valid addresses (the key block's
+first Q / dO tile and statistics rows) that the requests of the steps without a tile left read into the dummy chunk ("s").
+The masked phases cost three more vector instructions per score."""
+import sys
+
+LOOKAHEAD, CAP, CAP_MASKED = 6, 5, 9
+X = [64, 96]; Y = [80, 112]; PB = [128, 144]; ZB = [136, 152]; SL = 160; RING = 176
+QRE, QRO, DRE, DRO, QC0, QC1, DC0, DC1, STAT, DSOFF, LANE4, LANE, V_LO, V_T, V_NINF = 208, 209, 210, 211, 212, 213, 214, 215, 216, 217, 218, 219, 220, 221, 222
+S_SLOT, S_CNT, S_DMALEFT, S_TOFF, S_TMP, S_TMP2 = "s72", "s73", "s74", "s75", "s76", "s77"
+QP, DP, LP, NP, DSP = (78, 79), (80, 81), (82, 83), (84, 85), (86, 87)
+S_DSTQ, S_M0SAVE, S_DSTS, S_USEALT, S_ISSUED = "s88", "s89", "s90", "s91", "s96"
+QORG, DORG, SRC = (92, 93), (94, 95), (98, 99)
+DUMMY_LDS = 133120                  # 1 KiB behind the statistics: where the requests of the steps without a tile land
+MASKED = False
+PHASE = "a"
+DO_LDS, LSE_LDS, ND_DELTA, NSLOT = 65536, 131072, 1024, 4
+VM_STEADY = 32                      # vector-memory operations issued behind the requests of tile t+1 when step t waits for it: 3 x 4 stores + 2 x 10 requests
+WAIT_GAP = 64 - LOOKAHEAD - 1
+DMA_GAPS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]      # the quiet head of the step (no vector work yet): tile t+3 into the slot tile t-1 left at the last barrier
+
+
+def vr(lo, n):
+    return "v[%d:%d]" % (lo, lo + n - 1) if n > 1 else "v%d" % lo
+
+
+def sp(pair):
+    return "s[%d:%d]" % pair
+
+
+class Ins:
+    def __init__(self, text, kind, reads=(), writes=(), lds_defs=None, cost=0):
+        self.text, self.kind, self.reads, self.writes, self.lds_defs, self.cost = text, kind, set(reads), set(writes), lds_defs, cost
+
+
+def regs(lo, n):
+    return ["v%d" % i for i in range(lo, lo + n)]
+
+
+def mfma_list():
+    out = []
+    for sub in (0, 1):
+        for ks in range(8):
+            out.append(dict(prod="S", sub=sub, ks=ks, a=("row", "q", sub, ks)))
+        for ks in range(8):
+            out.append(dict(prod="dP", sub=sub, ks=ks, a=("row", "do", sub, ks)))
+    for sub in (0, 1):
+        for i in range(8):
+            out.append(dict(prod="dV", sub=sub, i=i, a=("col", "do", sub, i)))
+        for i in range(8):
+            out.append(dict(prod="dK", sub=sub, i=i, a=("col", "q", sub, i)))
+    return out
+
+
+def a_loads(desc, slot):
+    kind, which, sub, j = desc
+    base = RING + 4 * slot
+    if kind == "row":
+        ks = j
+        addr = (QRE, QRO)[ks & 1] if which == "q" else (DRE, DRO)[ks & 1]
+        off = 8192 * sub + 512 * (ks >> 1)
+        return [Ins("ds_read_b128 %s, v%d offset:%d" % (vr(base, 4), addr, off), "lds", reads=["v%d" % addr], writes=regs(base, 4), lds_defs=regs(base, 4))]
+    k16, dt = j // 4, j % 4
+    c0, c1 = (QC0, QC1) if which == "q" else (DC0, DC1)
+    o0 = 2048 * (4 * sub + 2 * k16) + 512 * dt
+    return [Ins("ds_read_b64_tr_b16 %s, v%d offset:%d" % (vr(base, 2), c0, o0), "lds", reads=["v%d" % c0], writes=regs(base, 2), lds_defs=regs(base, 2)),
+            Ins("ds_read_b64_tr_b16 %s, v%d offset:%d" % (vr(base + 2, 2), c1, o0 + 2048), "lds", reads=["v%d" % c1], writes=regs(base + 2, 2),
+                lds_defs=regs(base + 2, 2))]
+
+
+def mfma_ins(n, m):
+    slot = RING + 4 * (n % 8)
+    a = vr(slot, 4)
+    if m["prod"] == "S":
+        d = vr(X[m["sub"]], 16)
+        c = "0" if m["ks"] == 0 else d
+        return Ins("v_mfma_f32_32x32x16_bf16 %s, %s, %%%d, %s" % (d, a, 8 + m["ks"], c), "mfma",
+                   reads=regs(slot, 4) + (regs(X[m["sub"]], 16) if m["ks"] else []), writes=regs(X[m["sub"]], 16))
+    if m["prod"] == "dP":
+        d = vr(Y[m["sub"]], 16)
+        return Ins("v_mfma_f32_32x32x16_bf16 %s, %s, %%%d, %s" % (d, a, 16 + m["ks"], d), "mfma", reads=regs(slot, 4) + regs(Y[m["sub"]], 16),
+                   writes=regs(Y[m["sub"]], 16))
+    k16, dt = m["i"] // 4, m["i"] % 4
+    if m["prod"] == "dV":
+        b = PB[m["sub"]] + 4 * k16
+        return Ins("v_mfma_f32_32x32x16_bf16 %%%d, %s, %s, %%%d" % (dt, a, vr(b, 4), dt), "mfma", reads=regs(slot, 4) + regs(b, 4))
+    b = ZB[m["sub"]] + 4 * k16
+    return Ins("v_mfma_f32_32x32x16_bf16 %%%d, %s, %s, %%%d" % (4 + dt, a, vr(b, 4), 4 + dt), "mfma", reads=regs(slot, 4) + regs(b, 4))
+
+
+def valu_ops(sub):
+    x, y, pb, zb = X[sub], Y[sub], PB[sub], ZB[sub]
+    A = lambda r: Ins("v_fma_f32 v%d, v%d, %%30, -v%d" % (x + r, x + r, SL + r), "valu", reads=["v%d" % (x + r), "v%d" % (SL + r)], writes=["v%d" % (x + r)], cost=1)
+    B = lambda r: Ins("v_exp_f32_e32 v%d, v%d" % (x + r, x + r), "trans", reads=["v%d" % (x + r)], writes=["v%d" % (x + r)], cost=2)
+    C = lambda r: Ins("v_mul_f32_e32 v%d, v%d, v%d" % (y + r, x + r, y + r), "valu", reads=["v%d" % (x + r), "v%d" % (y + r)], writes=["v%d" % (y + r)], cost=1)
+    Dp = lambda i: Ins("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (pb + i, x + 2 * i, x + 2 * i + 1), "valu", reads=["v%d" % (x + 2 * i), "v%d" % (x + 2 * i + 1)],
+                       writes=["v%d" % (pb + i)], cost=1)
+    E = lambda i: Ins("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (zb + i, y + 2 * i, y + 2 * i + 1), "valu", reads=["v%d" % (y + 2 * i), "v%d" % (y + 2 * i + 1)],
+                      writes=["v%d" % (zb + i)], cost=1)
+    def Mk(r):      # x = -inf unless unsigned(c_r - lo) < range: three dependent instructions kept together (they share VCC)
+        c = 32 * sub + (r & 3) + 8 * (r >> 2)
+        return [Ins("v_sub_u32_e32 v%d, %d, v%d" % (V_T, c, V_LO), "valu", reads=["v%d" % V_LO], writes=["v%d" % V_T], cost=1),
+                Ins("v_cmp_lt_u32_e32 vcc, v%d, %%42" % V_T, "valu", reads=["v%d" % V_T], cost=1),
+                Ins("v_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (x + r, V_NINF, x + r), "valu", reads=["v%d" % (x + r), "v%d" % V_NINF], writes=["v%d" % (x + r)], cost=1)]
+    AM = (lambda r: Mk(r) + [A(r)]) if MASKED else (lambda r: [A(r)])
+    s1 = AM(0) + AM(1) + AM(2) + AM(3)
+    for r in range(12):
+        s1 += [B(r)] + AM(r + 4)
+    s1 += [B(12), B(13), B(14), B(15)]
+    s2 = []
+    for i in range(8):
+        s2 += [C(2 * i), C(2 * i + 1), Dp(i)]
+        if i >= 1:
+            s2.append(E(i - 1))
+    s2.append(E(7))
+    return [(1, o) for o in s1] + [(2, o) for o in s2]
+
+
+def addr_setup():
+    """address registers of the tile in ring slot S_SLOT (S_TOFF = slot * 16 KiB)"""
+    o = []
+    o.append(Ins("v_add_u32_e32 v%d, %s, %%24" % (QRE, S_TOFF), "valu", writes=["v%d" % QRE], cost=1))
+    o.append(Ins("v_xor_b32_e32 v%d, 32, v%d" % (QRO, QRE), "valu", reads=["v%d" % QRE], writes=["v%d" % QRO], cost=1))
+    o.append(Ins("v_add_u32_e32 v%d, %d, v%d" % (DRE, DO_LDS, QRE), "valu", reads=["v%d" % QRE], writes=["v%d" % DRE], cost=1))
+    o.append(Ins("v_add_u32_e32 v%d, %d, v%d" % (DRO, DO_LDS, QRO), "valu", reads=["v%d" % QRO], writes=["v%d" % DRO], cost=1))
+    o.append(Ins("v_add_u32_e32 v%d, %s, %%25" % (QC0, S_TOFF), "valu", writes=["v%d" % QC0], cost=1))
+    o.append(Ins("v_xor_b32_e32 v%d, 32, v%d" % (QC1, QC0), "valu", reads=["v%d" % QC0], writes=["v%d" % QC1], cost=1))
+    o.append(Ins("v_add_u32_e32 v%d, %d, v%d" % (DC0, DO_LDS, QC0), "valu", reads=["v%d" % QC0], writes=["v%d" % DC0], cost=1))
+    o.append(Ins("v_add_u32_e32 v%d, %d, v%d" % (DC1, DO_LDS, QC1), "valu", reads=["v%d" % QC1], writes=["v%d" % DC1], cost=1))
+    o.append(Ins("s_lshl_b32 %s, %s, 8" % (S_TMP, S_SLOT), "salu"))
+    o.append(Ins("s_add_u32 %s, %s, %d" % (S_TMP, S_TMP, LSE_LDS), "salu"))
+    o.append(Ins("v_add_u32_e32 v%d, %s, %%26" % (STAT, S_TMP), "valu", writes=["v%d" % STAT], cost=1))
+    return o
+
+
+def dma_groups():
+    """[list of instruction texts] x 10: the requests of the tile three steps ahead - WITHOUT a taken branch on the common path (a taken
+    branch costs the wave tens of cycles, and eleven of them per step were a sixth of the step).  When no tile is left (the last steps of a
+    key block) the requests are still issued, redirected to a 1-KiB dummy chunk of LDS and to the first tile's rows: harmless, and the
+    step's vector-memory operations stay the same fourteen, so the wait for tile t+1 is ONE counted vmcnt in every step.  Only the partial
+    last tile of a sequence (rows clamped piece by piece: S_USEALT) leaves the line, to code behind the loop (`ool`)."""
+    groups, ool = [], []
+    pre = ["s_add_u32 %s, %s, 3" % (S_TMP, S_SLOT), "s_and_b32 %s, %s, 3" % (S_TMP, S_TMP), "s_lshl_b32 %s, %s, 14" % (S_DSTQ, S_TMP),
+           "s_lshl_b32 %s, %%34, 10" % S_TMP2, "s_add_u32 %s, %s, %s" % (S_DSTQ, S_DSTQ, S_TMP2), "s_lshl_b32 %s, %s, 8" % (S_DSTS, S_TMP),
+           "s_add_u32 %s, %s, %d" % (S_DSTS, S_DSTS, LSE_LDS),
+           "s_cmp_eq_u32 %s, 1" % S_DMALEFT, "s_cselect_b32 %s, %%52, 0" % S_USEALT, "s_min_u32 %s, %s, 1" % (S_ISSUED, S_DMALEFT),
+           "s_mov_b64 %s, %s" % (sp(QORG), sp(QP)), "s_mov_b64 %s, %s" % (sp(DORG), sp(DP))]
+    k = 0
+    for which, ptr, org, voff, piece, base, alt0, safe in (("q", QP, QORG, "%27", "%37", 0, 43, "%55"), ("do", DP, DORG, "%28", "%38", DO_LDS, 47, "%56")):
+        for i in range(4):
+            g = ["s_add_u32 %s, %s, %d" % (S_TMP, S_DSTQ, base + 4096 * i), "s_cmp_lg_u32 %s, 0" % S_ISSUED, "s_cselect_b32 m0, %s, %d" % (S_TMP, DUMMY_LDS),
+                 "s_cselect_b64 %s, %s, %s" % (sp(SRC), sp(ptr), safe), "s_cmp_lg_u32 %s, 0" % S_USEALT, "s_cbranch_scc1 .Ldkv3_a%d%s_%%=" % (k, PHASE),
+                 "global_load_lds_dwordx4 %s, %s" % (voff, sp(SRC)), ".Ldkv3_j%d%s_%%=:" % (k, PHASE),
+                 "s_add_u32 s%d, s%d, %s" % (ptr[0], ptr[0], piece), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])]
+            ool += [".Ldkv3_a%d%s_%%=:" % (k, PHASE), "global_load_lds_dwordx4 %%%d, %s" % (alt0 + i, sp(org)), "s_branch .Ldkv3_j%d%s_%%=" % (k, PHASE)]
+            groups.append((pre if k == 0 else []) + g)
+            k += 1
+    for ptr, extra, safe in ((LP, 0, "%57"), (NP, ND_DELTA, "%58")):
+        g = ["s_add_u32 %s, %s, %d" % (S_TMP, S_DSTS, extra), "s_cmp_lg_u32 %s, 0" % S_ISSUED, "s_cselect_b32 m0, %s, %d" % (S_TMP, DUMMY_LDS),
+             "s_cselect_b64 %s, %s, %s" % (sp(SRC), sp(ptr), safe), "s_cmp_lg_u32 %s, 0" % S_USEALT, "s_cbranch_scc1 .Ldkv3_a%d%s_%%=" % (k, PHASE),
+             "global_load_lds_dword v%d, %s" % (LANE4, sp(SRC)), ".Ldkv3_j%d%s_%%=:" % (k, PHASE),
+             "s_add_u32 s%d, s%d, 256" % (ptr[0], ptr[0]), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])]
+        ool += [".Ldkv3_a%d%s_%%=:" % (k, PHASE), "global_load_lds_dword %%51, %s" % sp(ptr), "s_branch .Ldkv3_j%d%s_%%=" % (k, PHASE)]
+        groups.append(g)
+        k += 1
+    return groups, ool
+
+
+def build_body():
+    M = mfma_list()
+    gaps = [[] for _ in range(64)]
+    for n in range(64):
+        g = n - LOOKAHEAD
+        if g >= 0:
+            gaps[g] += a_loads(M[n]["a"], n % 8)
+
+    def stat(sub, j, which):
+        off = (ND_DELTA if which == "nd" else 0) + 128 * sub + 32 * j
+        dst = (Y[sub] if which == "nd" else SL) + 4 * j
+        return Ins("ds_read_b128 %s, v%d offset:%d" % (vr(dst, 4), STAT, off), "lds", reads=["v%d" % STAT], writes=regs(dst, 4), lds_defs=regs(dst, 4))
+    for j in range(4):
+        gaps[0 + j].append(stat(0, j, "nd"))
+        gaps[4 + j].append(stat(0, j, "lse"))
+        gaps[15 + j].append(stat(1, j, "nd"))
+        gaps[19 + j].append(stat(1, j, "lse"))
+    chain_end = {("S", 0): 7, ("dP", 0): 15, ("S", 1): 23, ("dP", 1): 31}
+    used = [sum(i.cost for i in g) for g in gaps]
+    for sub in (0, 1):
+        g = 0
+        for stage, ins in valu_ops(sub):
+            earliest = chain_end[("S", sub)] + 2 if stage == 1 else max(chain_end[("dP", sub)] + 2, g)
+            g = max(g, earliest)
+            while used[g] + ins.cost > (CAP_MASKED if MASKED else CAP):
+                g += 1
+            gaps[g].append(ins)
+            used[g] += ins.cost
+        assert g < 48, "vector work of a sub-tile ran past its packs' consumers"
+
+    def last_gap_writing(regnames):
+        lg = -1
+        for gi, g in enumerate(gaps):
+            for ins in g:
+                if ins.writes & set(regnames):
+                    lg = max(lg, gi)
+        return lg
+    for sub in (0, 1):
+        g0 = last_gap_writing(regs(ZB[sub], 8)) + 1
+        for half in (0, 1):
+            assert g0 + half < WAIT_GAP           # (the vmcnt arithmetic assumes the step's stores are issued in front of its wait)
+            gaps[g0 + half].append(Ins("global_store_dwordx4 v%d, %s, %s offset:%d nt" % (DSOFF, vr(ZB[sub] + 4 * half, 4), sp(DSP), 2048 * sub + 1024 * half),
+                                       "vmem", reads=regs(ZB[sub] + 4 * half, 4) + ["v%d" % DSOFF]))
+    dma, ool = dma_groups()
+    # gap WAIT_GAP (behind the reads of MFMA 63): tile t+1 has landed for every wave; move on to its slot
+    # the wait: tile t+1 was requested three steps ago; while this step still requested a tile, VM_STEADY younger operations may stay in flight
+    w = ["s_waitcnt vmcnt(%d)" % VM_STEADY, "s_barrier",
+         "s_add_u32 %s, %s, 1" % (S_SLOT, S_SLOT), "s_and_b32 %s, %s, %d" % (S_SLOT, S_SLOT, NSLOT - 1), "s_lshl_b32 %s, %s, 14" % (S_TOFF, S_SLOT),
+         "s_add_u32 s%d, s%d, 16384" % (DSP[0], DSP[0]), "s_addc_u32 s%d, s%d, 0" % (DSP[1], DSP[1]),
+         "v_subrev_u32_e32 v%d, 64, v%d" % (V_LO, V_LO)]      # the next step's rows lie 64 further down: lo -= 64 (kept in both variants)
+    gaps[WAIT_GAP] += [Ins(t, "raw") for t in w] + addr_setup()
+    for n in range(LOOKAHEAD):
+        gaps[64 - LOOKAHEAD + n] += a_loads(M[n]["a"], n % 8)
+    for k, grp in enumerate(dma):
+        gaps[DMA_GAPS[k]] += [Ins(t, "raw") for t in grp]
+    gaps[DMA_GAPS[-1]] += [Ins(t, "raw") for t in ("s_sub_u32 %s, %s, 1" % (S_DMALEFT, S_DMALEFT), "s_max_i32 %s, %s, 0" % (S_DMALEFT, S_DMALEFT))]
+    return M, gaps, ool
+
+
+def linearize(M, gaps):
+    seq = []
+    for n in range(64):
+        seq.append(mfma_ins(n, M[n]))
+        seq += gaps[n]
+    return seq
+
+
+def insert_waits(seq, carried):
+    fifo = list(carried)
+    pending = {}
+    for e in fifo:
+        for r in e["defs"]:
+            pending[r] = e
+    lines = []
+    prev = None
+    for ins in seq:
+        need = [pending[r] for r in (ins.reads | ins.writes) if r in pending]
+        if need:
+            last = max(fifo.index(e) for e in need)
+            cnt = len(fifo) - 1 - last
+            assert cnt <= 15, "lgkmcnt field overflow"
+            lines.append("s_waitcnt lgkmcnt(%d)" % cnt)
+            for e in fifo[:last + 1]:
+                for r in e["defs"]:
+                    if pending.get(r) is e:
+                        del pending[r]
+            fifo = fifo[last + 1:]
+        if prev is not None and prev.kind == "trans" and ins.kind in ("valu", "trans", "mfma", "vmem") and (prev.writes & ins.reads):
+            lines.append("s_nop 0")
+        lines.append(ins.text)
+        if ins.kind == "lds":
+            e = {"defs": set(ins.lds_defs)}
+            fifo.append(e)
+            for r in e["defs"]:
+                pending[r] = e
+        assert len(fifo) <= 15, "more than 15 LDS reads in flight"
+        if ins.kind not in ("salu", "raw"):
+            prev = ins
+    return lines, fifo
+
+
+def check(seq):
+    pos_mfma = [i for i, s in enumerate(seq) if s.kind == "mfma"]
+    last_writer = {}
+    for i, s in enumerate(seq):
+        if s.kind in ("valu", "trans", "vmem"):
+            for r in s.reads:
+                if r in last_writer and last_writer[r][0] == "mfma":
+                    assert sum(1 for p in pos_mfma if last_writer[r][1] < p < i) >= 2, "%s reads %s too close behind its MFMA chain" % (s.text, r)
+        if s.kind == "mfma":
+            for r in s.reads:
+                if r in last_writer and last_writer[r][0] in ("valu", "trans"):
+                    assert i - last_writer[r][1] >= 4, "%s reads %s right behind the vector write" % (s.text, r)
+        for r in s.writes:
+            last_writer[r] = (s.kind, i)
+
+
+def variant(masked, phase):
+    global MASKED, PHASE
+    MASKED, PHASE = masked, phase
+    M, gaps, ool = build_body()
+    seq = linearize(M, gaps)
+    check(seq + seq)
+    carried = []
+    for n in range(LOOKAHEAD):
+        for l in a_loads(M[n]["a"], n % 8):
+            carried.append({"defs": set(l.lds_defs)})
+    lines1, fifo1 = insert_waits(seq, carried)
+    lines2, fifo2 = insert_waits(seq, fifo1)
+    assert lines1 == lines2 and [sorted(e["defs"]) for e in fifo1] == [sorted(e["defs"]) for e in fifo2], "loop is not in steady state"
+    nv = sum(1 for s in seq if s.kind in ("valu", "trans"))
+    nl = sum(1 for s in seq if s.kind == "lds")
+    print("phase %s (%s): 64 MFMAs, %d vector, %d LDS reads, %d asm lines per iteration" % (phase, "masked" if masked else "plain", nv, nl, len(lines1)))
+    return M, lines1, ool
+
+
+def main():
+    import os
+    out = os.environ.get("DKV3_OUT", "sdpa_dkv3_loop.inc")
+    M, body_a, ool_a = variant(True, "a")
+    _, body_b, ool_b = variant(False, "b")
+    _, body_c, ool_c = variant(True, "c")
+    pro = ["s_waitcnt lgkmcnt(0)", "s_mov_b32 %s, m0" % S_M0SAVE,
+           "v_mbcnt_lo_u32_b32 v%d, -1, 0" % LANE, "v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (LANE, LANE),
+           "v_lshlrev_b32_e32 v%d, 4, v%d" % (DSOFF, LANE), "v_lshlrev_b32_e32 v%d, 2, v%d" % (LANE4, LANE),
+           "s_mov_b32 %s, %%33" % S_SLOT, "s_mov_b32 %s, %%32" % S_DMALEFT,
+           "s_mov_b64 %s, %%35" % sp(QP), "s_mov_b64 %s, %%36" % sp(DP), "s_mov_b64 %s, %%39" % sp(LP), "s_mov_b64 %s, %%40" % sp(NP), "s_mov_b64 %s, %%29" % sp(DSP),
+           "s_lshl_b32 %s, %s, 14" % (S_TOFF, S_SLOT), "v_mov_b32_e32 v%d, %%41" % V_LO, "v_mov_b32_e32 v%d, 0xff800000" % V_NINF]
+    global PHASE
+    PHASE = "p"
+    # ---- first call of a key block (%59 != 0): zero the accumulators and request the block's first %60 (<= 3) tiles + statistics rows here,
+    #      with the loop's own cheap form of a request (the caller has passed the barrier behind the previous block's last reads); tile %61
+    #      of them (7 = none) is the sequence's partial last tile and takes the clamped lane offsets.  Then everything has to land.
+    pro += ["s_cmp_eq_u32 %59, 0", "s_cbranch_scc1 .Ldkv3_nofirst_%="]
+    # (an accumulator tuple operand cannot be sliced into single registers from here: it is zeroed by an MFMA of zero fragments, D = 0 * 0 + 0)
+    pro += ["v_mov_b32_e32 v%d, 0" % (RING + j) for j in range(4)] + ["s_nop 4"]
+    for opnd in range(8):
+        pro += ["ZERO_TUPLE %%%d" % opnd]
+    for i in range(3):
+        pro += ["s_cmp_le_u32 %%60, %d" % i, "s_cbranch_scc1 .Ldkv3_prodone_%="]
+        pro += ["s_add_u32 %s, %s, %d" % (S_TMP, S_SLOT, i), "s_and_b32 %s, %s, 3" % (S_TMP, S_TMP), "s_lshl_b32 %s, %s, 14" % (S_DSTQ, S_TMP),
+                "s_lshl_b32 %s, %%34, 10" % S_TMP2, "s_add_u32 %s, %s, %s" % (S_DSTQ, S_DSTQ, S_TMP2), "s_lshl_b32 %s, %s, 8" % (S_DSTS, S_TMP),
+                "s_add_u32 %s, %s, %d" % (S_DSTS, S_DSTS, LSE_LDS), "s_mov_b64 %s, %s" % (sp(QORG), sp(QP)), "s_mov_b64 %s, %s" % (sp(DORG), sp(DP)),
+                "s_cmp_eq_u32 %%61, %d" % i, "s_cselect_b32 %s, 1, 0" % S_USEALT]
+        for which, ptr, org, voff, piece, base, alt0 in (("q", QP, QORG, "%27", "%37", 0, 43), ("do", DP, DORG, "%28", "%38", DO_LDS, 47)):
+            for k in range(4):
+                pro += ["s_add_u32 m0, %s, %d" % (S_DSTQ, base + 4096 * k), "s_cmp_lg_u32 %s, 0" % S_USEALT, "s_cbranch_scc1 .Ldkv3_pa%d%s%d_%%=" % (i, which, k),
+                        "global_load_lds_dwordx4 %s, %s" % (voff, sp(ptr)), "s_branch .Ldkv3_pj%d%s%d_%%=" % (i, which, k),
+                        ".Ldkv3_pa%d%s%d_%%=:" % (i, which, k), "global_load_lds_dwordx4 %%%d, %s" % (alt0 + k, sp(org)), ".Ldkv3_pj%d%s%d_%%=:" % (i, which, k),
+                        "s_add_u32 s%d, s%d, %s" % (ptr[0], ptr[0], piece), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])]
+        for which, ptr, extra in (("l", LP, 0), ("n", NP, ND_DELTA)):
+            pro += ["s_add_u32 m0, %s, %d" % (S_DSTS, extra), "s_cmp_lg_u32 %s, 0" % S_USEALT, "s_cbranch_scc1 .Ldkv3_pa%d%s_%%=" % (i, which),
+                    "global_load_lds_dword v%d, %s" % (LANE4, sp(ptr)), "s_branch .Ldkv3_pj%d%s_%%=" % (i, which),
+                    ".Ldkv3_pa%d%s_%%=:" % (i, which), "global_load_lds_dword %%51, %s" % sp(ptr), ".Ldkv3_pj%d%s_%%=:" % (i, which),
+                    "s_add_u32 s%d, s%d, 256" % (ptr[0], ptr[0]), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])]
+    pro += [".Ldkv3_prodone_%=:", "s_waitcnt vmcnt(0)", "s_barrier", ".Ldkv3_nofirst_%=:"]
+    pro += [i.text for i in addr_setup()]
+    for n in range(LOOKAHEAD):
+        pro += [l.text for l in a_loads(M[n]["a"], n % 8)]
+    lines = list(pro)
+    for phase, body, count in (("a", body_a, "%31"), ("b", body_b, "%53"), ("c", body_c, "%54")):
+        lines += ["s_mov_b32 %s, %s" % (S_CNT, count), "s_cmp_eq_u32 %s, 0" % S_CNT, "s_cbranch_scc1 .Ldkv3_skip%s_%%=" % phase, ".Ldkv3_loop%s_%%=:" % phase]
+        lines += body
+        lines += ["s_sub_u32 %s, %s, 1" % (S_CNT, S_CNT), "s_cmp_lg_u32 %s, 0" % S_CNT, "s_cbranch_scc1 .Ldkv3_loop%s_%%=" % phase, ".Ldkv3_skip%s_%%=:" % phase]
+    lines += ["s_branch .Ldkv3_end_%="] + ool_a + ool_b + ool_c + [".Ldkv3_end_%=:", "s_waitcnt lgkmcnt(0)", "s_mov_b32 m0, %s" % S_M0SAVE]
+    expanded = []
+    for l in lines:
+        if l.startswith("ZERO_TUPLE"):      # D = 0 * 0 + 0: the operand tuple cannot be sliced into single registers from here
+            expanded.append("v_mfma_f32_32x32x16_bf16 %s, v[%d:%d], v[%d:%d], 0" % (l.split()[1], RING, RING + 3, RING, RING + 3))
+        else:
+            expanded.append(l)
+    lines = expanded
+    diag = os.environ.get("DKV3_DIAG", "")      # timing experiments only (results are wrong): nodma / nobar / nostore, comma separated
+    if "nodma" in diag:
+        lines = [l for l in lines if not l.startswith("global_load_lds")]
+    if "nobar" in diag:
+        lines = [l for l in lines if l != "s_barrier" and not l.startswith("s_waitcnt vmcnt")]
+    if "nostore" in diag:
+        lines = [l for l in lines if not l.startswith("global_store")]
+    with open(out, "w") as f:
+        f.write("// generated by gen_dkv3_loop.py - do not edit (python3 gen_dkv3_loop.py)\n")
+        for l in lines:
+            f.write('"%s\\n\\t"\n' % l)
+    with open(os.environ.get("DKV3_OUT", "sdpa_dkv3_loop.inc").replace(".inc", "_clobbers.inc"), "w") as f:
+        f.write("// generated by gen_dkv3_loop.py - do not edit\n")
+        f.write(", ".join('"v%d"' % i for i in range(64, 223)) + ",\n" + ", ".join('"s%d"' % i for i in range(72, 100)) + ', "vcc", "scc", "memory"\n')
+    print("%s: %d asm lines" % (out, len(lines)))
+
+
+if __name__ == "__main__":
+    main()

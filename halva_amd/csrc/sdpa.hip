@@ -43,13 +43,28 @@ constexpr float kLn2 = 0.6931471805599453f;
 unsigned long long* g_dbg = nullptr;
 extern "C" unsigned long long* halva_dbg_buffer() {
     if (!g_dbg) {
-        (void)hipMalloc(&g_dbg, 4096 * 8);
-        (void)hipMemset(g_dbg, 0, 4096 * 8);
+        (void)hipMalloc(&g_dbg, 8192 * 8);
+        (void)hipMemset(g_dbg, 0, 8192 * 8);
     }
     return g_dbg;
 }
+// whole-workgroup clock stamp: cycles (s_memtime) and 100 MHz ticks (s_memrealtime) of every 8th workgroup -> in-kernel clock of THIS kernel
+// (MI355X_MICROARCH.md, DVFS give-back item 6); slot k of the debug buffer's upper half: {cycles, ticks, start tick, block}
+#define WG_CLOCK_BEGIN() const unsigned long long wgc0_ = __builtin_amdgcn_s_memtime(), wgr0_ = __builtin_amdgcn_s_memrealtime()
+#define WG_CLOCK_END(dbg, region)                                                                                     \
+    do {                                                                                                              \
+        if ((dbg) && threadIdx.x == 0 && blockIdx.x % 8 == 0 && blockIdx.x / 8 < 120) {                               \
+            unsigned long long* o_ = (dbg) + 4096 + (region)*480 + (blockIdx.x / 8) * 4;                              \
+            o_[0] = __builtin_amdgcn_s_memtime() - wgc0_;                                                             \
+            o_[1] = __builtin_amdgcn_s_memrealtime() - wgr0_;                                                         \
+            o_[2] = wgr0_;                                                                                            \
+            o_[3] = blockIdx.x;                                                                                       \
+        }                                                                                                             \
+    } while (0)
 #else
 #define STAMP(i)
+#define WG_CLOCK_BEGIN()
+#define WG_CLOCK_END(dbg, region)
 #endif
 
 struct SdpaParams {
@@ -64,6 +79,7 @@ struct SdpaParams {
     bf16_t* dv;
     float* lse;           // [S, H, T]
     float* delta;         // [S, H, T]
+    float* lse2;          // [S, H, T] lse * log2(e), written by the delta pass for sdpa_bwd_dkv3 (tail of the dS workspace), or nullptr
     const int32_t* seq_start;
     const int32_t* seq_len;
     const int32_t* br_a;  // optional per-sequence branch points (local indices; br_b a multiple of 64), include/halva_hip.h:
@@ -754,6 +770,7 @@ __global__ __launch_bounds__(512) void sdpa_fwd_kernel(const SdpaParams p) {
     const int len = p.seq_len ? p.seq_len[s] : p.T;
     const Branch br = load_branch(p, s);
     s16x8 qf[D / 16];
+    WG_CLOCK_BEGIN();
     if (CAUSAL) {
         const int first = p.nblk - 1 - b, second = (b != first) ? b : -1;
         sdpa_fwd_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, first, second, false, true, qf, start, len, br);
@@ -761,6 +778,7 @@ __global__ __launch_bounds__(512) void sdpa_fwd_kernel(const SdpaParams p) {
     } else {
         sdpa_fwd_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, b, -1, false, true, qf, start, len, br);
     }
+    WG_CLOCK_END(p.dbg, 0);
 }
 
 // ===================================================================================================
@@ -1342,8 +1360,10 @@ __global__ __launch_bounds__(512) void sdpa_bwd_dkv2_kernel(const SdpaParams p) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the role is a per-wave constant: branch on it once, on the scalar unit, so that each side gets its own register allocation
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    WG_CLOCK_BEGIN();
     if (wave < 4) sdpa_bwd_dkv2_role<D, CAUSAL, SLOW_TR, 0>(p, smem, wave);
     else sdpa_bwd_dkv2_role<D, CAUSAL, SLOW_TR, 1>(p, smem, wave - 4);      // (raising these waves' s_setprio changes nothing)
+    WG_CLOCK_END(p.dbg, 1);
 }
 
 // ===================================================================================================
@@ -1352,7 +1372,7 @@ __global__ __launch_bounds__(512) void sdpa_bwd_dkv2_kernel(const SdpaParams p) 
 // delta[s, h, t] = sum_d dO o O for every valid query row (both later kernels read it), and zeros into dq of the PADDED rows (the dQ
 // kernel below walks a sequence in its own coordinates and only writes its valid rows).  One wave per (row, 4 heads); HBM-bound.
 template <int D>
-__global__ __launch_bounds__(256) void sdpa_bwd_delta_kernel(const SdpaParams p, int S) {
+__global__ __launch_bounds__(256) void sdpa_bwd_delta_kernel(const SdpaParams p, int S, int for_dkv3) {
     constexpr int HPW = 512 / D;                       // heads per wave pass: 64 lanes x 8 elements
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1376,7 +1396,15 @@ __global__ __launch_bounds__(256) void sdpa_bwd_delta_kernel(const SdpaParams p,
         for (int i = 0; i < 4; ++i) acc += bf16_lo(ov[i]) * bf16_lo(dv[i]) + bf16_hi(ov[i]) * bf16_hi(dv[i]);
 #pragma unroll
         for (int o = D / 16; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
-        if (lane % (D / 8) == 0) p.delta[((int64_t)s * p.H + hd) * p.T + t] = acc;
+        if (lane % (D / 8) == 0) {
+            const int64_t at = ((int64_t)s * p.H + hd) * p.T + t;
+            if (for_dkv3) {      // sdpa_bwd_dkv3 starts its dP chain from -delta and fetches lse * log2(e) as a plain row (sdpa_dkv3.h)
+                p.delta[at] = -acc;
+                p.lse2[at] = p.lse[at] * kLog2e;
+            } else {
+                p.delta[at] = acc;
+            }
+        }
     }
 }
 
@@ -1523,8 +1551,19 @@ __global__ __launch_bounds__(512) void sdpa_bwd_dq2_kernel(const SdpaParams p) {
     int s, hd, b;
     map_block(blockIdx.x, (p.nblk + 1) / 2, p.H, p.npairs, false, s, hd, b);
     const int npass = (b != p.nblk - 1 - b) ? 2 : 1;
+    WG_CLOCK_BEGIN();
 #pragma unroll 1
     for (int pass = 0; pass < npass; ++pass) sdpa_bwd_dq2_block<D, SLOW_TR>(p, smem, s, hd, pass ? b : p.nblk - 1 - b, wave, lane);
+    WG_CLOCK_END(p.dbg, 2);
+}
+
+#include "sdpa_dkv3.h"
+
+// HALVA_SDPA_DKV3=0: the two-role dK/dV kernel of rounds 1-2 instead of sdpa_bwd_dkv3; HALVA_DKV3_ASM=0: sdpa_bwd_dkv3 with every step in
+// plain HIP (the generated loop off) - A/B and debugging switches, read on every call like the one below.
+bool env_flag_on(const char* name) {
+    const char* e = getenv(name);
+    return !(e && e[0] == '0');
 }
 
 // HALVA_SDPA_SLOW_TR=1 (tests): scalar transposed reads instead of ds_read_b64_tr_b16.  Read on every call - a test flips it inside
@@ -1580,6 +1619,33 @@ int launch_fwd(const SdpaParams& p_in, int S, hipStream_t st) {
                                : launch_one(sdpa_fwd_kernel<D, CAUSAL, false>, p, CAUSAL, 256, 512, lds, S, st, "sdpa_fwd");
 }
 
+// sdpa_bwd_dkv3: 4 waves, one per SIMD (512 registers), 128 keys per workgroup, 130 KiB of LDS (four Q / dO tile slots + statistics)
+template <bool CAUSAL>
+int launch_dkv3(SdpaParams p, int S, hipStream_t st) {
+    p.nblk = (p.T + 127) / 128;
+    p.npairs = S * p.H;
+    const int wg_per_pair = CAUSAL ? (p.nblk + 1) / 2 : p.nblk;
+    const bool use_asm = env_flag_on("HALVA_DKV3_ASM");
+    static std::atomic<int> attr_set[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
+        hipError_t ea = hipFuncSetAttribute((const void*)sdpa_bwd_dkv3_kernel<128, CAUSAL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV3_LDS);
+        if (ea == hipSuccess)
+            ea = hipFuncSetAttribute((const void*)sdpa_bwd_dkv3_kernel<128, CAUSAL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV3_LDS);
+        if (ea != hipSuccess) {
+            halva_set_error("sdpa_bwd_dkv3: hipFuncSetAttribute(%d B of LDS) failed: %s", DKV3_LDS, hipGetErrorString(ea));
+            return HALVA_ERR_LAUNCH;
+        }
+        if (dev >= 0 && dev < 64) attr_set[dev].store(1, std::memory_order_release);
+    }
+    const dim3 grid((unsigned)(wg_per_pair * p.npairs));
+    if (use_asm) hipLaunchKernelGGL((sdpa_bwd_dkv3_kernel<128, CAUSAL, true>), grid, dim3(256), DKV3_LDS, st, p);
+    else hipLaunchKernelGGL((sdpa_bwd_dkv3_kernel<128, CAUSAL, false>), grid, dim3(256), DKV3_LDS, st, p);
+    HALVA_CHECK_LAUNCH("sdpa_bwd_dkv3");
+    return HALVA_OK;
+}
+
 template <int D, bool CAUSAL>
 int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st) {
     SdpaParams p = p_in;
@@ -1591,9 +1657,13 @@ int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st) {
     const bool slow = slow_tr_requested();
     if (p.ds_ws != nullptr && D == 128) {      // dS formed once: delta (+ zero-fill of padded dq rows) -> dK/dV (+ dS store) -> dQ = dS K
         const int64_t rows = (int64_t)S * p.T;
-        hipLaunchKernelGGL((sdpa_bwd_delta_kernel<D>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, S);
+        const bool dkv3 = !slow && p.lse2 != nullptr && rows >= 16 && env_flag_on("HALVA_SDPA_DKV3");
+        hipLaunchKernelGGL((sdpa_bwd_delta_kernel<D>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, S, dkv3 ? 1 : 0);
         HALVA_CHECK_LAUNCH("sdpa_bwd_delta");      // (a failed launch would leave stale delta / unzeroed padded dq rows for the two kernels below)
-        int rc2 = slow ? launch_one(sdpa_bwd_dkv2_kernel<D, CAUSAL, true>, p, CAUSAL, 128, 512, lds_dkv, S, st, "sdpa_bwd_dkv2")
+        int rc2;
+        if (dkv3) rc2 = launch_dkv3<CAUSAL>(p, S, st);
+        else
+            rc2 = slow ? launch_one(sdpa_bwd_dkv2_kernel<D, CAUSAL, true>, p, CAUSAL, 128, 512, lds_dkv, S, st, "sdpa_bwd_dkv2")
                        : launch_one(sdpa_bwd_dkv2_kernel<D, CAUSAL, false>, p, CAUSAL, 128, 512, lds_dkv, S, st, "sdpa_bwd_dkv2");
         if (rc2 != HALVA_OK) return rc2;
         const size_t lds_dq2 = 3 * 64 * D * 2 + 8 * 3 * 4096;
@@ -1661,9 +1731,11 @@ extern "C" int halva_sdpa_causal_bwd_ld(const void* qkv, const void* out, int64_
                                  scale, stream);
 }
 
+static int64_t ds_region_bytes(int S, int T, int H) { return (int64_t)S * H * ((T + 127) / 128) * ((T + 63) / 64) * 16384; }
+
 extern "C" int64_t halva_sdpa_bwd_ws_bytes(int S, int T, int H, int D) {
     if (D != 128) return 0;                                      // the dS path is the head_dim-128 instantiation; others use the 3-product dQ kernel
-    return (int64_t)S * H * ((T + 127) / 128) * ((T + 63) / 64) * 16384;
+    return ds_region_bytes(S, T, H) + (int64_t)S * H * T * 4 + 256;     // dS, then [S, H, T] f32 lse * log2(e) for sdpa_bwd_dkv3 (+ one padding row)
 }
 
 extern "C" int halva_sdpa_branch_bwd(const void* qkv, const void* out, int64_t ld_out, const void* dout, int64_t ld_dout,
@@ -1709,6 +1781,7 @@ extern "C" int halva_sdpa_branch_bwd_ws(const void* qkv, const void* out, int64_
     p.T = T;
     p.H = H;
     p.ds_ws = D == 128 ? (char*)ds_ws : nullptr;
+    p.lse2 = p.ds_ws ? reinterpret_cast<float*>(p.ds_ws + ds_region_bytes(S, T, H)) : nullptr;
     p.ds_nkb = (T + 127) / 128;
     p.ds_nt = (T + 63) / 64;
     p.scale = scale > 0.f ? scale : 1.f / sqrtf((float)D);
