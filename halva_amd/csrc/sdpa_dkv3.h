@@ -134,8 +134,9 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_block(const SdpaParams& p, char* s
         }
     }
     if (ASM) {      // the generated block zeroes them itself on its first call (no copies into its operand registers)
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) asm volatile("" : "=a"(st.accV[dt]), "=a"(st.accK[dt]));
+        // (fixed accumulator registers, the same in every asm statement that touches them: no copies between the compiler's choice and the block's)
+        asm volatile("" : "={a[0:15]}"(st.accV[0]), "={a[16:31]}"(st.accV[1]), "={a[32:47]}"(st.accV[2]), "={a[48:63]}"(st.accV[3]), "={a[64:79]}"(st.accK[0]), "={a[80:95]}"(st.accK[1]), "={a[96:111]}"(st.accK[2]),
+                     "={a[112:127]}"(st.accK[3]));
     } else {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
@@ -174,11 +175,7 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_block(const SdpaParams& p, char* s
     DKV3_NOW(stamp[0]);                                                       // 6 before stores, 7 done, 8 first barrier passed, 9 requests issued, 10 tiles landed
 #endif
     // a step the UNMASKED phase may run: whole tile, every key of the block visible to every row, no padded key, no branch edge
-    auto interior = [&](int t) {
-        const int qt0 = q_begin + t * BQ;
-        const bool q_in_b = qt0 >= br.b;
-        return (qt0 + BQ <= len) && (!CAUSAL || qt0 >= kblk_min + 127) && block_all_keys_valid && !(q_in_b && kblk_min < br.b && kblk_min + 127 >= br.a);
-    };
+    // (the HIP build classifies per wave inside its step; the ASM build derives the three run lengths from the same conditions below)
     // lane parts of the LDS / global addresses of the generated loop
     const unsigned rowrel = 2048 * ((lane & 31) >> 3) + 64 * (lane & 7) + 16 * (h ^ (((lane & 31) >> 2) & 3));
     const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3, h2 = g16 >> 1;
@@ -215,11 +212,8 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_block(const SdpaParams& p, char* s
             if (i < ntiles && wave == 0) store_stats(i, sa[i], sb[i]);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else {      // (the generated block requests tiles 0..2 itself on its first call, and waits for them)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            DKV3_PIN_A(st.kq[ks]);
-            DKV3_PIN_A(st.vq[ks]);
-        }
+        asm volatile("" : "+{a[128:131]}"(st.kq[0]), "+{a[132:135]}"(st.kq[1]), "+{a[136:139]}"(st.kq[2]), "+{a[140:143]}"(st.kq[3]), "+{a[144:147]}"(st.kq[4]), "+{a[148:151]}"(st.kq[5]), "+{a[152:155]}"(st.kq[6]), "+{a[156:159]}"(st.kq[7]),
+                     "+{a[160:163]}"(st.vq[0]), "+{a[164:167]}"(st.vq[1]), "+{a[168:171]}"(st.vq[2]), "+{a[172:175]}"(st.vq[3]), "+{a[176:179]}"(st.vq[4]), "+{a[180:183]}"(st.vq[5]), "+{a[184:187]}"(st.vq[6]), "+{a[188:191]}"(st.vq[7]));
     }
 #ifdef HALVA_STAMP
     DKV3_NOW(stamp[9]);
@@ -239,9 +233,16 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_block(const SdpaParams& p, char* s
 #ifdef HALVA_DKV3_ALL_MASKED      // diagnostic: every step through the masked phase (same results: an interior step's masks pass everything)
             n0 = t_side - t, t1 = t_side;
 #else
-            while (t1 < t_side && !interior(t1)) ++t1, ++n0;
-            while (t1 < t_side && interior(t1)) ++t1, ++n1;
-            while (t1 < t_side && !interior(t1)) ++t1, ++n2;
+            {      // interior(t') on this side of br.b = side_ok && t_diag <= t' < t_full: three runs, no scan
+                const bool side_ok = block_all_keys_valid && !(q_in_b && kblk_min < br.b && kblk_min + 127 >= br.a);
+                const int t_diag = CAUSAL ? max(0, (kblk_min + 127 - q_begin + BQ - 1) / BQ) : 0;      // first t' with qt0 >= kblk_min + 127
+                const int t_full = max(0, (len - q_begin) / BQ);                                          // first t' with qt0 + 64 > len
+                const int lo = min(t_side, max(t, t_diag)), hi = min(t_side, max(lo, t_full));
+                n0 = side_ok ? lo - t : t_side - t;
+                n1 = side_ok ? hi - lo : 0;
+                n2 = t_side - t - n0 - n1;
+                t1 = t_side;
+            }
 #endif
             const int n = t1 - t;
             const int ndma = min(n, max(0, ntiles - 3 - t));      // steps t' of the call with a tile t'+3 to request
@@ -271,9 +272,9 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_block(const SdpaParams& p, char* s
 #endif
             asm volatile(
 #include "sdpa_dkv3_loop.inc"
-                : "+a"(st.accV[0]), "+a"(st.accV[1]), "+a"(st.accV[2]), "+a"(st.accV[3]), "+a"(st.accK[0]), "+a"(st.accK[1]), "+a"(st.accK[2]), "+a"(st.accK[3])
-                : "a"(st.kq[0]), "a"(st.kq[1]), "a"(st.kq[2]), "a"(st.kq[3]), "a"(st.kq[4]), "a"(st.kq[5]), "a"(st.kq[6]), "a"(st.kq[7]), "a"(st.vq[0]),
-                  "a"(st.vq[1]), "a"(st.vq[2]), "a"(st.vq[3]), "a"(st.vq[4]), "a"(st.vq[5]), "a"(st.vq[6]), "a"(st.vq[7]), "v"(rowrel), "v"(colrel),
+                : "+{a[0:15]}"(st.accV[0]), "+{a[16:31]}"(st.accV[1]), "+{a[32:47]}"(st.accV[2]), "+{a[48:63]}"(st.accV[3]), "+{a[64:79]}"(st.accK[0]), "+{a[80:95]}"(st.accK[1]), "+{a[96:111]}"(st.accK[2]), "+{a[112:127]}"(st.accK[3])
+                : "{a[128:131]}"(st.kq[0]), "{a[132:135]}"(st.kq[1]), "{a[136:139]}"(st.kq[2]), "{a[140:143]}"(st.kq[3]), "{a[144:147]}"(st.kq[4]), "{a[148:151]}"(st.kq[5]), "{a[152:155]}"(st.kq[6]), "{a[156:159]}"(st.kq[7]),
+                  "{a[160:163]}"(st.vq[0]), "{a[164:167]}"(st.vq[1]), "{a[168:171]}"(st.vq[2]), "{a[172:175]}"(st.vq[3]), "{a[176:179]}"(st.vq[4]), "{a[180:183]}"(st.vq[5]), "{a[184:187]}"(st.vq[6]), "{a[188:191]}"(st.vq[7]), "v"(rowrel), "v"(colrel),
                   "v"(statrel), "v"(voff_q), "v"(voff_do), "s"(ds_ptr), "s"(sc), "s"(n0_u), "s"(ndma_u), "s"(slot_u), "s"(wave_u), "s"(q_ptr), "s"(do_ptr),
                   "s"(q_piece), "s"(do_piece), "s"(lse_ptr), "s"(nd_ptr), "v"(lo0), "v"(range), "v"(alt_q[0]), "v"(alt_q[1]), "v"(alt_q[2]), "v"(alt_q[3]),
                   "v"(alt_do[0]), "v"(alt_do[1]), "v"(alt_do[2]), "v"(alt_do[3]), "v"(alt_stat), "s"(part_u), "s"(n1_u), "s"(n2_u), "s"(safe_q), "s"(safe_do),
