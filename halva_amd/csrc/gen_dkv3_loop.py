@@ -14,18 +14,20 @@ over S and dZ = P dP' in place over dP'.  This script assigns every instruction 
     result in the next issue slot, a packed operand is written >= 4 instructions before the MFMA that reads it.
 The stream was developed and timed in experiments/dkv3 (2 419 cycles per step against 3 650 for hipcc's own schedule, bit-identical).
 
-Operands of the asm block (sdpa_dkv3.h):  %0-%3 dV^T, %4-%7 dK^T accumulators ("+a"); %8-%15 K, %16-%23 V fragments ("a");
-%24 row-read, %25 transposed-read, %26 statistics lane offsets, %27 / %28 lane offsets of the Q / dO tile pieces ("v");
-%29 dS pointer of the first step (this wave's strip), %30 scale*log2 e, %31 / %53 / %54 steps of the three phases (masked, plain, masked: the diagonal steps, the interior, the tail - ONE asm block per key
-block and side of the branch point, so that the compiler's reloads around it never wait on tile requests in flight), %32 steps that request a tile, %33 ring slot of the
-first step's tile, %34 wave, %35 / %36 first row of the first tile to request (Q / dO, this head), %37 / %38 bytes between a wave's
-pieces (16 rows), %39 / %40 statistics of the first tile to request (lse2, -delta) ("s");
-%41 / %42 the masks' per-lane bounds ("v"): a score of key kl and row ql = qt0 + 4 h + c (c = the register's row inside the step) survives iff
-unsigned(c - lo) < range with lo = kl - qt0 - 4 h of the first step (the loop subtracts 64 per step) and range = len - kl (0 = lane off);
-%43-%46 / %47-%50 lane offsets of the four Q / dO pieces of a PARTIAL last tile (rows clamped to the sequence), %51 the same for its
-statistics row ("v"), %52 = 1 when the run's last request is that partial tile ("s"); %59 first call of the key block, %60 tiles to request up front (<= 3), %61 which of them is the partial last tile (7: none) ("s");
-%55 - %58: always-valid addresses (the key block's
-first Q / dO tile and statistics rows) that the requests of the steps without a tile left read into the dummy chunk ("s").
+Operands of the asm block (sdpa_dkv3.h), by NAME in the emitted text (%[name]; the %NN in this script are shorthand resolved in main()):
+accV0-3 / accK0-3 the dV^T / dK^T accumulators ("+a", fixed registers), kq0-7 / vq0-7 the K / V fragments ("a", fixed registers: possibly
+still in flight when the block is entered - its first call starts with s_waitcnt vmcnt(0)); rowrel, colrel, statrel the
+row-read, transposed-read and statistics lane offsets, voff_q / voff_do the lane offsets of the Q / dO tile pieces ("v"); sc = scale * log2 e,
+n02 / n1 the steps of the three phases (masked | plain | masked: the diagonal steps, the interior, the tail; n02 = first | last << 16),
+ndma the steps that request a tile, wave, q_piece / do_piece the bytes between a wave's pieces (16 rows) ("s");
+lo0 / range the masks' per-lane bounds ("v"): a score of key kl and row ql = qt0 + 4 h + c (c = the register's row inside the step) survives
+iff unsigned(c - lo) < range with lo = kl - qt0 - 4 h of the first step (the loop subtracts 64 per step) and range = len - kl (0 = lane off);
+alt_q0-3 / alt_do0-3 / alt_stat the lane offsets of the pieces / the statistics row of a PARTIAL last tile (rows clamped to the sequence) ("v");
+safe_q / safe_do / safe_l always-valid addresses that the requests of the steps without a tile left read into the dummy chunk ("s");
+ctl the control word (CTL_* below) ("s");  every other address arrives as the low / high word of a uniform value in VECTOR registers
+(x_lo, x_hi: scalar operands are scarce, and when they run out the compiler silently hands the asm a vector register): q / do the first row
+of the first tile to request, lse / nd its statistics rows, ds the dS pointer of the first step (this wave's strip), nq / ndo / nlse / nnd
+the rows of the workgroup's NEXT item.
 The masked phases cost three more vector instructions per score."""
 import sys
 
@@ -42,6 +44,10 @@ PHASE = "a"
 DO_LDS, LSE_LDS, ND_DELTA, NSLOT = 65536, 131072, 1024, 4
 VM_STEADY = 32                      # vector-memory operations issued behind the requests of tile t+1 when step t waits for it: 3 x 4 stores + 2 x 10 requests
 WAIT_GAP = 64 - LOOKAHEAD - 1
+# ctl, the call's control word: bit 0 first call of the key block, bits 1-2 tiles to request up front, bits 3-5 which of them is the partial
+# last tile (7: none), bits 6-7 tiles of the workgroup's next item to request on the way out, bit 8 the run's last request is the partial
+# last tile, bits 9-10 ring slot of the first step's tile;  s97 takes the field being looked at
+CTL_NPRO, CTL_PROALT, CTL_TAIL = "s_bfe_u32 s97, %[ctl], 0x20001", "s_bfe_u32 s97, %[ctl], 0x30003", "s_bfe_u32 s97, %[ctl], 0x20006"
 DMA_GAPS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]      # the quiet head of the step (no vector work yet): tile t+3 into the slot tile t-1 left at the last barrier
 
 
@@ -168,7 +174,7 @@ def dma_groups():
     pre = ["s_add_u32 %s, %s, 3" % (S_TMP, S_SLOT), "s_and_b32 %s, %s, 3" % (S_TMP, S_TMP), "s_lshl_b32 %s, %s, 14" % (S_DSTQ, S_TMP),
            "s_lshl_b32 %s, %%34, 10" % S_TMP2, "s_add_u32 %s, %s, %s" % (S_DSTQ, S_DSTQ, S_TMP2), "s_lshl_b32 %s, %s, 8" % (S_DSTS, S_TMP),
            "s_add_u32 %s, %s, %d" % (S_DSTS, S_DSTS, LSE_LDS),
-           "s_cmp_eq_u32 %s, 1" % S_DMALEFT, "s_cselect_b32 %s, %%52, 0" % S_USEALT, "s_min_u32 %s, %s, 1" % (S_ISSUED, S_DMALEFT),
+           "s_bfe_u32 s97, %[ctl], 0x10008", "s_cmp_eq_u32 %s, 1" % S_DMALEFT, "s_cselect_b32 %s, s97, 0" % S_USEALT, "s_min_u32 %s, %s, 1" % (S_ISSUED, S_DMALEFT),
            "s_mov_b64 %s, %s" % (sp(QORG), sp(QP)), "s_mov_b64 %s, %s" % (sp(DORG), sp(DP))]
     k = 0
     for which, ptr, org, voff, piece, base, alt0, safe in (("q", QP, QORG, "%27", "%37", 0, 43, "%55"), ("do", DP, DORG, "%28", "%38", DO_LDS, 47, "%56")):
@@ -180,7 +186,7 @@ def dma_groups():
             ool += [".Ldkv3_a%d%s_%%=:" % (k, PHASE), "global_load_lds_dwordx4 %%%d, %s" % (alt0 + i, sp(org)), "s_branch .Ldkv3_j%d%s_%%=" % (k, PHASE)]
             groups.append((pre if k == 0 else []) + g)
             k += 1
-    for ptr, extra, safe in ((LP, 0, "%57"), (NP, ND_DELTA, "%58")):
+    for ptr, extra, safe in ((LP, 0, "%57"), (NP, ND_DELTA, "%57")):
         g = ["s_add_u32 %s, %s, %d" % (S_TMP, S_DSTS, extra), "s_cmp_lg_u32 %s, 0" % S_ISSUED, "s_cselect_b32 m0, %s, %d" % (S_TMP, DUMMY_LDS),
              "s_cselect_b64 %s, %s, %s" % (sp(SRC), sp(ptr), safe), "s_cmp_lg_u32 %s, 0" % S_USEALT, "s_cbranch_scc1 .Ldkv3_a%d%s_%%=" % (k, PHASE),
              "global_load_lds_dword v%d, %s" % (LANE4, sp(SRC)), ".Ldkv3_j%d%s_%%=:" % (k, PHASE),
@@ -336,25 +342,26 @@ def main():
     pro = ["s_waitcnt lgkmcnt(0)", "s_mov_b32 %s, m0" % S_M0SAVE,
            "v_mbcnt_lo_u32_b32 v%d, -1, 0" % LANE, "v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (LANE, LANE),
            "v_lshlrev_b32_e32 v%d, 4, v%d" % (DSOFF, LANE), "v_lshlrev_b32_e32 v%d, 2, v%d" % (LANE4, LANE),
-           "s_mov_b32 %s, %%33" % S_SLOT, "s_mov_b32 %s, %%32" % S_DMALEFT,
-           "s_mov_b64 %s, %%35" % sp(QP), "s_mov_b64 %s, %%36" % sp(DP), "s_mov_b64 %s, %%39" % sp(LP), "s_mov_b64 %s, %%40" % sp(NP), "s_mov_b64 %s, %%29" % sp(DSP),
+           "s_bfe_u32 %s, %%[ctl], 0x20009" % S_SLOT, "s_mov_b32 %s, %%32" % S_DMALEFT] + \
+          ["v_readfirstlane_b32 s%d, %%[%s_%s]" % (ptr[w], nm, "lo" if w == 0 else "hi") for ptr, nm in ((QP, "q"), (DP, "do"), (LP, "lse"), (NP, "nd"), (DSP, "ds")) for w in (0, 1)] + [
+
            "s_lshl_b32 %s, %s, 14" % (S_TOFF, S_SLOT), "v_mov_b32_e32 v%d, %%41" % V_LO, "v_mov_b32_e32 v%d, 0xff800000" % V_NINF]
     global PHASE
     PHASE = "p"
-    # ---- first call of a key block (%59 != 0): zero the accumulators and request the block's first %60 (<= 3) tiles + statistics rows here,
-    #      with the loop's own cheap form of a request (the caller has passed the barrier behind the previous block's last reads); tile %61
+    # ---- first call of a key block (control bit 0): zero the accumulators and request the block's first (<= 3) tiles + statistics rows here,
+    #      with the loop's own cheap form of a request (the caller has passed the barrier behind the previous block's last reads); tile CTL_PROALT
     #      of them (7 = none) is the sequence's partial last tile and takes the clamped lane offsets.  Then everything has to land.
-    pro += ["s_cmp_eq_u32 %59, 0", "s_cbranch_scc1 .Ldkv3_nofirst_%="]
+    pro += ["s_bitcmp0_b32 %[ctl], 0", "s_cbranch_scc1 .Ldkv3_nofirst_%="]
     # (an accumulator tuple operand cannot be sliced into single registers from here: it is zeroed by an MFMA of zero fragments, D = 0 * 0 + 0)
     pro += ["v_mov_b32_e32 v%d, 0" % (RING + j) for j in range(4)] + ["s_nop 4"]
     for opnd in range(8):
         pro += ["ZERO_TUPLE %%%d" % opnd]
     for i in range(3):
-        pro += ["s_cmp_le_u32 %%60, %d" % i, "s_cbranch_scc1 .Ldkv3_prodone_%="]
+        pro += [CTL_NPRO, "s_cmp_le_u32 s97, %d" % i, "s_cbranch_scc1 .Ldkv3_prodone_%="]
         pro += ["s_add_u32 %s, %s, %d" % (S_TMP, S_SLOT, i), "s_and_b32 %s, %s, 3" % (S_TMP, S_TMP), "s_lshl_b32 %s, %s, 14" % (S_DSTQ, S_TMP),
                 "s_lshl_b32 %s, %%34, 10" % S_TMP2, "s_add_u32 %s, %s, %s" % (S_DSTQ, S_DSTQ, S_TMP2), "s_lshl_b32 %s, %s, 8" % (S_DSTS, S_TMP),
                 "s_add_u32 %s, %s, %d" % (S_DSTS, S_DSTS, LSE_LDS), "s_mov_b64 %s, %s" % (sp(QORG), sp(QP)), "s_mov_b64 %s, %s" % (sp(DORG), sp(DP)),
-                "s_cmp_eq_u32 %%61, %d" % i, "s_cselect_b32 %s, 1, 0" % S_USEALT]
+                CTL_PROALT, "s_cmp_eq_u32 s97, %d" % i, "s_cselect_b32 %s, 1, 0" % S_USEALT]
         for which, ptr, org, voff, piece, base, alt0 in (("q", QP, QORG, "%27", "%37", 0, 43), ("do", DP, DORG, "%28", "%38", DO_LDS, 47)):
             for k in range(4):
                 pro += ["s_add_u32 m0, %s, %d" % (S_DSTQ, base + 4096 * k), "s_cmp_lg_u32 %s, 0" % S_USEALT, "s_cbranch_scc1 .Ldkv3_pa%d%s%d_%%=" % (i, which, k),
@@ -371,11 +378,39 @@ def main():
     for n in range(LOOKAHEAD):
         pro += [l.text for l in a_loads(M[n]["a"], n % 8)]
     lines = list(pro)
-    for phase, body, count in (("a", body_a, "%31"), ("b", body_b, "%53"), ("c", body_c, "%54")):
-        lines += ["s_mov_b32 %s, %s" % (S_CNT, count), "s_cmp_eq_u32 %s, 0" % S_CNT, "s_cbranch_scc1 .Ldkv3_skip%s_%%=" % phase, ".Ldkv3_loop%s_%%=:" % phase]
+    for phase, body, count in (("a", body_a, "s_and_b32 %s, %%[n02], 0xffff" % S_CNT), ("b", body_b, "s_mov_b32 %s, %%[n1]" % S_CNT), ("c", body_c, "s_lshr_b32 %s, %%[n02], 16" % S_CNT)):
+        lines += [count, "s_cmp_eq_u32 %s, 0" % S_CNT, "s_cbranch_scc1 .Ldkv3_skip%s_%%=" % phase, ".Ldkv3_loop%s_%%=:" % phase]
         lines += body
         lines += ["s_sub_u32 %s, %s, 1" % (S_CNT, S_CNT), "s_cmp_lg_u32 %s, 0" % S_CNT, "s_cbranch_scc1 .Ldkv3_loop%s_%%=" % phase, ".Ldkv3_skip%s_%%=:" % phase]
+    # ---- tail (%62 != 0: the key block is done and the workgroup's NEXT item is known): behind a barrier - every wave has read its last
+    #      tile - request the next item's first (<= 3) tiles + statistics rows into slots 0..2 (%59.. its Q / dO rows, its
+    #      lse2 / -delta rows; whole tiles only, the caller does not ask otherwise), and leave without waiting: they land while the caller
+    #      stores this block's dK / dV and fetches the next K / V fragments; the next call (first call, nothing to request) waits for them.
+    tail = [CTL_TAIL, "s_cmp_eq_u32 s97, 0", "s_cbranch_scc1 .Ldkv3_notail_%=", "s_waitcnt lgkmcnt(0)", "s_barrier",
+            "s_lshl_b32 %s, %%34, 10" % S_TMP2]
+    for k, ptr in enumerate((QP, DP, LP, NP)):      # (scalar operands are scarce - the compiler silently hands out a vector register when they run out - so these come in vector registers)
+        tail += ["v_readfirstlane_b32 s%d, %%[n%s_lo]" % (ptr[0], ("q", "do", "lse", "nd")[k]), "v_readfirstlane_b32 s%d, %%[n%s_hi]" % (ptr[1], ("q", "do", "lse", "nd")[k])]
+    for i in range(3):
+        tail += ["s_cmp_le_u32 s97, %d" % i, "s_cbranch_scc1 .Ldkv3_notail_%="]
+        for ptr, voff, piece, base in ((QP, "%27", "%37", 0), (DP, "%28", "%38", DO_LDS)):
+            for k in range(4):
+                tail += ["s_add_u32 m0, %s, %d" % (S_TMP2, (i << 14) + base + 4096 * k), "s_nop 0", "global_load_lds_dwordx4 %s, %s" % (voff, sp(ptr)),
+                         "s_add_u32 s%d, s%d, %s" % (ptr[0], ptr[0], piece), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])]
+        for ptr, extra in ((LP, 0), (NP, ND_DELTA)):
+            tail += ["s_mov_b32 m0, %d" % (LSE_LDS + (i << 8) + extra), "s_nop 0", "global_load_lds_dword v%d, %s" % (LANE4, sp(ptr)),
+                     "s_add_u32 s%d, s%d, 256" % (ptr[0], ptr[0]), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])]
+    tail += [".Ldkv3_notail_%=:"]
+    lines += tail
     lines += ["s_branch .Ldkv3_end_%="] + ool_a + ool_b + ool_c + [".Ldkv3_end_%=:", "s_waitcnt lgkmcnt(0)", "s_mov_b32 m0, %s" % S_M0SAVE]
+    names = {24: "rowrel", 25: "colrel", 26: "statrel", 27: "voff_q", 28: "voff_do", 30: "sc", 32: "ndma", 34: "wave", 37: "q_piece", 38: "do_piece", 41: "lo0", 42: "range",
+             51: "alt_stat", 55: "safe_q", 56: "safe_do", 57: "safe_l"}
+    names.update({i: "accV%d" % i for i in range(4)}); names.update({4 + i: "accK%d" % i for i in range(4)})
+    names.update({8 + i: "kq%d" % i for i in range(8)}); names.update({16 + i: "vq%d" % i for i in range(8)})
+    names.update({43 + i: "alt_q%d" % i for i in range(4)}); names.update({47 + i: "alt_do%d" % i for i in range(4)})
+    import re
+    def named(l):      # the asm statement's operands are NAMED (sdpa_dkv3.h): the numbers above are this script's shorthand
+        return re.sub(r"%(\d+)", lambda m: "%%[%s]" % names[int(m.group(1))], l)
+    lines = [named(l) for l in lines]
     expanded = []
     for l in lines:
         if l.startswith("ZERO_TUPLE"):      # D = 0 * 0 + 0: the operand tuple cannot be sliced into single registers from here

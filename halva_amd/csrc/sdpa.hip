@@ -50,11 +50,14 @@ extern "C" unsigned long long* halva_dbg_buffer() {
 }
 // whole-workgroup clock stamp: cycles (s_memtime) and 100 MHz ticks (s_memrealtime) of every 8th workgroup -> in-kernel clock of THIS kernel
 // (MI355X_MICROARCH.md, DVFS give-back item 6); slot k of the debug buffer's upper half: {cycles, ticks, start tick, block}
+#ifndef HALVA_STAMP_STRIDE
+#define HALVA_STAMP_STRIDE 8      // 8: the first 120 workgroups of XCD 0;  17: every XCD and every round of a 2048-workgroup launch
+#endif
 #define WG_CLOCK_BEGIN() const unsigned long long wgc0_ = __builtin_amdgcn_s_memtime(), wgr0_ = __builtin_amdgcn_s_memrealtime()
 #define WG_CLOCK_END(dbg, region)                                                                                     \
     do {                                                                                                              \
-        if ((dbg) && threadIdx.x == 0 && blockIdx.x % 8 == 0 && blockIdx.x / 8 < 120) {                               \
-            unsigned long long* o_ = (dbg) + 4096 + (region)*480 + (blockIdx.x / 8) * 4;                              \
+        if ((dbg) && threadIdx.x == 0 && blockIdx.x % HALVA_STAMP_STRIDE == 0 && blockIdx.x / HALVA_STAMP_STRIDE < 120) { \
+            unsigned long long* o_ = (dbg) + 4096 + (region)*480 + (blockIdx.x / HALVA_STAMP_STRIDE) * 4;             \
             o_[0] = __builtin_amdgcn_s_memtime() - wgc0_;                                                             \
             o_[1] = __builtin_amdgcn_s_memrealtime() - wgr0_;                                                         \
             o_[2] = wgr0_;                                                                                            \
@@ -80,6 +83,8 @@ struct SdpaParams {
     float* lse;           // [S, H, T]
     float* delta;         // [S, H, T]
     float* lse2;          // [S, H, T] lse * log2(e), written by the delta pass for sdpa_bwd_dkv3 (tail of the dS workspace), or nullptr
+    int sched_order;      // order of the items inside a queue (sdpa_dkv3.h)
+    int* sched;           // sdpa_bwd_dkv3's eight work-queue counters, 128 B apart (behind lse2 in the workspace), zeroed by the delta pass
     const int32_t* seq_start;
     const int32_t* seq_len;
     const int32_t* br_a;  // optional per-sequence branch points (local indices; br_b a multiple of 64), include/halva_hip.h:
@@ -1376,6 +1381,7 @@ __global__ __launch_bounds__(256) void sdpa_bwd_delta_kernel(const SdpaParams p,
     constexpr int HPW = 512 / D;                       // heads per wave pass: 64 lanes x 8 elements
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (for_dkv3 && blockIdx.x == 0 && threadIdx.x < 8) p.sched[32 * threadIdx.x] = 0;
     if (row >= (int64_t)S * p.T) return;
     const int s = (int)(row / p.T), t = (int)(row % p.T);
     const int start = p.seq_start ? p.seq_start[s] : 0;
@@ -1624,8 +1630,11 @@ template <bool CAUSAL>
 int launch_dkv3(SdpaParams p, int S, hipStream_t st) {
     p.nblk = (p.T + 127) / 128;
     p.npairs = S * p.H;
-    const int wg_per_pair = CAUSAL ? (p.nblk + 1) / 2 : p.nblk;
     const bool use_asm = env_flag_on("HALVA_DKV3_ASM");
+    {
+        const char* e = getenv("HALVA_DKV3_ORDER");
+        p.sched_order = e ? atoi(e) : (CAUSAL ? 2 : 0);
+    }
     static std::atomic<int> attr_set[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1639,7 +1648,15 @@ int launch_dkv3(SdpaParams p, int S, hipStream_t st) {
         }
         if (dev >= 0 && dev < 64) attr_set[dev].store(1, std::memory_order_release);
     }
-    const dim3 grid((unsigned)(wg_per_pair * p.npairs));
+    // one persistent workgroup per CU (it takes the CU's whole register file and 131 KiB of its LDS), fewer when there is less to do
+    static std::atomic<int> n_cu[64];
+    int cus = (dev >= 0 && dev < 64) ? n_cu[dev].load(std::memory_order_acquire) : 0;
+    if (cus == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        if (dev >= 0 && dev < 64) n_cu[dev].store(cus, std::memory_order_release);
+    }
+    const int64_t items = (int64_t)p.nblk * p.npairs;
+    const dim3 grid((unsigned)std::min<int64_t>(items, cus));
     if (use_asm) hipLaunchKernelGGL((sdpa_bwd_dkv3_kernel<128, CAUSAL, true>), grid, dim3(256), DKV3_LDS, st, p);
     else hipLaunchKernelGGL((sdpa_bwd_dkv3_kernel<128, CAUSAL, false>), grid, dim3(256), DKV3_LDS, st, p);
     HALVA_CHECK_LAUNCH("sdpa_bwd_dkv3");
@@ -1657,7 +1674,7 @@ int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st) {
     const bool slow = slow_tr_requested();
     if (p.ds_ws != nullptr && D == 128) {      // dS formed once: delta (+ zero-fill of padded dq rows) -> dK/dV (+ dS store) -> dQ = dS K
         const int64_t rows = (int64_t)S * p.T;
-        const bool dkv3 = !slow && p.lse2 != nullptr && rows >= 16 && env_flag_on("HALVA_SDPA_DKV3");
+        const bool dkv3 = !slow && p.lse2 != nullptr && rows >= 16 && p.T < (1 << 22) && env_flag_on("HALVA_SDPA_DKV3");      // (its step counts travel as 16-bit fields)
         hipLaunchKernelGGL((sdpa_bwd_delta_kernel<D>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, S, dkv3 ? 1 : 0);
         HALVA_CHECK_LAUNCH("sdpa_bwd_delta");      // (a failed launch would leave stale delta / unzeroed padded dq rows for the two kernels below)
         int rc2;
@@ -1731,11 +1748,13 @@ extern "C" int halva_sdpa_causal_bwd_ld(const void* qkv, const void* out, int64_
                                  scale, stream);
 }
 
+static int64_t lse2_region_bytes(int S, int T, int H) { return (((int64_t)S * H * T * 4 + 256) + 127) / 128 * 128; }
 static int64_t ds_region_bytes(int S, int T, int H) { return (int64_t)S * H * ((T + 127) / 128) * ((T + 63) / 64) * 16384; }
 
 extern "C" int64_t halva_sdpa_bwd_ws_bytes(int S, int T, int H, int D) {
     if (D != 128) return 0;                                      // the dS path is the head_dim-128 instantiation; others use the 3-product dQ kernel
-    return ds_region_bytes(S, T, H) + (int64_t)S * H * T * 4 + 256;     // dS, then [S, H, T] f32 lse * log2(e) for sdpa_bwd_dkv3 (+ one padding row)
+    // dS, then [S, H, T] f32 lse * log2(e) for sdpa_bwd_dkv3 (+ one padding row), then its work-queue counters
+    return ds_region_bytes(S, T, H) + lse2_region_bytes(S, T, H) + 1024;
 }
 
 extern "C" int halva_sdpa_branch_bwd(const void* qkv, const void* out, int64_t ld_out, const void* dout, int64_t ld_dout,
@@ -1782,6 +1801,7 @@ extern "C" int halva_sdpa_branch_bwd_ws(const void* qkv, const void* out, int64_
     p.H = H;
     p.ds_ws = D == 128 ? (char*)ds_ws : nullptr;
     p.lse2 = p.ds_ws ? reinterpret_cast<float*>(p.ds_ws + ds_region_bytes(S, T, H)) : nullptr;
+    p.sched = p.ds_ws ? reinterpret_cast<int*>(p.ds_ws + ds_region_bytes(S, T, H) + lse2_region_bytes(S, T, H)) : nullptr;
     p.ds_nkb = (T + 127) / 128;
     p.ds_nt = (T + 63) / 64;
     p.scale = scale > 0.f ? scale : 1.f / sqrtf((float)D);

@@ -22,7 +22,8 @@ constexpr int DKV3_DO = 4 * DKV3_TILE;                       // dO ring behind t
 constexpr int DKV3_LSE = 8 * DKV3_TILE;                      // [4][64] lse2, then [4][64] -delta
 constexpr int DKV3_ND = DKV3_LSE + 4 * 64 * 4;
 constexpr int DKV3_DUMMY = DKV3_ND + 4 * 64 * 4;              // 1 KiB: where the requests of the last steps of a block (no tile left) land
-constexpr int DKV3_LDS = DKV3_DUMMY + 1024;
+constexpr int DKV3_SCHED = DKV3_DUMMY + 1024;                // [2][8] ints: the persistent workgroup's item mail box
+constexpr int DKV3_LDS = DKV3_SCHED + 64;
 
 #define DKV3_PIN_A(x) asm volatile("" : "+a"(x))
 
@@ -96,8 +97,9 @@ __device__ __forceinline__ unsigned dkv3_piece_voff(int64_t ld, int wave, int la
     return (unsigned)((min(row, nrows - 1) * ld + ch * 8) * 2);
 }
 
-template <bool CAUSAL, bool ASM>
-__device__ __forceinline__ void sdpa_bwd_dkv3_block(const SdpaParams& p, char* smem, int s, int hd, int kb, int wave, int lane, int start, int len,
+// One key block in plain HIP (HALVA_DKV3_ASM=0: the readable twin of the generated loop, with the same ring protocol; every item starts cold)
+template <bool CAUSAL>
+__device__ __forceinline__ void sdpa_bwd_dkv3_block_hip(const SdpaParams& p, char* smem, int s, int hd, int kb, int wave, int lane, int start, int len,
                                                     const Branch br) {
     constexpr int D = 128, KS = 8, DT = 4, BQ = 64;
     const int h = lane >> 5;
@@ -133,16 +135,10 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_block(const SdpaParams& p, char* s
             st.vq[ks] = k_valid ? *reinterpret_cast<const u32x4*>(vrow + 16 * ks + 8 * h) : u32x4{0u, 0u, 0u, 0u};
         }
     }
-    if (ASM) {      // the generated block zeroes them itself on its first call (no copies into its operand registers)
-        // (fixed accumulator registers, the same in every asm statement that touches them: no copies between the compiler's choice and the block's)
-        asm volatile("" : "={a[0:15]}"(st.accV[0]), "={a[16:31]}"(st.accV[1]), "={a[32:47]}"(st.accV[2]), "={a[48:63]}"(st.accV[3]), "={a[64:79]}"(st.accK[0]), "={a[80:95]}"(st.accK[1]), "={a[96:111]}"(st.accK[2]),
-                     "={a[112:127]}"(st.accK[3]));
-    } else {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st.accV[dt][r] = 0.f, st.accK[dt][r] = 0.f;
-    }
+        for (int r = 0; r < 16; ++r) st.accV[dt][r] = 0.f, st.accK[dt][r] = 0.f;
     const bf16_t* qp = p.q + hd * D;
     const bf16_t* dop = p.d_o + hd * D;
     const int64_t qrow0 = seq_row0 + start;
@@ -169,37 +165,9 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_block(const SdpaParams& p, char* s
         lse_lds[(i & 3) * 64 + lane] = a;
         nd_lds[(i & 3) * 64 + lane] = b;
     };
-#ifdef HALVA_STAMP
-#define DKV3_NOW(x) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory")
-    unsigned long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // 0 entry, 1 loop start, 2 asm cycles, 3 plain steps, 5 masked steps,
-    DKV3_NOW(stamp[0]);                                                       // 6 before stores, 7 done, 8 first barrier passed, 9 requests issued, 10 tiles landed
-#endif
-    // a step the UNMASKED phase may run: whole tile, every key of the block visible to every row, no padded key, no branch edge
-    // (the HIP build classifies per wave inside its step; the ASM build derives the three run lengths from the same conditions below)
-    // lane parts of the LDS / global addresses of the generated loop
-    const unsigned rowrel = 2048 * ((lane & 31) >> 3) + 64 * (lane & 7) + 16 * (h ^ (((lane & 31) >> 2) & 3));
-    const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3, h2 = g16 >> 1;
-    const unsigned colrel = 64 * (4 * h2 + q4) + 16 * ((2 * (g16 & 1) + (pp >> 1)) ^ h2) + 8 * (pp & 1);
-    const unsigned statrel = 16 * h;
-    const unsigned voff_q = dkv3_piece_voff(p.ld_qkv, wave, lane, 0, 64), voff_do = dkv3_piece_voff(p.ld_do, wave, lane, 0, 64);
-    // a partial last tile: its rows are clamped to the sequence, piece by piece
-    const int last_rows = len - (q_begin + (ntiles - 1) * BQ);              // >= 64: whole (or the block's rows stop at br.b); 1..63: the sequence ends inside the tile
-    const bool last_partial = last_rows < BQ;
-    const int lr = last_partial ? last_rows : BQ;
-    unsigned alt_q[4], alt_do[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        alt_q[i] = dkv3_piece_voff(p.ld_qkv, wave, lane, i, lr);
-        alt_do[i] = dkv3_piece_voff(p.ld_do, wave, lane, i, lr);
-    }
-    const unsigned alt_stat = 4 * min(lane, lr - 1);
-
     // ---- prologue: the previous block's readers are done; request tiles 0..2, prepare everything else, then wait
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#ifdef HALVA_STAMP
-    DKV3_NOW(stamp[8]);
-#endif
-    if (!ASM) {
+    {
         float sa[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};      // every request first, ONE wait: a statistic stored right behind its load
 #pragma unroll                                                      // would wait for the tile requests in front of it as well (vmcnt is in order)
         for (int i = 0; i < 3; ++i)
@@ -211,86 +179,12 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_block(const SdpaParams& p, char* s
         for (int i = 0; i < 3; ++i)
             if (i < ntiles && wave == 0) store_stats(i, sa[i], sb[i]);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    } else {      // (the generated block requests tiles 0..2 itself on its first call, and waits for them)
-        asm volatile("" : "+{a[128:131]}"(st.kq[0]), "+{a[132:135]}"(st.kq[1]), "+{a[136:139]}"(st.kq[2]), "+{a[140:143]}"(st.kq[3]), "+{a[144:147]}"(st.kq[4]), "+{a[148:151]}"(st.kq[5]), "+{a[152:155]}"(st.kq[6]), "+{a[156:159]}"(st.kq[7]),
-                     "+{a[160:163]}"(st.vq[0]), "+{a[164:167]}"(st.vq[1]), "+{a[168:171]}"(st.vq[2]), "+{a[172:175]}"(st.vq[3]), "+{a[176:179]}"(st.vq[4]), "+{a[180:183]}"(st.vq[5]), "+{a[184:187]}"(st.vq[6]), "+{a[188:191]}"(st.vq[7]));
     }
-#ifdef HALVA_STAMP
-    DKV3_NOW(stamp[9]);
-    DKV3_NOW(stamp[10]);
-    DKV3_NOW(stamp[1]);
-#endif
     int t = 0;
 #pragma unroll 1
     while (t < ntiles) {
         const int qt0 = q_begin + t * BQ;
         const bool q_in_b = qt0 >= br.b;                     // br.b and qt0 are multiples of 64: uniform over the step
-        if (ASM) {
-            // ONE asm block for the steps up to the branch point (or the end): masked steps (the diagonal), interior steps, masked steps (the
-            // tail); a layout with more alternations than that takes another round of this loop
-            const int t_side = q_in_b ? ntiles : min(ntiles, (int)(((int64_t)br.b - q_begin + BQ - 1) / BQ));      // first step at or behind br.b
-            int t1 = t, n0 = 0, n1 = 0, n2 = 0;
-#ifdef HALVA_DKV3_ALL_MASKED      // diagnostic: every step through the masked phase (same results: an interior step's masks pass everything)
-            n0 = t_side - t, t1 = t_side;
-#else
-            {      // interior(t') on this side of br.b = side_ok && t_diag <= t' < t_full: three runs, no scan
-                const bool side_ok = block_all_keys_valid && !(q_in_b && kblk_min < br.b && kblk_min + 127 >= br.a);
-                const int t_diag = CAUSAL ? max(0, (kblk_min + 127 - q_begin + BQ - 1) / BQ) : 0;      // first t' with qt0 >= kblk_min + 127
-                const int t_full = max(0, (len - q_begin) / BQ);                                          // first t' with qt0 + 64 > len
-                const int lo = min(t_side, max(t, t_diag)), hi = min(t_side, max(lo, t_full));
-                n0 = side_ok ? lo - t : t_side - t;
-                n1 = side_ok ? hi - lo : 0;
-                n2 = t_side - t - n0 - n1;
-                t1 = t_side;
-            }
-#endif
-            const int n = t1 - t;
-            const int ndma = min(n, max(0, ntiles - 3 - t));      // steps t' of the call with a tile t'+3 to request
-            const bool part = last_partial && ndma > 0 && (t + ndma - 1 + 3 == ntiles - 1);
-            const bool lane_off = !k_valid || (q_in_b && key_hidden);
-            const unsigned lo0 = (unsigned)(kl - qt0 - 4 * h), range = lane_off ? 0u : (unsigned)(len - kl);
-            const unsigned long long ds_ptr = dkv3_uni64(ds_block + (int64_t)t * 16384);
-            // the next tile to request: tile t+3 - or tile 0 on the block's first call, which requests tiles 0..2 up front
-            const int tq = t == 0 ? 0 : t + 3;
-            const unsigned long long q_ptr = dkv3_uni64(qp + (qrow0 + q_begin + (int64_t)tq * BQ) * p.ld_qkv);
-            const unsigned long long do_ptr = dkv3_uni64(dop + (qrow0 + q_begin + (int64_t)tq * BQ) * p.ld_do);
-            const unsigned long long lse_ptr = dkv3_uni64(lse2_g + q_begin + tq * BQ);
-            const unsigned long long nd_ptr = dkv3_uni64(nd_g + q_begin + tq * BQ);
-            const unsigned first_u = dkv3_uni(t == 0 ? 1u : 0u), npro_u = dkv3_uni((unsigned)min(3, ntiles));
-            const unsigned proalt_u = dkv3_uni((last_partial && ntiles <= 3) ? (unsigned)(ntiles - 1) : 7u);
-            const unsigned q_piece = dkv3_uni((unsigned)(16 * p.ld_qkv * 2)), do_piece = dkv3_uni((unsigned)(16 * p.ld_do * 2));
-            const unsigned n0_u = dkv3_uni((unsigned)n0), n1_u = dkv3_uni((unsigned)n1), n2_u = dkv3_uni((unsigned)n2);
-            const unsigned ndma_u = dkv3_uni((unsigned)ndma), slot_u = dkv3_uni((unsigned)(t & 3)), wave_u = dkv3_uni((unsigned)wave);
-            const unsigned part_u = dkv3_uni(part ? 1u : 0u);
-            // always-valid sources for the requests of the steps with no tile left (they land in the dummy chunk): the tensors' first 16 rows
-            // (the launcher requires S * T >= 16) and this pair's first statistics row (the lse2 region is padded by a row)
-            const unsigned long long safe_q = dkv3_uni64(qp), safe_do = dkv3_uni64(dop);
-            const unsigned long long safe_l = dkv3_uni64(p.lse2 + ((int64_t)s * p.H + hd) * p.T), safe_n = safe_l;
-#ifdef HALVA_STAMP
-            unsigned long long run0, run1;
-            DKV3_NOW(run0);
-#endif
-            asm volatile(
-#include "sdpa_dkv3_loop.inc"
-                : "+{a[0:15]}"(st.accV[0]), "+{a[16:31]}"(st.accV[1]), "+{a[32:47]}"(st.accV[2]), "+{a[48:63]}"(st.accV[3]), "+{a[64:79]}"(st.accK[0]), "+{a[80:95]}"(st.accK[1]), "+{a[96:111]}"(st.accK[2]), "+{a[112:127]}"(st.accK[3])
-                : "{a[128:131]}"(st.kq[0]), "{a[132:135]}"(st.kq[1]), "{a[136:139]}"(st.kq[2]), "{a[140:143]}"(st.kq[3]), "{a[144:147]}"(st.kq[4]), "{a[148:151]}"(st.kq[5]), "{a[152:155]}"(st.kq[6]), "{a[156:159]}"(st.kq[7]),
-                  "{a[160:163]}"(st.vq[0]), "{a[164:167]}"(st.vq[1]), "{a[168:171]}"(st.vq[2]), "{a[172:175]}"(st.vq[3]), "{a[176:179]}"(st.vq[4]), "{a[180:183]}"(st.vq[5]), "{a[184:187]}"(st.vq[6]), "{a[188:191]}"(st.vq[7]), "v"(rowrel), "v"(colrel),
-                  "v"(statrel), "v"(voff_q), "v"(voff_do), "s"(ds_ptr), "s"(sc), "s"(n0_u), "s"(ndma_u), "s"(slot_u), "s"(wave_u), "s"(q_ptr), "s"(do_ptr),
-                  "s"(q_piece), "s"(do_piece), "s"(lse_ptr), "s"(nd_ptr), "v"(lo0), "v"(range), "v"(alt_q[0]), "v"(alt_q[1]), "v"(alt_q[2]), "v"(alt_q[3]),
-                  "v"(alt_do[0]), "v"(alt_do[1]), "v"(alt_do[2]), "v"(alt_do[3]), "v"(alt_stat), "s"(part_u), "s"(n1_u), "s"(n2_u), "s"(safe_q), "s"(safe_do),
-                  "s"(safe_l), "s"(safe_n), "s"(first_u), "s"(npro_u), "s"(proalt_u)
-                :
-#include "sdpa_dkv3_loop_clobbers.inc"
-            );
-#ifdef HALVA_STAMP
-            DKV3_NOW(run1);
-            stamp[2] += run1 - run0;
-            stamp[3] += n1;
-            stamp[5] += n0 + n2;
-#endif
-            t = t1;
-            continue;
-        }
         // ---- plain HIP step (debug build of the kernel, ASM = false): request tile t+3, compute with the masks, end with "tile t+1 has landed"
         float sa = 0.f, sb = 0.f;
         if (t + 3 < ntiles) {      // (behind step t-1's barrier the slot of tile t-1 is free: tile t+3; tiles 0..2 came with the prologue)
@@ -309,36 +203,297 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_block(const SdpaParams& p, char* s
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         ++t;
     }
-#ifdef HALVA_STAMP
-    DKV3_NOW(stamp[6]);
-#endif
     if (k_in_T) {
         store_rows_T<D>(dv_row, st.accV, k_valid ? 1.f : 0.f, true, lane);
         store_rows_T<D>(dk_row, st.accK, k_valid ? p.scale : 0.f, true, lane);
     }
+}
+
+// What an item (sequence, head, key block) looks like to every wave of the workgroup: all of it wave-uniform.
+struct Dkv3Geom {
+    int valid;                          // 0: the queues are empty
+    int s, hd, kb, start, len;
+    Branch br;
+    int kblk_min, q_begin, ntiles;      // first key of the block in sequence coordinates; first query row that sees it; its 64-row steps
+    int last_partial, lr;               // the last step's tile stops inside the sequence: lr of its 64 rows exist
+    template <bool CAUSAL>
+    __device__ __forceinline__ void set(const SdpaParams& p, int item, int start_, int len_, int a, int b) {
+        constexpr int BQ = 64;
+        valid = item >= 0;
+        const int it = max(item, 0), g = it / p.nblk;
+        kb = it - g * p.nblk, s = g / p.H, hd = g - s * p.H;
+        start = start_, len = len_, br.a = a, br.b = b;
+        kblk_min = kb * 128 - start;
+        q_begin = CAUSAL ? max(0, kblk_min) / BQ * BQ : 0;
+        const bool block_has_keys = (kblk_min < len) && (kblk_min + 128 > 0);
+        const int q_stop = (kblk_min >= br.a && kblk_min + 127 < br.b) ? min(len, br.b) : len;
+        ntiles = (valid && block_has_keys && q_stop > q_begin) ? (q_stop - q_begin + BQ - 1) / BQ : 0;
+        const int last_rows = len - (q_begin + (ntiles - 1) * BQ);      // >= 64: whole (or the block's rows stop at br.b)
+        last_partial = last_rows < BQ;
+        lr = last_partial ? last_rows : BQ;
+        // the divisions above run on the vector unit; without this everything derived from them stays in vector registers and the loops over
+        // the block's steps are compiled as divergent ones (accumulators copied out of and into their registers around the asm block)
+        kb = (int)dkv3_uni((unsigned)kb), s = (int)dkv3_uni((unsigned)s), hd = (int)dkv3_uni((unsigned)hd), kblk_min = (int)dkv3_uni((unsigned)kblk_min);
+        q_begin = (int)dkv3_uni((unsigned)q_begin), ntiles = (int)dkv3_uni((unsigned)ntiles), last_partial = (int)dkv3_uni((unsigned)last_partial), lr = (int)dkv3_uni((unsigned)lr);
+    }
+    // the block's first three tiles are whole ones: the previous item's asm block may request them on its way out
+    __device__ __forceinline__ int prefetchable() const { return (ntiles > 0 && !(last_partial && ntiles <= 3)) ? min(3, ntiles) : 0; }
+};
+
+// The item loop of the generated-asm build.  Per item: [the asm block: every step of the key block; on its way out it requests the NEXT
+// item's first tiles] -> the next item's K / V fragments are asked for -> this item's dK / dV rows are converted and stored while those
+// loads and requests fly -> the fragments move into their accumulator registers -> next item.  (Before this pipelining an item paid
+// ~16 000 cycles around its steps - K / V fragments 2 200, the first tiles 4 000, address arithmetic 2 500, the stores and their
+// acknowledgements 4 700, the scheduler 2 500 - with nothing else resident on the CU to fill them: a fifth of the kernel.)
+template <bool CAUSAL>
+__device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* smem, int wave, int lane_in) {
+    constexpr int D = 128, KS = 8, BQ = 64;
+    // ---- the scheduler: thread 0 draws items one round ahead and leaves them, with their sequence's geometry, in a two-slot mail box
+    // (an LDS-typed pointer: through a generic one the accesses are FLAT instructions, which wait on the vector-memory counter as well - i.e.
+    // for the acknowledgements of the rows just stored and the next item's tiles, all of which this loop is arranged not to wait for)
+    typedef __attribute__((address_space(3))) volatile int LdsInt;
+    LdsInt* mail = (LdsInt*)(__attribute__((address_space(3))) char*)(smem + DKV3_SCHED);      // [2][8]: item, start, len, br.a, br.b
+    const int home = blockIdx.x & 7, order = p.sched_order;
+    int nkb = p.nblk, G = p.npairs;      // (not const: laundered once per round, see below)
+    auto queue_len = [&](int x) { return x < G ? ((G - x + 7) >> 3) * nkb : 0; };
+    auto item_of = [&](int x, int j) {
+        const int ng = (G - x + 7) >> 3;
+        int gi, kb;
+        if (order == 1) {      // key-block major over the whole queue (measured: loses the L2's reuse of Q / dO, +30 % per step)
+            kb = j / ng, gi = j - kb * ng;
+        } else if (order == 2) {      // the long half of every pair, pair by pair; then the short halves key-block major: what is left for the end is short
+            const int hl = (nkb + 1) >> 1, nl = ng * hl;
+            if (j < nl) gi = j / hl, kb = j - gi * hl;
+            else kb = hl + (j - nl) / ng, gi = (j - nl) % ng;
+        } else {
+            gi = j / nkb, kb = j - gi * nkb;
+        }
+        return (x + 8 * gi) * nkb + kb;
+    };
+    auto resolve = [&](int j) {      // j: what the home queue's counter returned
+        if (j < queue_len(home)) return item_of(home, j);
+        for (int k = 1; k < 8; ++k) {      // the home queue is empty: the others, nearest first
+            const int x = (home + k) & 7, n = queue_len(x);
+            if (n == 0) continue;
+            const int jj = atomicAdd(p.sched + 32 * x, 1);
+            if (jj < n) return item_of(x, jj);
+        }
+        return -1;
+    };
+    struct Posting {
+        int item, start, len, a, b;
+    };
+    // the item's sequence, by SCALAR loads: they return through lgkmcnt; as vector loads the compiler would wait for them with vmcnt(0) (it
+    // knows nothing of what the asm blocks have in flight), i.e. for everything
+    auto look_up = [&](int item) {      // thread 0 only
+        const int sq = (int)dkv3_uni((unsigned)(max(item, 0) / nkb / p.H));
+        Posting w{item, 0, p.T, 0x7fffffff, 0x7fffffff};
+        if (p.seq_start && p.seq_len && p.br_a && p.br_b) {      // (the packed launch of the training step: four loads, one wait)
+            asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\ts_load_dword %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(w.start), "=&s"(w.len), "=&s"(w.a), "=&s"(w.b)
+                         : "s"(dkv3_uni64(p.seq_start + sq)), "s"(dkv3_uni64(p.seq_len + sq)), "s"(dkv3_uni64(p.br_a + sq)), "s"(dkv3_uni64(p.br_b + sq))
+                         : "memory");
+        } else {
+            auto sload = [&](const int32_t* base, int dflt) {
+                if (base == nullptr) return dflt;
+                int v;
+                asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(dkv3_uni64(base + sq)) : "memory");
+                return v;
+            };
+            w.start = sload(p.seq_start, 0), w.len = sload(p.seq_len, p.T), w.a = sload(p.br_a, 0x7fffffff), w.b = sload(p.br_b, 0x7fffffff);
+        }
+        return w;
+    };
+    auto post = [&](int slot, const Posting& w) {
+        mail[8 * slot + 0] = w.item, mail[8 * slot + 1] = w.start, mail[8 * slot + 2] = w.len, mail[8 * slot + 3] = w.a, mail[8 * slot + 4] = w.b;
+    };
+    auto collect = [&](int slot, Dkv3Geom& g) {
+        g.set<CAUSAL>(p, (int)dkv3_uni((unsigned)mail[8 * slot + 0]), (int)dkv3_uni((unsigned)mail[8 * slot + 1]), (int)dkv3_uni((unsigned)mail[8 * slot + 2]),
+                      (int)dkv3_uni((unsigned)mail[8 * slot + 3]), (int)dkv3_uni((unsigned)mail[8 * slot + 4]));
+    };
+    int drawn = 0;      // thread 0: the home counter's answer for the item after next
+    if (threadIdx.x == 0) {
+        post(0, look_up(resolve(atomicAdd(p.sched + 32 * home, 1))));
+        post(1, look_up(resolve(atomicAdd(p.sched + 32 * home, 1))));
+        drawn = atomicAdd(p.sched + 32 * home, 1);
+    }
+    __syncthreads();
+    Dkv3Geom cur, nxt;
+    collect(0, cur);
+    collect(1, nxt);
+
+    const unsigned q_piece = dkv3_uni((unsigned)(16 * p.ld_qkv * 2)), do_piece = dkv3_uni((unsigned)(16 * p.ld_do * 2));
+    const unsigned wave_u = dkv3_uni((unsigned)wave);
+    const float sc = p.scale * kLog2e;
+    const bf16_t* qp0 = p.q;
+    const bf16_t* dop0 = p.d_o;
+
+    bool prefetched = false;      // cur's first tiles were requested by the previous item's asm block
+
 #ifdef HALVA_STAMP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    DKV3_NOW(stamp[7]);
-    if (p.dbg && lane == 0 && s == 1 && hd == 3 && wave == 0)      // (a pair in the middle of the launch, not its very first workgroups)
-        for (int i = 0; i < 12; ++i) p.dbg[1024 + kb * 12 + i] = stamp[i];
+#define DKV3_NOW(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory")
+    unsigned long long acc_pre_ = 0, acc_asm_ = 0, acc_post_ = 0, n_items_ = 0, t0_, t1_, t2_, t3_;
+#endif
+#pragma unroll 1
+    for (int round = 0; cur.valid; ++round) {
+#ifdef HALVA_STAMP
+        DKV3_NOW(t0_);
+        t1_ = t2_ = t0_;
+#endif
+        asm volatile("" : "+s"(nkb), "+s"(G));      // (else the reciprocals of the scheduler's divisions are hoisted out of the loop, spilled, and reloaded behind the requests in flight)
+        // the lane parts of the generated loop's LDS / global addresses are the same for every item, and are formed per item all the same:
+        // kept across the asm block (which leaves the compiler 97 vector registers) they were spilled to scratch, and a scratch reload waits
+        // for every tile request in flight (vmcnt counts in order)
+        int lane = lane_in;
+        asm volatile("" : "+v"(lane));
+        const int h = lane >> 5;
+        const unsigned rowrel = 2048 * ((lane & 31) >> 3) + 64 * (lane & 7) + 16 * (h ^ (((lane & 31) >> 2) & 3));
+        const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3, h2 = g16 >> 1;
+        const unsigned colrel = 64 * (4 * h2 + q4) + 16 * ((2 * (g16 & 1) + (pp >> 1)) ^ h2) + 8 * (pp & 1);
+        const unsigned statrel = 16 * h;
+        const unsigned voff_q = dkv3_piece_voff(p.ld_qkv, wave, lane, 0, 64), voff_do = dkv3_piece_voff(p.ld_do, wave, lane, 0, 64);
+        const int s = cur.s, hd = cur.hd, kb = cur.kb, len = cur.len, ntiles = cur.ntiles, q_begin = cur.q_begin, kblk_min = cur.kblk_min;
+        const Branch br = cur.br;
+        const int64_t seq_row0 = (int64_t)s * p.T;
+        const int gk = kb * 128 + 32 * wave + (lane & 31);
+        const int kl = gk - cur.start;
+        const bool k_in_T = gk < p.T;
+        const bool k_valid = k_in_T && kl >= 0 && kl < len;
+        const int npro_next = nxt.valid ? nxt.prefetchable() : 0;
+        bool requested_next = false;
+        const bool next_runs = nxt.valid && nxt.ntiles > 0;
+        if (ntiles > 0) {
+            // this item's K / V fragments, asked for FIRST and by hand, straight into the registers the block reads them from (a key outside
+            // the sequence reads the nearest one inside: its lane is masked).  They land during the address arithmetic below; nobody waits
+            // for them before the block's own s_waitcnt vmcnt(0).  Loaded by the compiler they cost a vmcnt(0) wherever it chose to move them
+            // (it cannot count past an asm block): behind the stores of the previous item's rows, i.e. a wait for their acknowledgements.
+            u32x4 kq[8], vq[8];
+            {
+                const int kgk = cur.start + min(max(kl, 0), len - 1);
+                const bf16_t* k_ptr = p.k + (seq_row0 + kgk) * p.ld_qkv + hd * D + 8 * h;
+                const bf16_t* v_ptr = p.v + (seq_row0 + kgk) * p.ld_qkv + hd * D + 8 * h;
+                asm volatile(
+                    "global_load_dwordx4 %0, %16, off\n\tglobal_load_dwordx4 %1, %16, off offset:32\n\tglobal_load_dwordx4 %2, %16, off offset:64\n\t"
+                    "global_load_dwordx4 %3, %16, off offset:96\n\tglobal_load_dwordx4 %4, %16, off offset:128\n\tglobal_load_dwordx4 %5, %16, off offset:160\n\t"
+                    "global_load_dwordx4 %6, %16, off offset:192\n\tglobal_load_dwordx4 %7, %16, off offset:224\n\t"
+                    "global_load_dwordx4 %8, %17, off\n\tglobal_load_dwordx4 %9, %17, off offset:32\n\tglobal_load_dwordx4 %10, %17, off offset:64\n\t"
+                    "global_load_dwordx4 %11, %17, off offset:96\n\tglobal_load_dwordx4 %12, %17, off offset:128\n\tglobal_load_dwordx4 %13, %17, off offset:160\n\t"
+                    "global_load_dwordx4 %14, %17, off offset:192\n\tglobal_load_dwordx4 %15, %17, off offset:224"
+                    : "={a[128:131]}"(kq[0]), "={a[132:135]}"(kq[1]), "={a[136:139]}"(kq[2]), "={a[140:143]}"(kq[3]), "={a[144:147]}"(kq[4]), "={a[148:151]}"(kq[5]),
+                      "={a[152:155]}"(kq[6]), "={a[156:159]}"(kq[7]), "={a[160:163]}"(vq[0]), "={a[164:167]}"(vq[1]), "={a[168:171]}"(vq[2]), "={a[172:175]}"(vq[3]),
+                      "={a[176:179]}"(vq[4]), "={a[180:183]}"(vq[5]), "={a[184:187]}"(vq[6]), "={a[188:191]}"(vq[7])
+                    : "v"(k_ptr), "v"(v_ptr)
+                    : "memory");
+            }
+            const bool key_hidden = kl >= br.a && kl < br.b;
+            const bool block_all_keys_valid = kblk_min >= 0 && kblk_min + 128 <= len;      // workgroup-uniform: no padded key in the block
+            const bf16_t* qp = qp0 + hd * D;
+            const bf16_t* dop = dop0 + hd * D;
+            const int64_t qrow0 = seq_row0 + cur.start;
+            const float* lse2_g = p.lse2 + ((int64_t)s * p.H + hd) * p.T + cur.start;
+            const float* nd_g = p.delta + ((int64_t)s * p.H + hd) * p.T + cur.start;
+            char* ds_block = p.ds_ws + ((((int64_t)s * p.H + hd) * p.ds_nkb + kb) * p.ds_nt + q_begin / BQ) * 16384 + wave * 4096;
+            // a partial last tile: its rows are clamped to the sequence, piece by piece
+            unsigned alt_q[4], alt_do[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                alt_q[i] = dkv3_piece_voff(p.ld_qkv, wave, lane, i, cur.lr);
+                alt_do[i] = dkv3_piece_voff(p.ld_do, wave, lane, i, cur.lr);
+            }
+            const unsigned alt_stat = 4 * min(lane, cur.lr - 1);
+            // the next item's first tiles (requested by this item's last asm call)
+            const int64_t nrow0 = (int64_t)nxt.s * p.T + nxt.start + nxt.q_begin;
+            const unsigned long long nq_ptr = (unsigned long long)(size_t)(qp0 + nxt.hd * D + nrow0 * p.ld_qkv), ndo_ptr = (unsigned long long)(size_t)(dop0 + nxt.hd * D + nrow0 * p.ld_do);
+            const unsigned long long nl_ptr = (unsigned long long)(size_t)(p.lse2 + ((int64_t)nxt.s * p.H + nxt.hd) * p.T + nxt.start + nxt.q_begin);
+            const unsigned long long nn_ptr = (unsigned long long)(size_t)(p.delta + ((int64_t)nxt.s * p.H + nxt.hd) * p.T + nxt.start + nxt.q_begin);
+            // (fixed accumulator registers, the same in every asm statement that touches them: no copies; the block zeroes them on its first call)
+            f32x16 accV[4], accK[4];      // dV^T, dK^T (local to the item: carried from round to round they travelled through vector registers)
+            // thread 0: the item after next.  The counter's answer - asked for one round ago - is looked at HERE, straight in front of the asm
+            // block: the compiler waits for it with vmcnt(0), i.e. for everything in flight, which the block's first call does anyway; it
+            // goes, with its sequence, into the slot `cur` was read from
+            if (threadIdx.x == 0) {
+                post(round & 1, look_up(resolve(drawn)));
+                drawn = atomicAdd(p.sched + 32 * home, 1);
+            }
+            int t = 0;
+#define DKV3_ACC_MOD "="
+#include "sdpa_dkv3_call.h"
+#undef DKV3_ACC_MOD
+#pragma unroll 1
+            while (t < ntiles) {
+#define DKV3_ACC_MOD "+"
+#include "sdpa_dkv3_call.h"
+#undef DKV3_ACC_MOD
+            }
+            // (straight behind the loop, in the same block: carried to a common tail the accumulators travelled through vector registers)
+            int gk_st = gk;      // (the row pointers are formed HERE: formed before the asm block they were spilled across it, and their reload waited for the requests it had just made)
+            asm volatile("" : "+v"(gk_st));
+            bf16_t* dk_row = p.dk + (seq_row0 + gk_st) * p.ld_qkv + hd * D;
+            bf16_t* dv_row = p.dv + (seq_row0 + gk_st) * p.ld_qkv + hd * D;
+            if (k_in_T) {
+                store_rows_T<D>(dv_row, accV, k_valid ? 1.f : 0.f, true, lane);
+                store_rows_T<D>(dk_row, accK, k_valid ? p.scale : 0.f, true, lane);
+            }
+        } else {
+            if (threadIdx.x == 0) {
+                post(round & 1, look_up(resolve(drawn)));
+                drawn = atomicAdd(p.sched + 32 * home, 1);
+            }
+            int gk_st = gk;      // (the row pointers are formed HERE: formed before the asm block they were spilled across it, and their reload waited for the requests it had just made)
+            asm volatile("" : "+v"(gk_st));
+            bf16_t* dk_row = p.dk + (seq_row0 + gk_st) * p.ld_qkv + hd * D;
+            bf16_t* dv_row = p.dv + (seq_row0 + gk_st) * p.ld_qkv + hd * D;
+            if (k_in_T) {
+                store_rows_zero<D>(dk_row, lane);
+                store_rows_zero<D>(dv_row, lane);
+            }
+        }
+        // the mail box is LDS: wait for the LDS write only.  (__syncthreads() also waits for every vector-memory operation in flight - the
+        // acknowledgements of the rows just stored, the next item's tiles - which is exactly what this loop is arranged not to wait for.)
+        // Also: every wave is done with this item's LDS before a cold first call of the next one requests into it.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        cur = nxt;
+        prefetched = requested_next;
+        collect(round & 1, nxt);
+#ifdef HALVA_STAMP
+        DKV3_NOW(t3_);
+        acc_pre_ += t1_ - t0_, acc_asm_ += t2_ - t1_, acc_post_ += t3_ - t2_, ++n_items_;
+#endif
+    }
+#ifdef HALVA_STAMP
+    if (p.dbg && threadIdx.x == 0 && blockIdx.x < 120)
+        p.dbg[6144 + blockIdx.x * 4] = acc_pre_, p.dbg[6144 + blockIdx.x * 4 + 1] = acc_asm_, p.dbg[6144 + blockIdx.x * 4 + 2] = acc_post_, p.dbg[6144 + blockIdx.x * 4 + 3] = n_items_;
 #endif
 }
 
+// Persistent workgroups, one per CU, that draw (sequence, head, key block) items from eight queues - one per XCD, so that the workgroups of an
+// XCD work on the same few (sequence, head) pairs and find their Q / dO tiles in that XCD's L2 - and help the other queues out when their own
+// is empty.  Measured on the static 2048-workgroup launch this replaces (tools/stamp_rounds.py): two of the eight XCDs of a box ran every
+// workgroup 6-8 % slower than the rest (12 % more cycles per item), and since the hardware deals workgroups to XCDs round-robin the launch
+// ended when THEY were done.  Queue x holds the pairs x, x + 8, ...; the order inside it: SdpaParams::sched_order.
+// p.sched: eight counters 128 B apart, zeroed by the delta pass of the same call.
 template <int D, bool CAUSAL, bool ASM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void sdpa_bwd_dkv3_kernel(const SdpaParams p) {
     static_assert(D == 128, "sdpa_bwd_dkv3 is the head_dim-128 instantiation");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int s, hd, b;
-    map_block(blockIdx.x, CAUSAL ? (p.nblk + 1) / 2 : p.nblk, p.H, p.npairs, false, s, hd, b);
-    const int start = p.seq_start ? p.seq_start[s] : 0;
-    const int len = p.seq_len ? p.seq_len[s] : p.T;
-    const Branch br = load_branch(p, s);
-    // under the causal mask key block b is visited by (nblk - b) query blocks: pair b with nblk-1-b (ONE copy of the block code: a loop)
-    const int second = (CAUSAL && b != p.nblk - 1 - b) ? p.nblk - 1 - b : -1;
     WG_CLOCK_BEGIN();
+    if (ASM) {
+        sdpa_bwd_dkv3_items<CAUSAL>(p, smem, wave, lane);
+    } else {      // the plain build: queue 0..7 in turn, group-major, one atomic per item, no look-ahead
+        volatile int* mail = reinterpret_cast<volatile int*>(smem + DKV3_SCHED);
+        const int nkb = p.nblk, total = p.npairs * nkb;
 #pragma unroll 1
-    for (int pass = 0; pass < (second >= 0 ? 2 : 1); ++pass)
-        sdpa_bwd_dkv3_block<CAUSAL, ASM>(p, smem, s, hd, pass ? second : b, wave, lane, start, len, br);
+        for (int round = 0;; ++round) {
+            if (threadIdx.x == 0) mail[round & 1] = atomicAdd(p.sched, 1);
+            __syncthreads();
+            const int item = mail[round & 1];
+            if (item >= total) break;
+            const int g = item / nkb, kb = item - g * nkb, s = g / p.H, hd = g - s * p.H;
+            const int start = p.seq_start ? p.seq_start[s] : 0;
+            const int len = p.seq_len ? p.seq_len[s] : p.T;
+            sdpa_bwd_dkv3_block_hip<CAUSAL>(p, smem, s, hd, kb, wave, lane, start, len, load_branch(p, s));
+        }
+    }
     WG_CLOCK_END(p.dbg, 3);
 }

@@ -1,0 +1,79 @@
+// One call of the generated block (sdpa_dkv3_loop.inc) for the steps t .. t_side of the current item - included TWICE by sdpa_bwd_dkv3_items
+// (sdpa_dkv3.h): once for the item's first call, where the accumulators are outputs only (DKV3_ACC_MOD "=": the block zeroes them itself),
+// and once inside the loop over the rare further calls (a key block cut by a branch point), where they are read and written ("+").  With ONE
+// site inside a loop the accumulators became a loop-carried value that the compiler kept in vector registers: 128 copies out of and 128
+// into the accumulator file around every call.
+{
+            const int qt0 = q_begin + t * BQ;
+            const bool q_in_b = qt0 >= br.b;                     // br.b and qt0 are multiples of 64: uniform over the step
+            // ONE asm block for the steps up to the branch point (or the end): masked steps (the diagonal), interior steps, masked steps (the tail)
+            const int t_side = q_in_b ? ntiles : min(ntiles, (int)(((int64_t)br.b - q_begin + BQ - 1) / BQ));      // first step at or behind br.b
+            int n0, n1, n2;
+#ifdef HALVA_DKV3_ALL_MASKED      // diagnostic: every step through the masked phase (same results: an interior step's masks pass everything)
+            n0 = t_side - t, n1 = 0, n2 = 0;
+#else
+            {      // interior(t') on this side of br.b = side_ok && t_diag <= t' < t_full: three runs, no scan
+                const bool side_ok = block_all_keys_valid && !(q_in_b && kblk_min < br.b && kblk_min + 127 >= br.a);
+                const int t_diag = CAUSAL ? max(0, (kblk_min + 127 - q_begin + BQ - 1) / BQ) : 0;      // first t' with qt0 >= kblk_min + 127
+                const int t_full = max(0, (len - q_begin) / BQ);                                          // first t' with qt0 + 64 > len
+                const int lo = min(t_side, max(t, t_diag)), hi = min(t_side, max(lo, t_full));
+                n0 = side_ok ? lo - t : t_side - t;
+                n1 = side_ok ? hi - lo : 0;
+                n2 = t_side - t - n0 - n1;
+            }
+#endif
+            const int n = t_side - t;
+            const int ndma = min(n, max(0, ntiles - 3 - t));      // steps t' of the call with a tile t'+3 to request
+            const bool part = cur.last_partial && ndma > 0 && (t + ndma - 1 + 3 == ntiles - 1);
+            const bool lane_off = !k_valid || (q_in_b && key_hidden);
+            const unsigned lo0 = (unsigned)(kl - qt0 - 4 * h), range = lane_off ? 0u : (unsigned)(len - kl);
+            const unsigned long long ds_ptr = (unsigned long long)(size_t)(ds_block + (int64_t)t * 16384);
+            // the next tile to request: tile t+3 - or tile 0 on a cold first call, which requests tiles 0..2 up front
+            const bool cold = t == 0 && !prefetched;
+            const int tq = cold ? 0 : t + 3;
+            const unsigned long long q_ptr = (unsigned long long)(size_t)(qp + (qrow0 + q_begin + (int64_t)tq * BQ) * p.ld_qkv);
+            const unsigned long long do_ptr = (unsigned long long)(size_t)(dop + (qrow0 + q_begin + (int64_t)tq * BQ) * p.ld_do);
+            const unsigned long long lse_ptr = (unsigned long long)(size_t)(lse2_g + q_begin + tq * BQ);
+            const unsigned long long nd_ptr = (unsigned long long)(size_t)(nd_g + q_begin + tq * BQ);
+            const unsigned tail_n = t_side == ntiles ? (unsigned)npro_next : 0u;
+            // the call's control word: first call of the block | tiles it requests itself | which of those is the partial last tile | the next item's tiles
+            // | the run's last request is the partial last tile | ring slot of the first step's tile   (gen_dkv3_loop.py: CTL_*)
+            const unsigned ctl_u = dkv3_uni((t == 0 ? 1u : 0u) | ((cold ? (unsigned)min(3, ntiles) : 0u) << 1) |
+                                            (((cur.last_partial && ntiles <= 3) ? (unsigned)(ntiles - 1) : 7u) << 3) | (tail_n << 6) | ((part ? 1u : 0u) << 8) |
+                                            ((unsigned)(t & 3) << 9));
+            const unsigned n02_u = dkv3_uni((unsigned)n0 | ((unsigned)n2 << 16)), n1_u = dkv3_uni((unsigned)n1);      // (the launcher keeps T < 2^22)
+            const unsigned ndma_u = dkv3_uni((unsigned)ndma);
+            requested_next = requested_next || tail_n != 0;
+            // always-valid sources for the requests of the steps with no tile left (they land in the dummy chunk): the tensors' first 16 rows
+            // (the launcher requires S * T >= 16) and this pair's first statistics row (the lse2 region is padded by a row)
+            const unsigned long long safe_q = dkv3_uni64(qp), safe_do = dkv3_uni64(dop);
+            const unsigned long long safe_l = dkv3_uni64(p.lse2 + ((int64_t)s * p.H + hd) * p.T);
+#ifdef HALVA_STAMP
+            if (t == 0) DKV3_NOW(t1_);
+#endif
+            asm volatile(
+#include "sdpa_dkv3_loop.inc"
+                : [accV0] DKV3_ACC_MOD "{a[0:15]}"(accV[0]), [accV1] DKV3_ACC_MOD "{a[16:31]}"(accV[1]), [accV2] DKV3_ACC_MOD "{a[32:47]}"(accV[2]), [accV3] DKV3_ACC_MOD "{a[48:63]}"(accV[3]),
+                  [accK0] DKV3_ACC_MOD "{a[64:79]}"(accK[0]), [accK1] DKV3_ACC_MOD "{a[80:95]}"(accK[1]), [accK2] DKV3_ACC_MOD "{a[96:111]}"(accK[2]), [accK3] DKV3_ACC_MOD "{a[112:127]}"(accK[3])
+                : [kq0] "{a[128:131]}"(kq[0]), [kq1] "{a[132:135]}"(kq[1]), [kq2] "{a[136:139]}"(kq[2]), [kq3] "{a[140:143]}"(kq[3]), [kq4] "{a[144:147]}"(kq[4]),
+                  [kq5] "{a[148:151]}"(kq[5]), [kq6] "{a[152:155]}"(kq[6]), [kq7] "{a[156:159]}"(kq[7]), [vq0] "{a[160:163]}"(vq[0]), [vq1] "{a[164:167]}"(vq[1]),
+                  [vq2] "{a[168:171]}"(vq[2]), [vq3] "{a[172:175]}"(vq[3]), [vq4] "{a[176:179]}"(vq[4]), [vq5] "{a[180:183]}"(vq[5]), [vq6] "{a[184:187]}"(vq[6]),
+                  [vq7] "{a[188:191]}"(vq[7]), [rowrel] "v"(rowrel), [colrel] "v"(colrel), [statrel] "v"(statrel), [voff_q] "v"(voff_q), [voff_do] "v"(voff_do),
+                  [sc] "s"(sc), [n02] "s"(n02_u), [n1] "s"(n1_u), [ndma] "s"(ndma_u), [wave] "s"(wave_u), [q_piece] "s"(q_piece), [do_piece] "s"(do_piece),
+                  [lo0] "v"(lo0), [range] "v"(range), [alt_q0] "v"(alt_q[0]), [alt_q1] "v"(alt_q[1]), [alt_q2] "v"(alt_q[2]), [alt_q3] "v"(alt_q[3]),
+                  [alt_do0] "v"(alt_do[0]), [alt_do1] "v"(alt_do[1]), [alt_do2] "v"(alt_do[2]), [alt_do3] "v"(alt_do[3]), [alt_stat] "v"(alt_stat),
+                  [safe_q] "s"(safe_q), [safe_do] "s"(safe_do), [safe_l] "s"(safe_l), [ctl] "s"(ctl_u),
+                  // uniform 64-bit addresses as two vector registers each (the block reads them with v_readfirstlane: scalar operands are scarce)
+                  [q_lo] "v"((unsigned)q_ptr), [q_hi] "v"((unsigned)(q_ptr >> 32)), [do_lo] "v"((unsigned)do_ptr), [do_hi] "v"((unsigned)(do_ptr >> 32)),
+                  [lse_lo] "v"((unsigned)lse_ptr), [lse_hi] "v"((unsigned)(lse_ptr >> 32)), [nd_lo] "v"((unsigned)nd_ptr), [nd_hi] "v"((unsigned)(nd_ptr >> 32)),
+                  [ds_lo] "v"((unsigned)ds_ptr), [ds_hi] "v"((unsigned)(ds_ptr >> 32)), [nq_lo] "v"((unsigned)nq_ptr), [nq_hi] "v"((unsigned)(nq_ptr >> 32)),
+                  [ndo_lo] "v"((unsigned)ndo_ptr), [ndo_hi] "v"((unsigned)(ndo_ptr >> 32)), [nlse_lo] "v"((unsigned)nl_ptr), [nlse_hi] "v"((unsigned)(nl_ptr >> 32)),
+                  [nnd_lo] "v"((unsigned)nn_ptr), [nnd_hi] "v"((unsigned)(nn_ptr >> 32))
+                :
+#include "sdpa_dkv3_loop_clobbers.inc"
+            );
+            t = t_side;
+#ifdef HALVA_STAMP
+            DKV3_NOW(t2_);
+#endif
+}

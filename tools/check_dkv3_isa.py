@@ -1,0 +1,26 @@
+"""Build-time check of sdpa_bwd_dkv3's generated-asm kernel (device assembly from `hipcc -S --cuda-device-only sdpa.hip`):
+  * no compiler-generated instruction touches a128-a191 (the K / V fragments are fetched by hand into those registers and may still be in
+    flight while the compiler's code runs: a copy would read them too early), nor - between the asm statements of an item - a0-a127;
+  * no scratch (a scratch reload waits, in order, for every tile request in flight).
+usage: python tools/check_dkv3_isa.py <file.s>"""
+import re, sys
+txt = open(sys.argv[1]).read().split("\n")
+bad = 0
+starts = [i for i, l in enumerate(txt) if re.match(r"_ZN\S*sdpa_bwd_dkv3_kernelILi128ELb[01]ELb1\S*:", l)]      # the ASM = true instantiations
+assert starts, "no sdpa_bwd_dkv3 kernel in " + sys.argv[1]
+for start in starts:
+    end = next(i for i in range(start, len(txt)) if "s_endpgm" in txt[i])
+    inasm = False
+    for i in range(start, end):
+        l = txt[i]
+        if "ASMSTART" in l: inasm = True; continue
+        if "ASMEND" in l: inasm = False; continue
+        if inasm or l.strip().startswith(";"): continue
+        if "scratch_" in l:
+            print("scratch:", l.strip()); bad += 1
+        for m in re.finditer(r"\ba\[?(\d+)(?::(\d+))?\]?", l.split(";")[0]):
+            lo = int(m.group(1)); hi = int(m.group(2) or lo)
+            if hi >= 128 and lo <= 191:
+                print("K/V fragment register touched by the compiler:", l.strip()); bad += 1
+print("sdpa_bwd_dkv3 ISA check:", "FAILED (%d)" % bad if bad else "ok")
+sys.exit(1 if bad else 0)

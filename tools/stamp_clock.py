@@ -29,6 +29,15 @@ for region, name in enumerate(("sdpa_fwd", "sdpa_bwd_dkv2", "sdpa_bwd_dq2", "sdp
     mhz = 100.0 * w[:, 0] / w[:, 1]
     out[name] = {"workgroups_sampled": int(len(w)), "cycles_per_workgroup_median": int(np.median(w[:, 0])), "us_per_workgroup_median": round(float(np.median(w[:, 1])) / 100.0, 1),
                  "in_kernel_mhz_median": round(float(np.median(mhz)), 0), "in_kernel_mhz_p10": round(float(np.percentile(mhz, 10)), 0), "in_kernel_mhz_p90": round(float(np.percentile(mhz, 90)), 0)}
+    # the samples are the first 120 workgroups of XCD 0 (blockIdx % 8 == 0), 32 CUs, one workgroup per CU for the dK/dV kernels: the k-th start
+    # (k >= slots) re-uses the CU the (k - slots)-th end freed -> how long a CU sits between two workgroups
+    st = np.sort(w[:, 2]); en = np.sort(w[:, 2] + w[:, 1])
+    out[name]["us_per_workgroup_p10_p90"] = [round(float(np.percentile(w[:, 1], 10)) / 100.0, 1), round(float(np.percentile(w[:, 1], 90)) / 100.0, 1)]
+    first = int((st < st[0] + 200).sum())          # workgroups that started within 2 us of the first = resident slots on this XCD
+    out[name]["resident_slots_xcd0"] = first
+    if first < len(st):
+        gaps = (st[first:] - en[:len(st) - first]) / 100.0
+        out[name]["us_between_workgroups_on_a_slot_median_p90"] = [round(float(np.median(gaps)), 2), round(float(np.percentile(gaps, 90)), 2)]
     print(name, out[name])
 if len(sys.argv) > 1:
     json.dump({"tool": "tools/stamp_clock.py", "shape": {"S": S, "T": T, "H": H, "D": D}, "commit": os.environ.get("HALVA_COMMIT"), "kernels": out}, open(sys.argv[1], "w"), indent=1)
