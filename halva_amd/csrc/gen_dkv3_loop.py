@@ -24,7 +24,7 @@ lo0 / range the masks' per-lane bounds ("v"): a score of key kl and row ql = qt0
 iff unsigned(c - lo) < range with lo = kl - qt0 - 4 h of the first step (the loop subtracts 64 per step) and range = len - kl (0 = lane off);
 alt_q0-3 / alt_do0-3 / alt_stat the lane offsets of the pieces / the statistics row of a PARTIAL last tile (rows clamped to the sequence) ("v");
 safe_q / safe_do / safe_l always-valid addresses that the requests of the steps without a tile left read into the dummy chunk ("s");
-ctl the control word (CTL_* below) ("s");  every other address arrives as the low / high word of a uniform value in VECTOR registers
+ctl the control word (CTL_* below) ("s"); drawn ("=&v") what the home queue's counter at sched_ptr ("v", 64 bit) answered (first call, thread 0);  every other address arrives as the low / high word of a uniform value in VECTOR registers
 (x_lo, x_hi: scalar operands are scarce, and when they run out the compiler silently hands the asm a vector register): q / do the first row
 of the first tile to request, lse / nd its statistics rows, ds the dS pointer of the first step (this wave's strip), nq / ndo / nlse / nnd
 the rows of the workgroup's NEXT item.
@@ -352,6 +352,11 @@ def main():
     #      with the loop's own cheap form of a request (the caller has passed the barrier behind the previous block's last reads); tile CTL_PROALT
     #      of them (7 = none) is the sequence's partial last tile and takes the clamped lane offsets.  Then everything has to land.
     pro += ["s_bitcmp0_b32 %[ctl], 0", "s_cbranch_scc1 .Ldkv3_nofirst_%="]
+    # the workgroup's scheduler (sdpa_dkv3.h): thread 0 draws the item after the item after next HERE - the counter's answer comes back under
+    # the s_waitcnt vmcnt(0) below and leaves the block as an ordinary output.  Asked for by the compiler's own atomic it had to be waited for
+    # with vmcnt(0) in the middle of the next round (the compiler cannot count past an asm block): ~6 000 cycles per item.
+    pro += ["s_cmp_lg_u32 %[wave], 0", "s_cbranch_scc1 .Ldkv3_nodraw_%=", "s_mov_b64 %s, exec" % sp(SRC), "s_mov_b64 exec, 1", "v_mov_b32_e32 v%d, 1" % RING,
+            "global_atomic_add %%[drawn], %%[sched_ptr], v%d, off sc0" % RING, "s_mov_b64 exec, %s" % sp(SRC), ".Ldkv3_nodraw_%=:"]
     # (an accumulator tuple operand cannot be sliced into single registers from here: it is zeroed by an MFMA of zero fragments, D = 0 * 0 + 0)
     pro += ["v_mov_b32_e32 v%d, 0" % (RING + j) for j in range(4)] + ["s_nop 4"]
     for opnd in range(8):

@@ -332,7 +332,7 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
 
 #ifdef HALVA_STAMP
 #define DKV3_NOW(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory")
-    unsigned long long acc_pre_ = 0, acc_asm_ = 0, acc_post_ = 0, n_items_ = 0, t0_, t1_, t2_, t3_;
+    unsigned long long acc_pre_ = 0, acc_asm_ = 0, acc_post_ = 0, n_items_ = 0, t0_, t1_, t2_, t3_, tk_ = 0, ts_ = 0, acc_k_ = 0, acc_s_ = 0;
 #endif
 #pragma unroll 1
     for (int round = 0; cur.valid; ++round) {
@@ -385,6 +385,9 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
                     : "v"(k_ptr), "v"(v_ptr)
                     : "memory");
             }
+#ifdef HALVA_STAMP
+            DKV3_NOW(tk_);
+#endif
             const bool key_hidden = kl >= br.a && kl < br.b;
             const bool block_all_keys_valid = kblk_min >= 0 && kblk_min + 128 <= len;      // workgroup-uniform: no padded key in the block
             const bf16_t* qp = qp0 + hd * D;
@@ -408,19 +411,22 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
             const unsigned long long nn_ptr = (unsigned long long)(size_t)(p.delta + ((int64_t)nxt.s * p.H + nxt.hd) * p.T + nxt.start + nxt.q_begin);
             // (fixed accumulator registers, the same in every asm statement that touches them: no copies; the block zeroes them on its first call)
             f32x16 accV[4], accK[4];      // dV^T, dK^T (local to the item: carried from round to round they travelled through vector registers)
-            // thread 0: the item after next.  The counter's answer - asked for one round ago - is looked at HERE, straight in front of the asm
-            // block: the compiler waits for it with vmcnt(0), i.e. for everything in flight, which the block's first call does anyway; it
-            // goes, with its sequence, into the slot `cur` was read from
-            if (threadIdx.x == 0) {
-                post(round & 1, look_up(resolve(drawn)));
-                drawn = atomicAdd(p.sched + 32 * home, 1);
-            }
+#ifdef HALVA_STAMP
+            DKV3_NOW(ts_);
+#endif
+            // thread 0: the item after next (the counter's answer came out of the previous item's asm block) goes, with its sequence, into the slot
+            // `cur` was read from
+            if (threadIdx.x == 0) post(round & 1, look_up(resolve(drawn)));
+            int* home_counter = p.sched + 32 * home;
+            int drawn_out;      // the next answer of the home queue's counter: asked for by the block's first call (see gen_dkv3_loop.py)
             int t = 0;
 #define DKV3_ACC_MOD "="
 #include "sdpa_dkv3_call.h"
 #undef DKV3_ACC_MOD
+            if (threadIdx.x == 0) drawn = drawn_out;
 #pragma unroll 1
             while (t < ntiles) {
+                int drawn_out;      // (not a first call: nothing is drawn)
 #define DKV3_ACC_MOD "+"
 #include "sdpa_dkv3_call.h"
 #undef DKV3_ACC_MOD
@@ -458,11 +464,12 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
 #ifdef HALVA_STAMP
         DKV3_NOW(t3_);
         acc_pre_ += t1_ - t0_, acc_asm_ += t2_ - t1_, acc_post_ += t3_ - t2_, ++n_items_;
+        if (tk_ > t0_) acc_k_ += tk_ - t0_, acc_s_ += ts_ - tk_;
 #endif
     }
 #ifdef HALVA_STAMP
     if (p.dbg && threadIdx.x == 0 && blockIdx.x < 120)
-        p.dbg[6144 + blockIdx.x * 4] = acc_pre_, p.dbg[6144 + blockIdx.x * 4 + 1] = acc_asm_, p.dbg[6144 + blockIdx.x * 4 + 2] = acc_post_, p.dbg[6144 + blockIdx.x * 4 + 3] = n_items_;
+        p.dbg[7000 + blockIdx.x * 2] = acc_k_, p.dbg[7000 + blockIdx.x * 2 + 1] = acc_s_, p.dbg[6144 + blockIdx.x * 4] = acc_pre_, p.dbg[6144 + blockIdx.x * 4 + 1] = acc_asm_, p.dbg[6144 + blockIdx.x * 4 + 2] = acc_post_, p.dbg[6144 + blockIdx.x * 4 + 3] = n_items_;
 #endif
 }
 

@@ -24,6 +24,9 @@ if not len(pb): sys.exit(0)
 n = pb[:, 3].sum()
 print("workgroups 0..%d: items %d..%d; per item: before the asm %.0f cycles, in the asm %.0f, behind it (K/V of the next, stores, scheduler) %.0f; life cycles median %d" % (
     len(pb) - 1, pb[:, 3].min(), pb[:, 3].max(), pb[:, 0].sum() / n, pb[:, 1].sum() / n, pb[:, 2].sum() / n, np.median(w[:, 0])))
+ks = a[7000:7000 + 240].reshape(120, 2)[:len(pb)]
+print("   of the cycles before the asm: round top -> K / V fetch issued %.0f, -> address arithmetic done %.0f, -> scheduler's part done (asm entered) %.0f" % (
+    ks[:, 0].sum() / n, ks[:, 1].sum() / n, (pb[:, 0].sum() - ks.sum()) / n))
 for x in range(8):
     g = pb[x::8]
     print("   XCD %d: items per workgroup %.1f, cycles per item %.0f + %.0f + %.0f" % (x, g[:, 3].mean(), g[:, 0].sum() / g[:, 3].sum(), g[:, 1].sum() / g[:, 3].sum(), g[:, 2].sum() / g[:, 3].sum()))
