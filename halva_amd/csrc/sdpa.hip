@@ -1674,7 +1674,8 @@ int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st) {
     const bool slow = slow_tr_requested();
     if (p.ds_ws != nullptr && D == 128) {      // dS formed once: delta (+ zero-fill of padded dq rows) -> dK/dV (+ dS store) -> dQ = dS K
         const int64_t rows = (int64_t)S * p.T;
-        const bool dkv3 = !slow && p.lse2 != nullptr && rows >= 16 && p.T < (1 << 22) && env_flag_on("HALVA_SDPA_DKV3");      // (its step counts travel as 16-bit fields)
+        const bool dkv3 = !slow && p.lse2 != nullptr && rows >= 16 && p.T < (1 << 22) && (int64_t)S * p.H * ((p.T + 127) / 128) < (1 << 23) &&
+                          env_flag_on("HALVA_SDPA_DKV3");      // (its step counts travel as 16-bit fields, its scheduler divides in fp32)
         hipLaunchKernelGGL((sdpa_bwd_delta_kernel<D>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, S, dkv3 ? 1 : 0);
         HALVA_CHECK_LAUNCH("sdpa_bwd_delta");      // (a failed launch would leave stale delta / unzeroed padded dq rows for the two kernels below)
         int rc2;

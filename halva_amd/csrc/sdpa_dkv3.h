@@ -217,11 +217,9 @@ struct Dkv3Geom {
     int kblk_min, q_begin, ntiles;      // first key of the block in sequence coordinates; first query row that sees it; its 64-row steps
     int last_partial, lr;               // the last step's tile stops inside the sequence: lr of its 64 rows exist
     template <bool CAUSAL>
-    __device__ __forceinline__ void set(const SdpaParams& p, int item, int start_, int len_, int a, int b) {
+    __device__ __forceinline__ void set(int valid_, int s_, int hd_, int kb_, int start_, int len_, int a, int b) {
         constexpr int BQ = 64;
-        valid = item >= 0;
-        const int it = max(item, 0), g = it / p.nblk;
-        kb = it - g * p.nblk, s = g / p.H, hd = g - s * p.H;
+        valid = valid_, s = s_, hd = hd_, kb = kb_;
         start = start_, len = len_, br.a = a, br.b = b;
         kblk_min = kb * 128 - start;
         q_begin = CAUSAL ? max(0, kblk_min) / BQ * BQ : 0;
@@ -231,9 +229,9 @@ struct Dkv3Geom {
         const int last_rows = len - (q_begin + (ntiles - 1) * BQ);      // >= 64: whole (or the block's rows stop at br.b)
         last_partial = last_rows < BQ;
         lr = last_partial ? last_rows : BQ;
-        // the divisions above run on the vector unit; without this everything derived from them stays in vector registers and the loops over
-        // the block's steps are compiled as divergent ones (accumulators copied out of and into their registers around the asm block)
-        kb = (int)dkv3_uni((unsigned)kb), s = (int)dkv3_uni((unsigned)s), hd = (int)dkv3_uni((unsigned)hd), kblk_min = (int)dkv3_uni((unsigned)kblk_min);
+        // (whatever of the above ran on the vector unit: without this everything derived from it stays in vector registers and the loops over
+        // the block's steps are compiled as divergent ones, the accumulators copied out of and into their registers around the asm block)
+        kblk_min = (int)dkv3_uni((unsigned)kblk_min);
         q_begin = (int)dkv3_uni((unsigned)q_begin), ntiles = (int)dkv3_uni((unsigned)ntiles), last_partial = (int)dkv3_uni((unsigned)last_partial), lr = (int)dkv3_uni((unsigned)lr);
     }
     // the block's first three tiles are whole ones: the previous item's asm block may request them on its way out
@@ -252,23 +250,37 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
     // (an LDS-typed pointer: through a generic one the accesses are FLAT instructions, which wait on the vector-memory counter as well - i.e.
     // for the acknowledgements of the rows just stored and the next item's tiles, all of which this loop is arranged not to wait for)
     typedef __attribute__((address_space(3))) volatile int LdsInt;
-    LdsInt* mail = (LdsInt*)(__attribute__((address_space(3))) char*)(smem + DKV3_SCHED);      // [2][8]: item, start, len, br.a, br.b
+    LdsInt* mail = (LdsInt*)(__attribute__((address_space(3))) char*)(smem + DKV3_SCHED);      // [2][8]: Posting
     const int home = blockIdx.x & 7, order = p.sched_order;
     int nkb = p.nblk, G = p.npairs;      // (not const: laundered once per round, see below)
     auto queue_len = [&](int x) { return x < G ? ((G - x + 7) >> 3) * nkb : 0; };
-    auto item_of = [&](int x, int j) {
+    // floor(n / d) for 0 <= n < 2^23 (the launcher checks), d >= 1: one multiplication by the reciprocal and one correction step
+    auto fdiv = [](int n, int d) {
+        int q = (int)((float)n * __frcp_rn((float)d));
+        const int r = n - q * d;
+        return r < 0 ? q - 1 : (r >= d ? q + 1 : q);
+    };
+    struct Posting {
+        int valid, s, hd, kb, start, len, a, b;
+    };
+    auto item_of = [&](int x, int j) {      // item j of queue x -> (pair, key block)
         const int ng = (G - x + 7) >> 3;
         int gi, kb;
         if (order == 1) {      // key-block major over the whole queue (measured: loses the L2's reuse of Q / dO, +30 % per step)
-            kb = j / ng, gi = j - kb * ng;
+            kb = fdiv(j, ng), gi = j - kb * ng;
         } else if (order == 2) {      // the long half of every pair, pair by pair; then the short halves key-block major: what is left for the end is short
             const int hl = (nkb + 1) >> 1, nl = ng * hl;
-            if (j < nl) gi = j / hl, kb = j - gi * hl;
-            else kb = hl + (j - nl) / ng, gi = (j - nl) % ng;
+            if (j < nl) {
+                gi = fdiv(j, hl), kb = j - gi * hl;
+            } else {
+                const int q = fdiv(j - nl, ng);
+                kb = hl + q, gi = j - nl - q * ng;
+            }
         } else {
-            gi = j / nkb, kb = j - gi * nkb;
+            gi = fdiv(j, nkb), kb = j - gi * nkb;
         }
-        return (x + 8 * gi) * nkb + kb;
+        const int g = x + 8 * gi, sq = fdiv(g, p.H);
+        return Posting{1, sq, g - sq * p.H, kb, 0, 0, 0, 0};
     };
     auto resolve = [&](int j) {      // j: what the home queue's counter returned
         if (j < queue_len(home)) return item_of(home, j);
@@ -278,16 +290,13 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
             const int jj = atomicAdd(p.sched + 32 * x, 1);
             if (jj < n) return item_of(x, jj);
         }
-        return -1;
-    };
-    struct Posting {
-        int item, start, len, a, b;
+        return Posting{0, 0, 0, 0, 0, 0, 0, 0};
     };
     // the item's sequence, by SCALAR loads: they return through lgkmcnt; as vector loads the compiler would wait for them with vmcnt(0) (it
     // knows nothing of what the asm blocks have in flight), i.e. for everything
-    auto look_up = [&](int item) {      // thread 0 only
-        const int sq = (int)dkv3_uni((unsigned)(max(item, 0) / nkb / p.H));
-        Posting w{item, 0, p.T, 0x7fffffff, 0x7fffffff};
+    auto look_up = [&](Posting w) {      // thread 0 only
+        const int sq = (int)dkv3_uni((unsigned)w.s);
+        w.start = 0, w.len = p.T, w.a = 0x7fffffff, w.b = 0x7fffffff;
         if (p.seq_start && p.seq_len && p.br_a && p.br_b) {      // (the packed launch of the training step: four loads, one wait)
             asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\ts_load_dword %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
                          : "=&s"(w.start), "=&s"(w.len), "=&s"(w.a), "=&s"(w.b)
@@ -305,11 +314,14 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
         return w;
     };
     auto post = [&](int slot, const Posting& w) {
-        mail[8 * slot + 0] = w.item, mail[8 * slot + 1] = w.start, mail[8 * slot + 2] = w.len, mail[8 * slot + 3] = w.a, mail[8 * slot + 4] = w.b;
+        mail[8 * slot + 0] = w.valid, mail[8 * slot + 1] = w.s, mail[8 * slot + 2] = w.hd, mail[8 * slot + 3] = w.kb;
+        mail[8 * slot + 4] = w.start, mail[8 * slot + 5] = w.len, mail[8 * slot + 6] = w.a, mail[8 * slot + 7] = w.b;
     };
     auto collect = [&](int slot, Dkv3Geom& g) {
-        g.set<CAUSAL>(p, (int)dkv3_uni((unsigned)mail[8 * slot + 0]), (int)dkv3_uni((unsigned)mail[8 * slot + 1]), (int)dkv3_uni((unsigned)mail[8 * slot + 2]),
-                      (int)dkv3_uni((unsigned)mail[8 * slot + 3]), (int)dkv3_uni((unsigned)mail[8 * slot + 4]));
+        int w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = (int)dkv3_uni((unsigned)mail[8 * slot + i]);
+        g.set<CAUSAL>(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
     };
     int drawn = 0;      // thread 0: the home counter's answer for the item after next
     if (threadIdx.x == 0) {

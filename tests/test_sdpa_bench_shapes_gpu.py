@@ -81,3 +81,49 @@ def test_packed_bench_row(ds_ws, monkeypatch):
     # rows of B really ignore A: recompute two B rows by hand from the prefix and B keys only
     # (dense-mask reference already encodes it; this guards the reference itself)
     assert rel_err(o[0, 2048:], ref[0, 2048:]) < 1e-2
+
+
+def _bwd_bits(S, T, H, D, lens, starts, br, seed, env):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        g = torch.Generator().manual_seed(seed)
+        qkv = bf(torch.randn(S, T, 3, H, D, generator=g))
+        dout = bf(torch.randn(S, T, H, D, generator=g))
+        qg = qkv.to(DEV).view(S, T, 3 * H * D).clone().requires_grad_(True)
+        mk = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+        args = (mk(br[0]), mk(br[1])) if br else ()
+        out = K().sdpa_causal(qg, mk(starts), mk(lens), H, D, *args)
+        out.backward(dout.to(DEV).view(S, T, H * D))
+        torch.cuda.synchronize()
+        return qg.grad.clone()
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+
+@pytest.mark.parametrize("case", ["ragged_5_heads", "packed", "one_pair"])
+def test_dkv3_work_queues_are_a_permutation_of_the_static_launch(case):
+    """sdpa_bwd_dkv3 runs as persistent workgroups that draw (sequence, head, key block) items from eight queues, steal from the others when
+    their own is empty, and hand each other the next item's tiles and K / V fragments across items.  Whatever order the items come in -
+    pair-major, key-block-major, long halves first (HALVA_DKV3_ORDER = 0 / 1 / 2) - every item must run exactly once and alone on its rows:
+    the gradients of the three orders are bit-identical, and equal to the two-role kernel's (HALVA_SDPA_DKV3=0) up to its own rounding.
+    Cases: S * H not a multiple of 8 with ragged sequences (empty queues, key blocks without rows); the packed bench row (blocks cut by the
+    branch point: two asm calls per item, no prefetch across some items); fewer items than CUs."""
+    D = 128
+    if case == "ragged_5_heads":
+        S, T, H, lens, starts, br = 3, 640, 5, [640, 333, 70], [0, 64, 500], None
+    elif case == "packed":
+        S, T, H, lens, starts, br = 2, 1216, 8, [1216, 1100], [0, 0], ([300, 290], [768, 704])
+    else:
+        S, T, H, lens, starts, br = 1, 384, 1, [384], [0], None
+    ref = None
+    for order in ("0", "1", "2"):
+        g = _bwd_bits(S, T, H, D, lens, starts, br, 5, {"HALVA_DKV3_ORDER": order})
+        assert torch.isfinite(g).all()
+        if ref is None: ref = g
+        else: assert torch.equal(g, ref), "order " + order
+    old = _bwd_bits(S, T, H, D, lens, starts, br, 5, {"HALVA_SDPA_DKV3": "0"})
+    assert rel_err(ref.float().cpu(), old.float().cpu()) < 5e-3
