@@ -19,15 +19,16 @@ accV0-3 / accK0-3 the dV^T / dK^T accumulators ("+a", fixed registers), kq0-7 / 
 still in flight when the block is entered - its first call starts with s_waitcnt vmcnt(0)); rowrel, colrel, statrel the
 row-read, transposed-read and statistics lane offsets, voff_q / voff_do the lane offsets of the Q / dO tile pieces ("v"); sc = scale * log2 e,
 n02 / n1 the steps of the three phases (masked | plain | masked: the diagonal steps, the interior, the tail; n02 = first | last << 16),
-ndma the steps that request a tile, wave, q_piece / do_piece the bytes between a wave's pieces (16 rows) ("s");
+ndma the steps that request a tile (+ the next item's tiles << 8, see dma_groups), wave, q_piece / do_piece the bytes between a wave's pieces (16 rows) ("s");
 lo0 / range the masks' per-lane bounds ("v"): a score of key kl and row ql = qt0 + 4 h + c (c = the register's row inside the step) survives
 iff unsigned(c - lo) < range with lo = kl - qt0 - 4 h of the first step (the loop subtracts 64 per step) and range = len - kl (0 = lane off);
 alt_q0-3 / alt_do0-3 / alt_stat the lane offsets of the pieces / the statistics row of a PARTIAL last tile (rows clamped to the sequence) ("v");
 safe_q / safe_do / safe_l always-valid addresses that the requests of the steps without a tile left read into the dummy chunk ("s");
 ctl the control word (CTL_* below) ("s"); drawn ("=&v") what the home queue's counter at sched_ptr ("v", 64 bit) answered (first call, thread 0);  every other address arrives as the low / high word of a uniform value in VECTOR registers
 (x_lo, x_hi: scalar operands are scarce, and when they run out the compiler silently hands the asm a vector register): q / do the first row
-of the first tile to request, lse / nd its statistics rows, ds the dS pointer of the first step (this wave's strip), nq / ndo / nlse / nnd
-the rows of the workgroup's NEXT item.
+of the first tile to request, lse / nd its statistics rows, ds the dS pointer of the first step (this wave's strip).  The rows of the
+workgroup's NEXT item (nq / ndo / nlse / nnd: low / high words in vector registers too) are requested by the block's last three steps
+(ndma bits 8-15: how many of its tiles).
 The masked phases cost three more vector instructions per score."""
 import sys
 
@@ -45,9 +46,9 @@ DO_LDS, LSE_LDS, ND_DELTA, NSLOT = 65536, 131072, 1024, 4
 VM_STEADY = 32                      # vector-memory operations issued behind the requests of tile t+1 when step t waits for it: 3 x 4 stores + 2 x 10 requests
 WAIT_GAP = 64 - LOOKAHEAD - 1
 # ctl, the call's control word: bit 0 first call of the key block, bits 1-2 tiles to request up front, bits 3-5 which of them is the partial
-# last tile (7: none), bits 6-7 tiles of the workgroup's next item to request on the way out, bit 8 the run's last request is the partial
+# last tile (7: none), bit 8 the run's last request is the partial
 # last tile, bits 9-10 ring slot of the first step's tile;  s97 takes the field being looked at
-CTL_NPRO, CTL_PROALT, CTL_TAIL = "s_bfe_u32 s97, %[ctl], 0x20001", "s_bfe_u32 s97, %[ctl], 0x30003", "s_bfe_u32 s97, %[ctl], 0x20006"
+CTL_NPRO, CTL_PROALT = "s_bfe_u32 s97, %[ctl], 0x20001", "s_bfe_u32 s97, %[ctl], 0x30003"
 DMA_GAPS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]      # the quiet head of the step (no vector work yet): tile t+3 into the slot tile t-1 left at the last barrier
 
 
@@ -171,10 +172,16 @@ def dma_groups():
     step's vector-memory operations stay the same fourteen, so the wait for tile t+1 is ONE counted vmcnt in every step.  Only the partial
     last tile of a sequence (rows clamped piece by piece: S_USEALT) leaves the line, to code behind the loop (`ool`)."""
     groups, ool = [], []
-    pre = ["s_add_u32 %s, %s, 3" % (S_TMP, S_SLOT), "s_and_b32 %s, %s, 3" % (S_TMP, S_TMP), "s_lshl_b32 %s, %s, 14" % (S_DSTQ, S_TMP),
+    # S_DMALEFT: bits 0-7 tiles of this block still to request; bits 8-15 tiles of the workgroup's NEXT item to request behind them (the steps
+    # of a block that have no tile of their own left to ask for - its last three - ask for the next item's first tiles instead of the dummy:
+    # same slot rotation, so the next block simply starts on a rotated ring; free of charge, where a prefetch block of its own behind the
+    # steps cost 3 700 cycles per item); bit 16: that switch has been made (it also keeps the partial-tile path off the next item's tiles)
+    pre = ["s_and_b32 s97, %s, 0xff" % S_DMALEFT, "s_cmp_eq_u32 s97, 0", "s_cbranch_scc1 .Ldkv3_sw%s_%%=" % PHASE, ".Ldkv3_swb%s_%%=:" % PHASE,
+           "s_add_u32 %s, %s, 3" % (S_TMP, S_SLOT), "s_and_b32 %s, %s, 3" % (S_TMP, S_TMP), "s_lshl_b32 %s, %s, 14" % (S_DSTQ, S_TMP),
            "s_lshl_b32 %s, %%34, 10" % S_TMP2, "s_add_u32 %s, %s, %s" % (S_DSTQ, S_DSTQ, S_TMP2), "s_lshl_b32 %s, %s, 8" % (S_DSTS, S_TMP),
            "s_add_u32 %s, %s, %d" % (S_DSTS, S_DSTS, LSE_LDS),
-           "s_bfe_u32 s97, %[ctl], 0x10008", "s_cmp_eq_u32 %s, 1" % S_DMALEFT, "s_cselect_b32 %s, s97, 0" % S_USEALT, "s_min_u32 %s, %s, 1" % (S_ISSUED, S_DMALEFT),
+           "s_and_b32 %s, %s, 0xff" % (S_ISSUED, S_DMALEFT), "s_min_u32 %s, %s, 1" % (S_ISSUED, S_ISSUED),
+           "s_and_b32 %s, %s, 0x100ff" % (S_USEALT, S_DMALEFT), "s_bfe_u32 s97, %[ctl], 0x10008", "s_cmp_eq_u32 %s, 1" % S_USEALT, "s_cselect_b32 %s, s97, 0" % S_USEALT,
            "s_mov_b64 %s, %s" % (sp(QORG), sp(QP)), "s_mov_b64 %s, %s" % (sp(DORG), sp(DP))]
     k = 0
     for which, ptr, org, voff, piece, base, alt0, safe in (("q", QP, QORG, "%27", "%37", 0, 43, "%55"), ("do", DP, DORG, "%28", "%38", DO_LDS, 47, "%56")):
@@ -194,6 +201,12 @@ def dma_groups():
         ool += [".Ldkv3_a%d%s_%%=:" % (k, PHASE), "global_load_lds_dword %%51, %s" % sp(ptr), "s_branch .Ldkv3_j%d%s_%%=" % (k, PHASE)]
         groups.append(g)
         k += 1
+    ool += [".Ldkv3_sw%s_%%=:" % PHASE, "s_bitcmp1_b32 %s, 16" % S_DMALEFT, "s_cbranch_scc1 .Ldkv3_swb%s_%%=" % PHASE,      # already switched: dummies from here on
+            "s_lshr_b32 %s, %s, 8" % (S_DMALEFT, S_DMALEFT), "s_or_b32 %s, %s, 0x10000" % (S_DMALEFT, S_DMALEFT),
+            "s_and_b32 s97, %s, 0xff" % S_DMALEFT, "s_cmp_eq_u32 s97, 0", "s_cbranch_scc1 .Ldkv3_swb%s_%%=" % PHASE]            # no next item to serve
+    for k, ptr in enumerate((QP, DP, LP, NP)):
+        ool += ["v_readfirstlane_b32 s%d, %%[n%s_lo]" % (ptr[0], ("q", "do", "lse", "nd")[k]), "v_readfirstlane_b32 s%d, %%[n%s_hi]" % (ptr[1], ("q", "do", "lse", "nd")[k])]
+    ool += ["s_nop 3", "s_branch .Ldkv3_swb%s_%%=" % PHASE]
     return groups, ool
 
 
@@ -252,7 +265,7 @@ def build_body():
         gaps[64 - LOOKAHEAD + n] += a_loads(M[n]["a"], n % 8)
     for k, grp in enumerate(dma):
         gaps[DMA_GAPS[k]] += [Ins(t, "raw") for t in grp]
-    gaps[DMA_GAPS[-1]] += [Ins(t, "raw") for t in ("s_sub_u32 %s, %s, 1" % (S_DMALEFT, S_DMALEFT), "s_max_i32 %s, %s, 0" % (S_DMALEFT, S_DMALEFT))]
+    gaps[DMA_GAPS[-1]] += [Ins(t, "raw") for t in ("s_and_b32 s97, %s, 0xff" % S_DMALEFT, "s_min_u32 s97, s97, 1", "s_sub_u32 %s, %s, s97" % (S_DMALEFT, S_DMALEFT))]
     return M, gaps, ool
 
 
@@ -387,25 +400,6 @@ def main():
         lines += [count, "s_cmp_eq_u32 %s, 0" % S_CNT, "s_cbranch_scc1 .Ldkv3_skip%s_%%=" % phase, ".Ldkv3_loop%s_%%=:" % phase]
         lines += body
         lines += ["s_sub_u32 %s, %s, 1" % (S_CNT, S_CNT), "s_cmp_lg_u32 %s, 0" % S_CNT, "s_cbranch_scc1 .Ldkv3_loop%s_%%=" % phase, ".Ldkv3_skip%s_%%=:" % phase]
-    # ---- tail (%62 != 0: the key block is done and the workgroup's NEXT item is known): behind a barrier - every wave has read its last
-    #      tile - request the next item's first (<= 3) tiles + statistics rows into slots 0..2 (%59.. its Q / dO rows, its
-    #      lse2 / -delta rows; whole tiles only, the caller does not ask otherwise), and leave without waiting: they land while the caller
-    #      stores this block's dK / dV and fetches the next K / V fragments; the next call (first call, nothing to request) waits for them.
-    tail = [CTL_TAIL, "s_cmp_eq_u32 s97, 0", "s_cbranch_scc1 .Ldkv3_notail_%=", "s_waitcnt lgkmcnt(0)", "s_barrier",
-            "s_lshl_b32 %s, %%34, 10" % S_TMP2]
-    for k, ptr in enumerate((QP, DP, LP, NP)):      # (scalar operands are scarce - the compiler silently hands out a vector register when they run out - so these come in vector registers)
-        tail += ["v_readfirstlane_b32 s%d, %%[n%s_lo]" % (ptr[0], ("q", "do", "lse", "nd")[k]), "v_readfirstlane_b32 s%d, %%[n%s_hi]" % (ptr[1], ("q", "do", "lse", "nd")[k])]
-    for i in range(3):
-        tail += ["s_cmp_le_u32 s97, %d" % i, "s_cbranch_scc1 .Ldkv3_notail_%="]
-        for ptr, voff, piece, base in ((QP, "%27", "%37", 0), (DP, "%28", "%38", DO_LDS)):
-            for k in range(4):
-                tail += ["s_add_u32 m0, %s, %d" % (S_TMP2, (i << 14) + base + 4096 * k), "s_nop 0", "global_load_lds_dwordx4 %s, %s" % (voff, sp(ptr)),
-                         "s_add_u32 s%d, s%d, %s" % (ptr[0], ptr[0], piece), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])]
-        for ptr, extra in ((LP, 0), (NP, ND_DELTA)):
-            tail += ["s_mov_b32 m0, %d" % (LSE_LDS + (i << 8) + extra), "s_nop 0", "global_load_lds_dword v%d, %s" % (LANE4, sp(ptr)),
-                     "s_add_u32 s%d, s%d, 256" % (ptr[0], ptr[0]), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])]
-    tail += [".Ldkv3_notail_%=:"]
-    lines += tail
     lines += ["s_branch .Ldkv3_end_%="] + ool_a + ool_b + ool_c + [".Ldkv3_end_%=:", "s_waitcnt lgkmcnt(0)", "s_mov_b32 m0, %s" % S_M0SAVE]
     names = {24: "rowrel", 25: "colrel", 26: "statrel", 27: "voff_q", 28: "voff_do", 30: "sc", 32: "ndma", 34: "wave", 37: "q_piece", 38: "do_piece", 41: "lo0", 42: "range",
              51: "alt_stat", 55: "safe_q", 56: "safe_do", 57: "safe_l"}

@@ -340,11 +340,12 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
     const bf16_t* qp0 = p.q;
     const bf16_t* dop0 = p.d_o;
 
-    bool prefetched = false;      // cur's first tiles were requested by the previous item's asm block
+    bool prefetched = false;      // cur's first tiles were requested by the previous item's asm block (its last three steps) ...
+    int ring_base = 0;            // ... into the ring slots ring_base, ring_base + 1, ...
 
 #ifdef HALVA_STAMP
 #define DKV3_NOW(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory")
-    unsigned long long acc_pre_ = 0, acc_asm_ = 0, acc_post_ = 0, n_items_ = 0, t0_, t1_, t2_, t3_, tk_ = 0, ts_ = 0, acc_k_ = 0, acc_s_ = 0;
+    unsigned long long acc_pre_ = 0, acc_asm_ = 0, acc_post_ = 0, n_items_ = 0, t0_, t1_, t2_, t3_, tk_ = 0, ts_ = 0, acc_k_ = 0, acc_s_ = 0, tp_ = 0, tst_ = 0, tb_ = 0, acc_p_ = 0, acc_st_ = 0, acc_b_ = 0;
 #endif
 #pragma unroll 1
     for (int round = 0; cur.valid; ++round) {
@@ -429,6 +430,9 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
             // thread 0: the item after next (the counter's answer came out of the previous item's asm block) goes, with its sequence, into the slot
             // `cur` was read from
             if (threadIdx.x == 0) post(round & 1, look_up(resolve(drawn)));
+#ifdef HALVA_STAMP
+            DKV3_NOW(tp_);
+#endif
             int* home_counter = p.sched + 32 * home;
             int drawn_out;      // the next answer of the home queue's counter: asked for by the block's first call (see gen_dkv3_loop.py)
             int t = 0;
@@ -452,6 +456,7 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
                 store_rows_T<D>(dv_row, accV, k_valid ? 1.f : 0.f, true, lane);
                 store_rows_T<D>(dk_row, accK, k_valid ? p.scale : 0.f, true, lane);
             }
+            ring_base = (ring_base + ntiles) & 3;      // (the next item's prefetched tiles continue the slot rotation)
         } else {
             if (threadIdx.x == 0) {
                 post(round & 1, look_up(resolve(drawn)));
@@ -466,21 +471,28 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
                 store_rows_zero<D>(dv_row, lane);
             }
         }
+#ifdef HALVA_STAMP
+        DKV3_NOW(tst_);
+#endif
         // the mail box is LDS: wait for the LDS write only.  (__syncthreads() also waits for every vector-memory operation in flight - the
         // acknowledgements of the rows just stored, the next item's tiles - which is exactly what this loop is arranged not to wait for.)
         // Also: every wave is done with this item's LDS before a cold first call of the next one requests into it.
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef HALVA_STAMP
+        DKV3_NOW(tb_);
+#endif
         cur = nxt;
         prefetched = requested_next;
         collect(round & 1, nxt);
 #ifdef HALVA_STAMP
         DKV3_NOW(t3_);
         acc_pre_ += t1_ - t0_, acc_asm_ += t2_ - t1_, acc_post_ += t3_ - t2_, ++n_items_;
-        if (tk_ > t0_) acc_k_ += tk_ - t0_, acc_s_ += ts_ - tk_;
+        if (tk_ > t0_) acc_k_ += tk_ - t0_, acc_s_ += ts_ - tk_, acc_p_ += tp_ - ts_, acc_st_ += tst_ - t2_, acc_b_ += tb_ - tst_;
 #endif
     }
 #ifdef HALVA_STAMP
     if (p.dbg && threadIdx.x == 0 && blockIdx.x < 120)
+        p.dbg[7300 + blockIdx.x * 3] = acc_p_, p.dbg[7300 + blockIdx.x * 3 + 1] = acc_st_, p.dbg[7300 + blockIdx.x * 3 + 2] = acc_b_,
         p.dbg[7000 + blockIdx.x * 2] = acc_k_, p.dbg[7000 + blockIdx.x * 2 + 1] = acc_s_, p.dbg[6144 + blockIdx.x * 4] = acc_pre_, p.dbg[6144 + blockIdx.x * 4 + 1] = acc_asm_, p.dbg[6144 + blockIdx.x * 4 + 2] = acc_post_, p.dbg[6144 + blockIdx.x * 4 + 3] = n_items_;
 #endif
 }

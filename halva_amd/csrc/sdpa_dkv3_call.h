@@ -35,15 +35,16 @@
             const unsigned long long do_ptr = (unsigned long long)(size_t)(dop + (qrow0 + q_begin + (int64_t)tq * BQ) * p.ld_do);
             const unsigned long long lse_ptr = (unsigned long long)(size_t)(lse2_g + q_begin + tq * BQ);
             const unsigned long long nd_ptr = (unsigned long long)(size_t)(nd_g + q_begin + tq * BQ);
-            const unsigned tail_n = t_side == ntiles ? (unsigned)npro_next : 0u;
-            // the call's control word: first call of the block | tiles it requests itself | which of those is the partial last tile | the next item's tiles
+            // the call's control word: first call of the block | tiles it requests itself | which of those is the partial last tile
             // | the run's last request is the partial last tile | ring slot of the first step's tile   (gen_dkv3_loop.py: CTL_*)
             const unsigned ctl_u = dkv3_uni((t == 0 ? 1u : 0u) | ((cold ? (unsigned)min(3, ntiles) : 0u) << 1) |
-                                            (((cur.last_partial && ntiles <= 3) ? (unsigned)(ntiles - 1) : 7u) << 3) | (tail_n << 6) | ((part ? 1u : 0u) << 8) |
-                                            ((unsigned)(t & 3) << 9));
+                                            (((cur.last_partial && ntiles <= 3) ? (unsigned)(ntiles - 1) : 7u) << 3) | ((part ? 1u : 0u) << 8) |
+                                            ((unsigned)((ring_base + t) & 3) << 9));
             const unsigned n02_u = dkv3_uni((unsigned)n0 | ((unsigned)n2 << 16)), n1_u = dkv3_uni((unsigned)n1);      // (the launcher keeps T < 2^22)
-            const unsigned ndma_u = dkv3_uni((unsigned)ndma);
-            requested_next = requested_next || tail_n != 0;
+            // the next item's first tiles ride on this call's last three steps (which have no tile of their own left to ask for) - when it has three
+            const unsigned pf = (t_side == ntiles && n - ndma == 3) ? (unsigned)npro_next : 0u;
+            requested_next = requested_next || pf != 0;
+            const unsigned ndma_u = dkv3_uni((unsigned)ndma | (pf << 8));
             // always-valid sources for the requests of the steps with no tile left (they land in the dummy chunk): the tensors' first 16 rows
             // (the launcher requires S * T >= 16) and this pair's first statistics row (the lse2 region is padded by a row)
             const unsigned long long safe_q = dkv3_uni64(qp), safe_do = dkv3_uni64(dop);

@@ -27,6 +27,9 @@ print("workgroups 0..%d: items %d..%d; per item: before the asm %.0f cycles, in 
 ks = a[7000:7000 + 240].reshape(120, 2)[:len(pb)]
 print("   of the cycles before the asm: round top -> K / V fetch issued %.0f, -> address arithmetic done %.0f, -> scheduler's part done (asm entered) %.0f" % (
     ks[:, 0].sum() / n, ks[:, 1].sum() / n, (pb[:, 0].sum() - ks.sum()) / n))
+ex = a[7300:7300 + 360].reshape(120, 3)[:len(pb)]
+print("   scheduler's part (resolve, look-up, post) %.0f, then run lengths / addresses up to the asm %.0f;  behind the asm: -> rows stored %.0f, -> barrier passed %.0f, -> next geometry collected %.0f" % (
+    ex[:, 0].sum() / n, (pb[:, 0].sum() - ks.sum() - ex[:, 0].sum()) / n, ex[:, 1].sum() / n, ex[:, 2].sum() / n, (pb[:, 2].sum() - ex[:, 1].sum() - ex[:, 2].sum()) / n))
 for x in range(8):
     g = pb[x::8]
     print("   XCD %d: items per workgroup %.1f, cycles per item %.0f + %.0f + %.0f" % (x, g[:, 3].mean(), g[:, 0].sum() / g[:, 3].sum(), g[:, 1].sum() / g[:, 3].sum(), g[:, 2].sum() / g[:, 3].sum()))
