@@ -256,7 +256,7 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
     auto queue_len = [&](int x) { return x < G ? ((G - x + 7) >> 3) * nkb : 0; };
     // floor(n / d) for 0 <= n < 2^23 (the launcher checks), d >= 1: one multiplication by the reciprocal and one correction step
     auto fdiv = [](int n, int d) {
-        int q = (int)((float)n * __frcp_rn((float)d));
+        int q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));      // (1 ulp: the quotient is off by one at most)
         const int r = n - q * d;
         return r < 0 ? q - 1 : (r >= d ? q + 1 : q);
     };
@@ -294,7 +294,12 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
     };
     // the item's sequence, by SCALAR loads: they return through lgkmcnt; as vector loads the compiler would wait for them with vmcnt(0) (it
     // knows nothing of what the asm blocks have in flight), i.e. for everything
+    Posting seen{0, -1, 0, 0, 0, 0, 0, 0};      // thread 0: the last sequence looked up (a workgroup's consecutive items mostly share it)
     auto look_up = [&](Posting w) {      // thread 0 only
+        if (w.s == seen.s) {
+            w.start = seen.start, w.len = seen.len, w.a = seen.a, w.b = seen.b;
+            return w;
+        }
         const int sq = (int)dkv3_uni((unsigned)w.s);
         w.start = 0, w.len = p.T, w.a = 0x7fffffff, w.b = 0x7fffffff;
         if (p.seq_start && p.seq_len && p.br_a && p.br_b) {      // (the packed launch of the training step: four loads, one wait)
@@ -311,6 +316,7 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
             };
             w.start = sload(p.seq_start, 0), w.len = sload(p.seq_len, p.T), w.a = sload(p.br_a, 0x7fffffff), w.b = sload(p.br_b, 0x7fffffff);
         }
+        seen = w;
         return w;
     };
     auto post = [&](int slot, const Posting& w) {
