@@ -117,8 +117,11 @@ int halva_sdpa_branch_bwd(const void* qkv, const void* out, int64_t ld_out, cons
  * ds_ws == NULL: identical to halva_sdpa_branch_bwd.  The workspace holds no state between calls.
  * Since round 3 the workspace also carries, behind the dS region, [S, H, T] f32 of lse * log2(e) (+ one padding row) that the delta pass
  * writes for the dK/dV kernel, and delta_ws then receives -delta: the dK/dV kernel of this path (sdpa_bwd_dkv3, one wave per SIMD, its
- * interior steps one generated inline-asm loop - halva_amd/csrc/sdpa_dkv3.h) fetches both as plain rows by LDS-DMA and starts its dP chain
- * from -delta.  HALVA_SDPA_DKV3=0 selects the two-role kernel of rounds 1-2 instead (same results up to bf16 rounding of P before dZ). */
+ * steps in generated inline-asm blocks - halva_amd/csrc/sdpa_dkv3.h) fetches both as plain rows by LDS-DMA and starts its dP chain
+ * from -delta; and 1 KiB of work-queue counters (zeroed by the delta pass of each call): that kernel runs as one persistent workgroup per
+ * CU drawing (sequence, head, key block) items from a queue per XCD.  The workspace still holds no state between calls, but one workspace
+ * serves ONE call at a time.  HALVA_SDPA_DKV3=0 selects the two-role kernel of rounds 1-2 instead (same results up to bf16 rounding of P
+ * before dZ). */
 int64_t halva_sdpa_bwd_ws_bytes(int S, int T, int H, int D);
 int halva_sdpa_branch_bwd_ws(const void* qkv, const void* out, int64_t ld_out, const void* dout, int64_t ld_dout, const float* lse,
                              void* dqkv, float* delta_ws, void* ds_ws, int64_t ds_ws_bytes, const int32_t* seq_start,

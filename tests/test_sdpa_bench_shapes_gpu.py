@@ -127,3 +127,15 @@ def test_dkv3_work_queues_are_a_permutation_of_the_static_launch(case):
         else: assert torch.equal(g, ref), "order " + order
     old = _bwd_bits(S, T, H, D, lens, starts, br, 5, {"HALVA_SDPA_DKV3": "0"})
     assert rel_err(ref.float().cpu(), old.float().cpu()) < 5e-3
+
+
+def test_dkv3_plain_hip_twin_matches_the_generated_loop():
+    """HALVA_DKV3_ASM=0 runs sdpa_bwd_dkv3 with every step in plain HIP (sdpa_dkv3.h: dkv3_hip_step) - the readable statement of what the
+    generated asm blocks compute, same ring protocol, same masks.  The two must agree to the last bit on a packed, ragged launch (the
+    arithmetic is the same sequence of MFMAs and fp32 operations; only who schedules it differs)."""
+    D, S, T, H = 128, 2, 1216, 8
+    lens, starts, br = [1216, 1100], [0, 0], ([300, 290], [768, 704])
+    asm = _bwd_bits(S, T, H, D, lens, starts, br, 9, {"HALVA_DKV3_ASM": "1"})
+    hip = _bwd_bits(S, T, H, D, lens, starts, br, 9, {"HALVA_DKV3_ASM": "0"})
+    assert torch.isfinite(asm).all()
+    assert torch.equal(asm, hip)
