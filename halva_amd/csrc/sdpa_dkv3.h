@@ -7,15 +7,19 @@
 // 4 waves = 128 keys, a wave owns 32 keys with BOTH accumulators (dK^T, dV^T: 128 accumulator registers), the K and V fragments (64) and
 // runs all four products of a step itself, alone on its SIMD with the whole 512-register file.  hipcc cannot schedule that (every MFMA
 // destination lands in the accumulator file and each score is copied out before the vector unit may touch it: 3 650 cycles per step), so
-// the INTERIOR steps of a key block - whole tile, every key of the block visible to every row, no padding, no branch edge: all but the
-// two diagonal steps and the sequence tail - run in one generated inline-asm loop (sdpa_dkv3_loop.inc <- gen_dkv3_loop.py; 2 419 cycles
-// per step in isolation, bit-identical to the plain code: experiments/dkv3).  The boundary steps run the plain HIP step below, which
-// carries the masks.  Both keep the same protocol on a ring of FOUR Q / dO tile slots (+ their lse2 / -delta rows):
+// EVERY step of a key block runs inside generated inline-asm (sdpa_dkv3_loop.inc <- gen_dkv3_loop.py, included through sdpa_dkv3_call.h):
+// a masked phase (the diagonal steps), the interior phase (whole tile, every key visible to every row: 2 419 cycles per step in
+// isolation, bit-identical to the plain code - experiments/dkv3), a masked phase (sequence tail / branch edge).  The plain-HIP twin of
+// the step (dkv3_hip_step, HALVA_DKV3_ASM=0) states the same arithmetic readably and is held to the asm bit for bit by a test.
+// Both keep the same protocol on a ring of FOUR Q / dO tile slots (+ their lse2 / -delta rows):
 //     at the start of step t tile t has landed and is visible to every wave; tiles t+1, t+2 have been requested;
 //     at the head of step t tile t+3 is requested into the slot tile t-1 left at the last barrier; the step ends with "tile t+1 has landed" + s_barrier.
 // Statistics: the delta pass writes -delta and lse2 = lse * log2(e) (SdpaParams::lse2, the tail of the workspace), so that both are plain
 // rows an LDS-DMA dword request can fetch and -delta is directly the initial accumulator of the dP chain.
 // dS leaves in the same image sdpa_bwd_dkv2 writes (strip = wave), so sdpa_bwd_dq2 is unchanged.
+// The kernel is launched as persistent workgroups (one per CU) that draw (sequence, head, key block) items from a work queue per XCD
+// and pipeline across items: sdpa_bwd_dkv3_items below.  What must hold for that pipelining - no compiler instruction touches the K / V
+// fragment registers, no scratch - is checked on the compiled kernel by tools/check_dkv3_isa.py (tests/test_cabi_symbols.py).
 
 constexpr int DKV3_TILE = 64 * 128 * 2;                      // one Q or dO tile
 constexpr int DKV3_DO = 4 * DKV3_TILE;                       // dO ring behind the Q ring
@@ -24,8 +28,6 @@ constexpr int DKV3_ND = DKV3_LSE + 4 * 64 * 4;
 constexpr int DKV3_DUMMY = DKV3_ND + 4 * 64 * 4;              // 1 KiB: where the requests of the last steps of a block (no tile left) land
 constexpr int DKV3_SCHED = DKV3_DUMMY + 1024;                // [2][8] ints: the persistent workgroup's item mail box
 constexpr int DKV3_LDS = DKV3_SCHED + 64;
-
-#define DKV3_PIN_A(x) asm volatile("" : "+a"(x))
 
 __device__ __forceinline__ unsigned dkv3_uni(unsigned x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ unsigned long long dkv3_uni64(const void* ptr) {
