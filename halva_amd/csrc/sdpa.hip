@@ -324,6 +324,33 @@ __device__ __forceinline__ void map_block(int L, int nblk, int H, int npairs, bo
     s = pair / H;
 }
 
+// Which two 256-row blocks of a (sequence, head) pair a workgroup takes under the causal mask.  Plain causal: block b needs b + 1 units of
+// key tiles, so b goes with nblk-1-b and every workgroup does nblk + 1 units.  A packed sequence [prefix | A | pad | B] breaks that: the blocks
+// wholly inside B (first row >= br.b) do not visit the tiles inside [br.a, br.b), so their work is (b + 1) - hid with hid = (br.b - br.a) / 256 units -
+// for the bench's row [668 | 1380 | 1380] the old pairing gave six workgroups of 37-39 units and one of 60 per pair, and the launch waited for
+// the sixties.  Here the blocks are RANKED by that work (two increasing runs merged in closed form) and pair k takes the k-th heaviest and the
+// k-th lightest (43 units at most in the example).  Without a branch the ranks are the block numbers: the old pairing.
+__device__ __forceinline__ int block_rank(int qb, int n1, int n2, int hid) {      // n1 blocks below br.b, n2 inside B
+    if (qb < n1) return qb + min(max(qb - n1 + hid, 0), n2);
+    const int j = qb - n1;
+    return j + min(max(n1 + j - hid + 1, 0), n1);
+}
+__device__ __forceinline__ void paired_blocks(int nblk, int start, const Branch& br, int k, int& heavy, int& light) {
+    int n1 = nblk, hid = 0;
+    if (br.b != 0x7fffffff && br.b > br.a) {
+        n1 = min(nblk, (br.b + start + 255) / 256);      // first block whose first row is >= br.b (local rows: row - start)
+        hid = (br.b - br.a + 128) / 256;
+    }
+    const int n2 = nblk - n1, want_h = nblk - 1 - k, want_l = k;
+    heavy = nblk - 1 - k, light = k;
+    if (n2 == 0 || hid == 0) return;
+    for (int qb = 0; qb < nblk; ++qb) {
+        const int r = block_rank(qb, n1, n2, hid);
+        if (r == want_h) heavy = qb;
+        if (r == want_l) light = qb;
+    }
+}
+
 // ===================================================================================================
 // forward
 // ===================================================================================================
@@ -777,7 +804,9 @@ __global__ __launch_bounds__(512) void sdpa_fwd_kernel(const SdpaParams p) {
     s16x8 qf[D / 16];
     WG_CLOCK_BEGIN();
     if (CAUSAL) {
-        const int first = p.nblk - 1 - b, second = (b != first) ? b : -1;
+        int first, second;
+        paired_blocks(p.nblk, start, br, b, first, second);
+        if (second == first) second = -1;
         sdpa_fwd_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, first, second, false, true, qf, start, len, br);
         if (second >= 0) sdpa_fwd_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, second, -1, true, false, qf, start, len, br);
     } else {
@@ -1556,10 +1585,12 @@ __global__ __launch_bounds__(512) void sdpa_bwd_dq2_kernel(const SdpaParams p) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int s, hd, b;
     map_block(blockIdx.x, (p.nblk + 1) / 2, p.H, p.npairs, false, s, hd, b);
-    const int npass = (b != p.nblk - 1 - b) ? 2 : 1;
+    int heavy, light;      // (the same pairing as the forward: the blocks' work is the same count of key tiles)
+    paired_blocks(p.nblk, p.seq_start ? p.seq_start[s] : 0, load_branch(p, s), b, heavy, light);
+    const int npass = (heavy != light) ? 2 : 1;
     WG_CLOCK_BEGIN();
 #pragma unroll 1
-    for (int pass = 0; pass < npass; ++pass) sdpa_bwd_dq2_block<D, SLOW_TR>(p, smem, s, hd, pass ? b : p.nblk - 1 - b, wave, lane);
+    for (int pass = 0; pass < npass; ++pass) sdpa_bwd_dq2_block<D, SLOW_TR>(p, smem, s, hd, pass ? light : heavy, wave, lane);
     WG_CLOCK_END(p.dbg, 2);
 }
 
