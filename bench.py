@@ -236,6 +236,27 @@ def visible_pairs(T, br_a=None, br_b=None, seq_len=None):
     return n1 * (n1 + 1) // 2 + lb * br_a + lb * (lb + 1) // 2
 
 
+def in_step_forward(probe, layout):
+    """The same for the forward launches of the timed steps (policy rows, reference rows, recomputation): 4 D x visible pairs x H FLOPs
+    per sequence over the summed launch time."""
+    flop = ms = 0.0
+    kinds = {}
+    for e0, e1, S, T, H, D, branched in probe:
+        if branched and layout is not None and layout[0] == T and len(layout[1]) == S:
+            pairs = sum(visible_pairs(T, a, b, n) for a, b, n in zip(*layout[1:]))
+        else:
+            pairs = S * visible_pairs(T)
+        t = e0.elapsed_time(e1)
+        flop += 4.0 * D * pairs * H
+        ms += t
+        k = kinds.setdefault("%dx%d%s" % (S, T, " packed" if branched else ""), [0, 0.0])
+        k[0] += 1
+        k[1] += t
+    return {"achieved": round(flop / ms / 1e9, 2), "frac": round(flop / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "launch_ms": round(ms / len(probe), 3),
+            "launches": len(probe), "measured": "HIP events around every sdpa_causal_fwd launch of the timed steps: " +
+            ", ".join("%s: %d launches avg %.3f ms" % (k, v[0], v[1] / v[0]) for k, v in kinds.items())}
+
+
 def in_step_roofline(probe, layout, micro):
     """The SDPA-backward launches of the TIMED steps themselves (events recorded by kernels._SdpaCausal.backward on the launch
     stream): algorithmic FLOPs = 2.5 x 4 D x visible pairs x H per sequence, over the summed launch time.  `micro` (the same
@@ -530,6 +551,7 @@ def main():
                                                                    " <- ".join(str(f).split("/")[-1] for f in e.stack[:5])), file=sys.stderr)
     from halva_amd import kernels as HK
     HK.sdpa_bwd_probe = [] if not args.no_roofline else None      # HIP events around every SDPA-backward launch of the timed steps
+    HK.sdpa_fwd_probe = [] if not args.no_roofline else None      # ... and every forward launch
     del comm_probe[:]
     trace = ClockTrace(dev, os.environ["HALVA_BENCH_CLOCK_TRACE"]) if (os.environ.get("HALVA_BENCH_CLOCK_TRACE") and ctx.rank == 0) else None
     dp.barrier(ctx)
@@ -544,6 +566,7 @@ def main():
     dt = time.perf_counter() - t0
     clock = trace.stop() if trace is not None else None
     probe, HK.sdpa_bwd_probe = HK.sdpa_bwd_probe, None
+    fprobe, HK.sdpa_fwd_probe = HK.sdpa_fwd_probe, None
     dt = dp.max_scalar(dt, ctx)
     loss_val = float(last)
     pairs_per_s = ctx.world * B * args.steps / dt
@@ -553,6 +576,8 @@ def main():
     roof = None if args.no_roofline else sdpa_roofline(dev)
     if roof is not None and probe:
         roof = in_step_roofline(probe, eng.last_layout, roof)
+        if fprobe:      # (roofline.fwd stays the micro-benchmark at the plain per-layer shape; this is the step's own mix of launches)
+            roof["fwd_in_step"] = in_step_forward(fprobe, eng.last_layout)
     cpu = None
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()

@@ -155,6 +155,7 @@ class _RopeQK(torch.autograd.Function):
 
 
 sdpa_bwd_probe = None      # a list: every causal-SDPA backward launch appends (start event, end event, S, T, H, D, branched)
+sdpa_fwd_probe = None      # the same for the forward launches (bench.py)
 # dS workspace of the attention backward (include/halva_hip.h:halva_sdpa_branch_bwd_ws): one buffer per device, grown on demand and
 # reused by every layer (it carries nothing between calls).  HALVA_SDPA_DS_WS=0 runs the split backward without it.
 SDPA_DS_WS = os.environ.get("HALVA_SDPA_DS_WS", "1") != "0"
@@ -188,8 +189,15 @@ class _SdpaCausal(torch.autograd.Function):
         out = torch.empty(S, T, width, dtype=torch.bfloat16, device=qkv.device)
         lse = torch.empty(S, H, T, dtype=torch.float32, device=qkv.device)
         br_a, br_b, pos = branch if branch is not None else (None, None, None)
+        probe = sdpa_fwd_probe
+        if probe is not None:          # bench.py: HIP events around the launch, on the stream it goes to
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         call("halva_sdpa_branch_fwd", ptr(qkv), ptr(out), width, ptr(lse), ptr(seq_start), ptr(seq_len), ptr(br_a), ptr(br_b), S, T, H,
              D, 0.0, stream_ptr())
+        if probe is not None:
+            e1.record()
+            probe.append((e0, e1, S, T, H, D, branch is not None))
         ctx.branch = branch
         ctx.save_for_backward(qkv, lse, seq_start, seq_len)
         # `out` may be the (wider) operand buffer of the next LoRA projection, which fills its right columns in place; the
