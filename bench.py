@@ -524,6 +524,30 @@ def main():
                       % ("this rank" if oom else "another rank", args.pairs_per_group), file=sys.stderr)
             continue
         done += 1
+    if os.environ.get("HALVA_BENCH_COPY_TRACE"):      # diagnostic: which .contiguous() / .reshape() calls of a step really copy (strided source)
+        import collections, traceback
+        seen = collections.Counter()
+        orig_c, orig_r = torch.Tensor.contiguous, torch.Tensor.reshape
+        def where():
+            for f in reversed(traceback.extract_stack()[:-2]):
+                if "/torch/" not in f.filename and "bench.py" not in f.filename:
+                    return "%s:%d" % (os.path.basename(f.filename), f.lineno)
+            return "?"
+        def c(t, *a, **k):
+            if t.is_cuda and not t.is_contiguous():
+                seen[("contiguous", tuple(t.shape), tuple(t.stride()), str(t.dtype), where())] += 1
+            return orig_c(t, *a, **k)
+        def r(t, *a, **k):
+            o = orig_r(t, *a, **k)
+            if t.is_cuda and o.data_ptr() != t.data_ptr() and t.numel() > 0:
+                seen[("reshape", tuple(t.shape), tuple(t.stride()), str(t.dtype), where())] += 1
+            return o
+        torch.Tensor.contiguous, torch.Tensor.reshape = c, r
+        step()
+        torch.cuda.synchronize()
+        torch.Tensor.contiguous, torch.Tensor.reshape = orig_c, orig_r
+        for k, n in seen.most_common(40):
+            print("%5d x %s" % (n, k), file=sys.stderr)
     if os.environ.get("HALVA_BENCH_TORCH_PROFILE"):      # diagnostic: where do the non-GEMM, non-HIP kernels of a step come from
         from torch.profiler import profile, ProfilerActivity
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
@@ -544,9 +568,25 @@ def main():
             for k, v in sorted(ks.items(), key=lambda kv: -kv[1][0])[:40]:
                 print("%9.2f ms %5.2f%% %6d  %s" % (v[0] / 1e3, 100 * v[0] / tot, v[1], k), file=sys.stderr)
             print("total device time of the step %.1f ms" % (tot / 1e3), file=sys.stderr)
-        rows = [e for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=5) if e.key in small]
+        if os.environ["HALVA_BENCH_TORCH_PROFILE"].startswith("owner:"):      # which ops launch the kernels whose name contains <pattern>
+            pat = os.environ["HALVA_BENCH_TORCH_PROFILE"][6:]
+            own = {}
+            for ev in prof.events():
+                for k in getattr(ev, "kernels", []):
+                    if pat in k.name:
+                        par, chain = ev, []
+                        while par is not None and len(chain) < 4:
+                            chain.append(par.name)
+                            par = par.cpu_parent
+                        t = own.setdefault((" <- ".join(chain), str(ev.input_shapes)[:120]), [0.0, 0])
+                        t[0] += k.duration
+                        t[1] += 1
+            for k, v in sorted(own.items(), key=lambda kv: -kv[1][0])[:30]:
+                print("%8.2f ms %5d  %s  %s" % (v[0] / 1e3, v[1], k[0], k[1]), file=sys.stderr)
+        everything = os.environ["HALVA_BENCH_TORCH_PROFILE"] == "all"      # every op, not only the small ones
+        rows = [e for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=5) if everything or e.key in small]
         rows.sort(key=lambda e: -e.self_device_time_total)
-        for e in rows[:60]:
+        for e in rows[:(400 if everything else 60)]:
             print("%-14s %8.2f ms %5d calls  shapes %s\n      %s" % (e.key, e.self_device_time_total / 1e3, e.count, str(e.input_shapes)[:110],
                                                                    " <- ".join(str(f).split("/")[-1] for f in e.stack[:5])), file=sys.stderr)
     from halva_amd import kernels as HK

@@ -336,6 +336,49 @@ extern "C" int halva_gelu_bwd(const void* dy, const void* h, void* dh, int64_t M
     return HALVA_OK;
 }
 
+// dst[c][r] = src[r][c] for a [rows x cols] bf16 matrix with row strides ld_src / ld_dst (elements): 64 x 64 tiles through LDS (33-word rows:
+// the transposed reads of a wave fall on different banks), 16-byte global loads and stores on both sides.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, int64_t ld_src, bf16_t* __restrict__ dst, int64_t ld_dst,
+                                                             int rows, int cols) {
+    __shared__ unsigned tile[64][33];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, v = threadIdx.x & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (threadIdx.x >> 3) + 32 * i, gr = r0 + r, gc = c0 + 8 * v;
+        u32x4 x = {0u, 0u, 0u, 0u};
+        if (gr < rows && gc < cols) x = *reinterpret_cast<const u32x4*>(src + (int64_t)gr * ld_src + gc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[r][4 * v + j] = x[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = (threadIdx.x >> 3) + 32 * i, gc = c0 + c, gr = r0 + 8 * v;
+        if (gc < cols && gr < rows) {
+            u32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned a = tile[8 * v + 2 * j][c >> 1], b = tile[8 * v + 2 * j + 1][c >> 1];
+                o[j] = (c & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+            }
+            *reinterpret_cast<u32x4*>(dst + (int64_t)gc * ld_dst + gr) = o;
+        }
+    }
+}
+
+extern "C" int halva_transpose_bf16(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int rows, int cols, void* stream) {
+    HALVA_CHECK_ARG(src && dst, "transpose_bf16: null pointer");
+    HALVA_CHECK_ARG(rows >= 0 && cols >= 0 && rows % 8 == 0 && cols % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && ld_src >= cols && ld_dst >= rows,
+                    "transpose_bf16: rows, cols and both row strides must be multiples of 8 (16-byte accesses); got %d x %d, strides %lld / %lld", rows,
+                    cols, (long long)ld_src, (long long)ld_dst);
+    HALVA_CHECK_ARG(((size_t)src | (size_t)dst) % 16 == 0, "transpose_bf16: 16-byte aligned pointers");
+    if (rows == 0 || cols == 0) return HALVA_OK;
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src,
+                       (bf16_t*)dst, ld_dst, rows, cols);
+    HALVA_CHECK_LAUNCH("transpose_bf16");
+    return HALVA_OK;
+}
+
 extern "C" int halva_colsum(const void* x, float* out, int64_t M, int N, void* stream) {
     HALVA_CHECK_ARG(x && out, "colsum: null pointer");
     if (M <= 0 || N <= 0) return HALVA_OK;

@@ -297,7 +297,10 @@ class LoraGroup(nn.Module):
                 # a read-modify-write pass over [rows, in] per group and backward (~56 ms per step).  fp32 accumulate, ONE rounding
                 # to bf16 - dx differs from the two-GEMM form by bf16 noise; dA, dB are formed from the same operands as before.
                 G = len(self.names)
-                torch.addmm(self.weight_cat[:, :K].t(), self.A_cat.data.t(), self.weight_cat_t[K:K + G * r], out=self.weight_cat_t[:K])
+                # (W^T by the tiled transpose kernel, then the product accumulated in place: torch.addmm(W.t(), ..., out=) copied the strided
+                # W^T into `out` with the framework's element-wise copy first - 0.45 ms per group, 30 ms per step over the model)
+                K_.transpose_into(self.weight_cat_t[:K], self.weight_cat[:, :K])
+                self.weight_cat_t[:K].addmm_(self.A_cat.data.t(), self.weight_cat_t[K:K + G * r])
         self._tail_versions = tuple(B._version for B in self._Bs()) + (self.A_cat._version,)
 
     def lora_state(self):

@@ -162,6 +162,11 @@ int halva_vit_patch_embed(const void* images, const void* weight_kp, const void*
 /* dh[M,N] = dy[M,N] * gelu'(h[M,N]) (h = pre-activation), and column sums for the bias grads. */
 int halva_gelu_bwd(const void* dy, const void* h, void* dh, int64_t M, int N, void* stream);
 int halva_colsum(const void* x, float* out, int64_t M, int N, void* stream);
+/* dst[c][r] = src[r][c], bf16, [rows x cols] with row strides ld_src / ld_dst in elements (rows, cols, strides multiples of 8; 16-byte
+ * aligned pointers).  Serves the once-per-optimizer-step refresh of the transposed, LoRA-merged weight copy the decoder's dgrad GEMMs read
+ * (halva_amd/llama.py:LoraGroup.refresh_tail; the reference has no counterpart - peft keeps W, A, B apart and autograd forms dx from each):
+ * `torch.addmm(W.t(), ...)` spent 0.45 ms per group copying the strided W^T with the framework's element-wise copy kernel. */
+int halva_transpose_bf16(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int rows, int cols, void* stream);
 
 /* ---- vision-side row kernels (VILA path).
  * LayerNorm over rows of [rows, d] bf16 (d % 8 == 0, d <= 8192): the nn.LayerNorm of mlp_downsample

@@ -574,3 +574,16 @@ def test_clip_tower_features_match_reference():
     w = torch.from_numpy(z["projected"])
     assert y.shape == tuple(w.shape)
     assert float((y.float().cpu() - w).norm() / w.norm()) < 1e-2
+
+
+@pytest.mark.parametrize("rows,cols,ld_src,ld_dst", [(64, 64, 64, 64), (72, 200, 328, 80), (4096, 12288, 12288 + 384, 4096), (8, 8, 8, 8)])
+def test_transpose_bf16_matches_torch(rows, cols, ld_src, ld_dst):
+    """halva_transpose_bf16 (the refresh of the transposed, LoRA-merged weight copy: llama.py LoraGroup.refresh_tail): exact, for strided
+    sources / destinations and partial tiles; what lies outside the [cols x rows] destination window is not touched."""
+    g = torch.Generator().manual_seed(rows + cols)
+    src = bf(torch.randn(rows, ld_src, generator=g)).to(DEV)
+    dst = torch.full((cols, ld_dst), 7.0, dtype=torch.bfloat16, device=DEV)
+    K().transpose_into(dst[:, :rows], src[:, :cols])
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:, :rows], src[:, :cols].t())
+    assert bool((dst[:, rows:] == 7.0).all())
