@@ -329,16 +329,17 @@ __device__ __forceinline__ void map_block(int L, int nblk, int H, int npairs, bo
 // wholly inside B (first row >= br.b) do not visit the tiles inside [br.a, br.b), so their work is (b + 1) - hid with hid = (br.b - br.a) / 256 units -
 // for the bench's row [668 | 1380 | 1380] the old pairing gave six workgroups of 37-39 units and one of 60 per pair, and the launch waited for
 // the sixties.  Here the blocks are RANKED by that work (two increasing runs merged in closed form) and pair k takes the k-th heaviest and the
-// k-th lightest (43 units at most in the example).  Without a branch the ranks are the block numbers: the old pairing.
-__device__ __forceinline__ int block_rank(int qb, int n1, int n2, int hid) {      // n1 blocks below br.b, n2 inside B
+// k-th lightest (44 units at most in the example).  Without a branch the ranks are the block numbers: the old pairing.
+__host__ __device__ __forceinline__ int block_rank(int qb, int n1, int n2, int hid) {      // n1 blocks below br.b, n2 inside B
     if (qb < n1) return qb + min(max(qb - n1 + hid, 0), n2);
     const int j = qb - n1;
     return j + min(max(n1 + j - hid + 1, 0), n1);
 }
-__device__ __forceinline__ void paired_blocks(int nblk, int start, const Branch& br, int k, int& heavy, int& light) {
+__host__ __device__ __forceinline__ void paired_blocks(int nblk, int start, const Branch& br, int k, int& heavy, int& light) {
     int n1 = nblk, hid = 0;
     if (br.b != 0x7fffffff && br.b > br.a) {
-        n1 = min(nblk, (br.b + start + 255) / 256);      // first block whose first row is >= br.b (local rows: row - start)
+        n1 = (br.b + start + 255) / 256;      // first block whose first row is >= br.b (local rows: row - start)
+        n1 = n1 < nblk ? n1 : nblk;
         hid = (br.b - br.a + 128) / 256;
     }
     const int n2 = nblk - n1, want_h = nblk - 1 - k, want_l = k;
@@ -1727,6 +1728,17 @@ int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int halva_sdpa_block_pairs(int nblk, int start, int br_a, int br_b, int32_t* out) {
+    HALVA_CHECK_ARG(nblk > 0 && out, "sdpa_block_pairs: bad arguments");
+    const Branch br{br_a, br_b};
+    for (int k = 0; k < (nblk + 1) / 2; ++k) {
+        int heavy, light;
+        paired_blocks(nblk, start, br, k, heavy, light);
+        out[2 * k] = heavy, out[2 * k + 1] = light;
+    }
+    return HALVA_OK;
+}
 
 extern "C" int halva_sdpa_causal_fwd(const void* qkv, void* out, float* lse, const int32_t* seq_start, const int32_t* seq_len,
                                      int S, int T, int H, int D, float scale, void* stream) {

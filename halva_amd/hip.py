@@ -54,6 +54,7 @@ SIGNATURES = {
     "halva_phrase_sum_bwd": [_P, _P, _P, _P, _I, _P, _I, _I, _P],
     "halva_probe_layouts": [_P, _I, _P],
     "halva_clock_probe": [_P, _I, _I, _P],
+    "halva_sdpa_block_pairs": [_I, _I, _I, _I, _P],
 }
 
 _lib = None

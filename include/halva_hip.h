@@ -243,6 +243,11 @@ int halva_probe_layouts(int32_t* out, int n, void* stream);
  * the constant 100 MHz counter and report out[4 b + {0,1,2,3}] = {shader cycles elapsed (s_memtime), 100 MHz ticks elapsed (s_memrealtime),
  * start tick, XCC id}: shader MHz = 100 * out[4b] / out[4b+1], the clock the chip holds while the step's kernels run beside the probe. */
 int halva_clock_probe(uint64_t* out, int blocks, int spin_ticks, void* stream);
+/* Host-side mirror (same inline function the kernels call) of how the forward and the dQ kernel pair the 256-row blocks of a sequence under
+ * the causal mask: out[2k], out[2k+1] = the heavier and the lighter block of workgroup k, k < (nblk + 1) / 2 (equal for the middle block of
+ * an odd count).  br_a / br_b as in halva_sdpa_branch_fwd (0x7fffffff for both: plain causal, i.e. nblk-1-k with k).  No GPU work: for
+ * tests of the index arithmetic. */
+int halva_sdpa_block_pairs(int nblk, int start, int br_a, int br_b, int32_t* out);
 
 #ifdef __cplusplus
 }
