@@ -1,3 +1,5 @@
+"""Per-shape averages of the SDPA kernels from the kernel trace of tools/bench_sdpa_branch.py (three shapes x 11 calls, the first of each dropped):
+    bash tools/prof_sdpa_branch.sh <tag>; python tools/sdpa_shape_times.py gpurun_out/prof_sdpab_<tag>/p_kernel_trace.csv"""
 import csv, sys, collections
 rows=list(csv.DictReader(open(sys.argv[1])))
 per=collections.defaultdict(list)
