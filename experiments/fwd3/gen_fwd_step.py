@@ -16,7 +16,9 @@ products of tile t (software pipelining over the step loop), so that the vector 
 Same machinery as experiments/dkv3/gen_step_asm.py: 8-slot A-operand ring filled LOOKAHEAD MFMAs ahead, <= CAP issue units of vector work per
 MFMA gap (a transcendental counts 2), every s_waitcnt lgkmcnt(N) from a simulation of the LDS queue over two iterations, hazard checks.
 Operands: %0-%3 / %4-%7 O^T accumulators of group 0 / 1 ("+a"), %8-%11 outputs: l and the running maximum of group 0, of group 1 ("=v"),
-%12-%19 / %20-%27 Q fragments ("a"), %28 row-read, %29 transposed-read lane offsets ("v"), %30 scale*log2(e), %31 iterations ("s")."""
+%12-%19 / %20-%27 Q fragments ("a"), %28 row-read, %29 transposed-read lane offsets ("v"), %30 scale*log2(e), %31 iterations ("s");
+fwd_step_dma_asm.inc (tiles streamed through the ring by LDS-DMA) also: %32 / %33 lane offsets of a wave's K / V tile pieces ("v"), %34 wave,
+%35 bytes between a wave's pieces (16 rows) ("s"), %36-%39 first K / V tile rows of the wave's first piece (low / high words, "v")."""
 import sys
 
 LOOKAHEAD, CAP = 6, 5
@@ -107,15 +109,38 @@ def addr_update(which):
                 Ins("v_add_u32_e32 v%d, %s, %%29" % (VC0, S_TOFFV), "valu", writes=["v%d" % VC0], cost=1),
                 Ins("v_add_u32_e32 v%d, %d, v%d" % (VC0, V_LDS, VC0), "valu", reads=["v%d" % VC0], writes=["v%d" % VC0], cost=1),
                 Ins("v_xor_b32_e32 v%d, 32, v%d" % (VC1, VC0), "valu", reads=["v%d" % VC0], writes=["v%d" % VC1], cost=1)]
-    return [Ins("s_add_u32 %s, %s, 1" % (S_T, S_T), "salu"), Ins("s_and_b32 %s, %s, %d" % (S_TMP, S_T, NTILE - 1), "salu"), Ins("s_lshl_b32 %s, %s, 14" % (S_TOFFK, S_TMP), "salu"),
+    return [Ins("s_add_u32 %s, %s, 1" % (S_T, S_T), "salu"), Ins("s_and_b32 %s, %s, %d" % (S_TMP, S_T, NTILE - 1), "salu"), Ins("s_lshl_b32 %s, %s, 14" % (S_TOFFK, S_TMP), "salu"),      # (S_T = tile of the next S chains)
             Ins("v_add_u32_e32 v%d, %s, %%28" % (KRE, S_TOFFK), "valu", writes=["v%d" % KRE], cost=1),
             Ins("v_xor_b32_e32 v%d, 32, v%d" % (KRO, KRE), "valu", reads=["v%d" % KRE], writes=["v%d" % KRO], cost=1)]
+
+
+DMA = False                   # fwd_step_dma_asm.inc: K / V tiles streamed from global memory through the ring of four LDS slots
+S_SLOT, S_M0SAVE, S_DST = "s95", "s96", "s97"
+KP, VP = (98, 99), (100, 101)      # next tile to request (this wave's first piece)
+
+
+def dma_groups():
+    """Iteration t runs O(t-1) on V tile t-1 and S(t) on K tile t.  At its head it requests tile t+2 (K and V: 4 + 4 one-KiB pieces per wave) into
+    the slot tile t-2 left at the last barrier (its V half was read by iteration t-1); the K half is needed two iterations later."""
+    pre = ["s_add_u32 %s, %s, 2" % (S_DST, S_SLOT), "s_and_b32 %s, %s, 3" % (S_DST, S_DST), "s_lshl_b32 %s, %s, 14" % (S_DST, S_DST),
+           "s_lshl_b32 %s, %%34, 10" % S_TMP, "s_add_u32 %s, %s, %s" % (S_DST, S_DST, S_TMP)]
+    groups = []
+    for ptr, base, voff in ((KP, K_LDS, "%32"), (VP, V_LDS, "%33")):
+        for i in range(4):
+            groups.append((pre if not groups else []) + ["s_add_u32 m0, %s, %d" % (S_DST, base + 4096 * i), "s_nop 0", "global_load_lds_dwordx4 %s, s[%d:%d]" % (voff, ptr[0], ptr[1]),
+                                                         "s_add_u32 s%d, s%d, %%35" % (ptr[0], ptr[0]), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])])
+    return groups
 
 
 def build_body():
     M = mfma_list()
     gaps = [[] for _ in range(64)]
     used = [0] * 64
+    if DMA:
+        for k, grp in enumerate(dma_groups()):
+            gaps[k] += [Ins(t, "raw") for t in grp]
+        # tile t+1 (its K half is read from gap 10 of the next iteration on) has landed for every wave: only tile t+2's 8 requests may stay in flight
+        gaps[57] += [Ins(t, "raw") for t in ("s_waitcnt vmcnt(8)", "s_barrier", "s_add_u32 %s, %s, 1" % (S_SLOT, S_SLOT), "s_and_b32 %s, %s, 3" % (S_SLOT, S_SLOT))]
     # A operands: pair m = MFMAs 2m, 2m+1; its read(s) go out in gap 2m - LOOKAHEAD (of the previous iteration for the first pairs)
     for m in range(32):
         g = (2 * m - LOOKAHEAD) % 64
@@ -194,6 +219,12 @@ def check(seq):
 
 
 def main():
+    global DMA
+    for DMA in (False, True):
+        emit()
+
+
+def emit():
     M, gaps, used = build_body()
     seq = linearize(M, gaps)
     check(seq + seq)
@@ -205,7 +236,17 @@ def main():
     lines1, fifo1 = insert_waits(seq, carried)
     lines2, fifo2 = insert_waits(seq, fifo1)
     assert lines1 == lines2, "loop is not in steady state"
-    pro = ["s_mov_b32 %s, 0" % S_T, "s_mov_b32 %s, 0" % S_TOFFK, "s_mov_b32 %s, 0" % S_TOFFV, "s_mov_b32 %s, %%31" % S_CNT,
+    pro = []
+    if DMA:      # tiles 0, 1 up front (the caller has filled nothing), then everything has to land; the loop's first requests are for tile 2
+        pro += ["s_mov_b32 %s, m0" % S_M0SAVE, "s_mov_b32 %s, 0" % S_SLOT, "v_readfirstlane_b32 s%d, %%36" % KP[0], "v_readfirstlane_b32 s%d, %%37" % KP[1],
+                "v_readfirstlane_b32 s%d, %%38" % VP[0], "v_readfirstlane_b32 s%d, %%39" % VP[1], "s_lshl_b32 %s, %%34, 10" % S_TMP, "s_nop 3"]
+        for i in range(2):
+            for ptr, base, voff in ((KP, K_LDS, "%32"), (VP, V_LDS, "%33")):
+                for k in range(4):
+                    pro += ["s_add_u32 m0, %s, %d" % (S_TMP, (i << 14) + base + 4096 * k), "s_nop 0", "global_load_lds_dwordx4 %s, s[%d:%d]" % (voff, ptr[0], ptr[1]),
+                            "s_add_u32 s%d, s%d, %%35" % (ptr[0], ptr[0]), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])]
+        pro += ["s_waitcnt vmcnt(0)", "s_barrier"]
+    pro += ["s_mov_b32 %s, 0" % S_T, "s_mov_b32 %s, 0" % S_TOFFK, "s_mov_b32 %s, 0" % S_TOFFV, "s_mov_b32 %s, %%31" % S_CNT,
            "v_add_u32_e32 v%d, %s, %%28" % (KRE, S_TOFFK), "v_xor_b32_e32 v%d, 32, v%d" % (KRO, KRE),
            "v_add_u32_e32 v%d, %d, %%29" % (VC0, V_LDS), "v_xor_b32_e32 v%d, 32, v%d" % (VC1, VC0)]
     # P of "tile -1" is zero (the first O products add nothing); the score tiles of key half 1 start at -inf (their vector work runs first)
@@ -218,11 +259,13 @@ def main():
         if 2 * m - LOOKAHEAD < 0:
             pro += [l.text for l in a_loads(M[2 * m]["a"], m % 8)]
     body = ["1:"] + lines1 + ["s_sub_u32 %s, %s, 1" % (S_CNT, S_CNT), "s_cmp_lg_u32 %s, 0" % S_CNT, "s_cbranch_scc1 1b", "s_waitcnt lgkmcnt(0)"]
+    if DMA:
+        body += ["s_waitcnt vmcnt(0)", "s_mov_b32 m0, %s" % S_M0SAVE]
     epi = []
     for g in (0, 1):
         epi += ["v_pk_add_f32 %s, %s, %s" % (vr(L2[g], 2), vr(L2[g], 2), vr(L2[g] + 2, 2)), "v_add_f32_e32 %%%d, v%d, v%d" % (8 + 2 * g, L2[g], L2[g] + 1),
                 "v_mov_b32_e32 %%%d, v%d" % (9 + 2 * g, MX[g])]
-    out = sys.argv[1] if len(sys.argv) > 1 else "fwd_step_asm.inc"
+    out = "fwd_step_dma_asm.inc" if DMA else "fwd_step_asm.inc"
     with open(out, "w") as f:
         f.write("// generated by gen_fwd_step.py - do not edit\n")
         for l in pro + body + epi:
@@ -231,7 +274,7 @@ def main():
     nl = sum(1 for s in seq if s.kind == "lds")
     print("step: 64 MFMAs, %d vector (%d issue units), %d LDS reads, %d lines; busiest gap %d units" % (nv, sum(used), nl, len(lines1), max(used)))
     with open(out.replace(".inc", "_clobbers.inc"), "w") as f:
-        f.write(", ".join('"v%d"' % i for i in range(64, 212)) + ', "s90", "s91", "s92", "s93", "s94", "scc", "memory"\n')
+        f.write(", ".join('"v%d"' % i for i in range(64, 212)) + ', "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101", "scc", "memory"\n')
 
 
 if __name__ == "__main__":

@@ -5,6 +5,8 @@
 // Question: how many cycles per 64-key step does a hand-placed stream take (matrix work: 64 MFMAs = 2 048 cycles), against the ~5 100 cycles
 // per 64 MFMAs and SIMD of the shipped sdpa_causal_fwd (two 32-row waves per SIMD)?
 //   MODE 0: plain HIP, one tile after the other          MODE 2: the loop as one generated asm block (gen_fwd_step.py)
+//   MODE 3: MODE 2 with the K / V tiles streamed from global memory by LDS-DMA through the ring of four slots (8 requests per wave and
+//           step, one counted vmcnt + s_barrier per step), every workgroup its own run of tiles
 // build: python3 gen_fwd_step.py && hipcc -O3 --offload-arch=gfx950 -Wno-unused-value -o step_bench step_bench.hip ; run: ./step_bench [nsteps] [nwg]
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -104,7 +106,8 @@ __device__ __forceinline__ void step_plain(State& st, const char* kt, const char
 
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void step_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, float* out,
-                                                                                              float* stats, unsigned long long* cycles, int nsteps, float sc) {
+                                                                                              float* stats, unsigned long long* cycles, int nsteps, float sc,
+                                                                                              const bf16_t* kstream, const bf16_t* vstream, int stream_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_lds = smem;
     char* v_lds = smem + NTILE * TILE_BYTES;
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    if (MODE == 2) {
+    if (MODE == 2 || MODE == 3) {
         const int r = lane & 31;
         const int rowrel = 2048 * (r >> 3) + 64 * (r & 7) + 16 * (h ^ ((r >> 2) & 3));
         const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3, h2 = g16 >> 1;
@@ -144,6 +147,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) q0[ks] = __builtin_bit_cast(u32x4, st.qf[0][ks]), q1[ks] = __builtin_bit_cast(u32x4, st.qf[1][ks]);
         const int iters = nsteps + 1;
+        if (MODE == 3) {
+            // lane offset of this lane's 16 bytes of the wave's chunk (1 KiB of the tile image: TileDma for four waves); the wave's pieces lie 16 rows apart
+            const int o = 1024 * wave + 16 * lane, band = o / 2048, rem = o % 2048, row = 8 * band + ((rem % 512) >> 6);
+            const int ch = 4 * (rem / 512) + (((rem >> 4) & 3) ^ ((row >> 2) & 3));
+            const unsigned voff = (unsigned)((row * D + ch * 8) * 2);
+            const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave), piece = 16 * D * 2;
+            const unsigned long long kp = (unsigned long long)(size_t)(kstream + (size_t)blockIdx.x * stream_tiles * 64 * D);
+            const unsigned long long vp = (unsigned long long)(size_t)(vstream + (size_t)blockIdx.x * stream_tiles * 64 * D);
+            asm volatile(
+#include "fwd_step_dma_asm.inc"
+                : "+a"(st.acc[0][0]), "+a"(st.acc[0][1]), "+a"(st.acc[0][2]), "+a"(st.acc[0][3]), "+a"(st.acc[1][0]), "+a"(st.acc[1][1]), "+a"(st.acc[1][2]), "+a"(st.acc[1][3]),
+                  "=v"(st.l[0]), "=v"(st.mx[0]), "=v"(st.l[1]), "=v"(st.mx[1])
+                : "a"(q0[0]), "a"(q0[1]), "a"(q0[2]), "a"(q0[3]), "a"(q0[4]), "a"(q0[5]), "a"(q0[6]), "a"(q0[7]),
+                  "a"(q1[0]), "a"(q1[1]), "a"(q1[2]), "a"(q1[3]), "a"(q1[4]), "a"(q1[5]), "a"(q1[6]), "a"(q1[7]),
+                  "v"(rowrel), "v"(colrel), "s"(sc), "s"(iters), "v"(voff), "v"(voff), "s"(wave_u), "s"(piece),
+                  "v"((unsigned)kp), "v"((unsigned)(kp >> 32)), "v"((unsigned)vp), "v"((unsigned)(vp >> 32))
+                :
+#include "fwd_step_dma_asm_clobbers.inc"
+            );
+        } else
         asm volatile(
 #include "fwd_step_asm.inc"
             : "+a"(st.acc[0][0]), "+a"(st.acc[0][1]), "+a"(st.acc[0][2]), "+a"(st.acc[0][3]), "+a"(st.acc[1][0]), "+a"(st.acc[1][1]), "+a"(st.acc[1][2]), "+a"(st.acc[1][3]),
@@ -173,6 +196,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     so[lane] = st.l[0], so[64 + lane] = st.mx[0], so[128 + lane] = st.l[1], so[192 + lane] = st.mx[1];
 }
 
+__global__ void fill_stream(const bf16_t* k, const bf16_t* v, bf16_t* ks, bf16_t* vs, int stream_tiles) {
+    const size_t dst = (size_t)blockIdx.x * 64 * D, src = (size_t)((blockIdx.x % stream_tiles) & 3) * 64 * D;
+    for (int i = threadIdx.x; i < 64 * D / 8; i += 256) {
+        reinterpret_cast<u32x4*>(ks + dst)[i] = reinterpret_cast<const u32x4*>(k + src)[i];
+        reinterpret_cast<u32x4*>(vs + dst)[i] = reinterpret_cast<const u32x4*>(v + src)[i];
+    }
+}
+
 static bf16_t f2bf(float f) {
     unsigned u; memcpy(&u, &f, 4);
     u += 0x7fff + ((u >> 16) & 1);
@@ -195,16 +226,25 @@ int main(int argc, char** argv) {
     hipMalloc(&out0, outn * 4); hipMalloc(&out2, outn * 4); hipMalloc(&st0, stn * 4); hipMalloc(&st2, stn * 4); hipMalloc(&cyc, nwg * 4 * 8);
     hipMemcpy(q, hq.data(), hq.size() * 2, hipMemcpyHostToDevice); hipMemcpy(k, hk.data(), hk.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(v, hv.data(), hv.size() * 2, hipMemcpyHostToDevice);
+    // MODE 3 streams its tiles from global memory: per workgroup a run of nsteps + 4 tiles, tile t = base tile t & 3 (so that every mode computes the same)
+    const int stream_tiles = nsteps + 4;
+    bf16_t *ks, *vs;
+    hipMalloc(&ks, (size_t)nwg * stream_tiles * 64 * D * 2); hipMalloc(&vs, (size_t)nwg * stream_tiles * 64 * D * 2);
+    hipLaunchKernelGGL(fill_stream, dim3((unsigned)(nwg * stream_tiles)), dim3(256), 0, 0, k, v, ks, vs, stream_tiles);
+    hipDeviceSynchronize();
     const size_t lds = 2 * NTILE * TILE_BYTES;
     hipFuncSetAttribute((const void*)step_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)step_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    float *out3, *st3; hipMalloc(&out3, outn * 4); hipMalloc(&st3, stn * 4);
     std::vector<unsigned long long> hc(nwg * 4);
-    for (int mode = 0; mode < 3; mode += 2) {
+    for (int mode = 0; mode < 4; mode += (mode == 2 ? 1 : 2)) {
         for (int rep = 0; rep < 3; ++rep) {
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             hipEventRecord(e0);
-            if (mode == 0) hipLaunchKernelGGL(step_kernel<0>, dim3(nwg), dim3(256), lds, 0, q, k, v, out0, st0, cyc, nsteps, sc);
-            else hipLaunchKernelGGL(step_kernel<2>, dim3(nwg), dim3(256), lds, 0, q, k, v, out2, st2, cyc, nsteps, sc);
+            if (mode == 0) hipLaunchKernelGGL(step_kernel<0>, dim3(nwg), dim3(256), lds, 0, q, k, v, out0, st0, cyc, nsteps, sc, ks, vs, stream_tiles);
+            else if (mode == 2) hipLaunchKernelGGL(step_kernel<2>, dim3(nwg), dim3(256), lds, 0, q, k, v, out2, st2, cyc, nsteps, sc, ks, vs, stream_tiles);
+            else hipLaunchKernelGGL(step_kernel<3>, dim3(nwg), dim3(256), lds, 0, q, k, v, out3, st3, cyc, nsteps, sc, ks, vs, stream_tiles);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             hipMemcpy(hc.data(), cyc, hc.size() * 8, hipMemcpyDeviceToHost);
@@ -220,6 +260,13 @@ int main(int argc, char** argv) {
     size_t d2 = 0; double md = 0, mx = 0;
     for (size_t i = 0; i < outn; ++i) { if (memcmp(&h0[i], &h2[i], 4)) { ++d2; md = fmax(md, fabs(h0[i] - h2[i])); } mx = fmax(mx, fabs(h0[i])); }
     printf("mode 2 (asm) vs mode 0: %zu of %zu accumulator values differ bitwise (max |diff| %.3e, max |value| %.3e)\n", d2, outn, md, mx);
+    {
+        std::vector<float> h3(outn);
+        hipMemcpy(h3.data(), out3, outn * 4, hipMemcpyDeviceToHost);
+        size_t d3 = 0;
+        for (size_t i = 0; i < outn; ++i) if (memcmp(&h0[i], &h3[i], 4)) ++d3;
+        printf("mode 3 (asm, tiles streamed by LDS-DMA) vs mode 0: %zu of %zu accumulator values differ bitwise\n", d3, outn);
+    }
     double ml = 0, mm = 0;
     for (size_t i = 0; i < stn; ++i) { const double rel = fabs(s0[i] - s2[i]) / fmax(1e-30, fabs(s0[i])); if ((i / 64) % 2 == 0) ml = fmax(ml, rel); else mm = fmax(mm, fabs(s0[i] - s2[i])); }
     printf("l: max relative difference %.2e; running maximum: max difference %.2e\n", ml, mm);
