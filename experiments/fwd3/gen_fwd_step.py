@@ -21,7 +21,7 @@ fwd_step_dma_asm.inc (tiles streamed through the ring by LDS-DMA) also: %32 / %3
 %35 bytes between a wave's pieces (16 rows) ("s"), %36-%39 first K / V tile rows of the wave's first piece (low / high words, "v")."""
 import sys
 
-LOOKAHEAD, CAP = 6, 5
+LOOKAHEAD, CAP, CAP_MASKED = 6, 5, 8
 XS = {(0, 0): 64, (0, 1): 80, (1, 0): 96, (1, 1): 112}      # score tiles [group][key half]: 16 registers each
 PB = {(0, 0): 128, (0, 1): 136, (1, 0): 144, (1, 1): 152}   # packed P: 8 registers each
 L2, MX, MREF = {0: 160, 1: 164}, {0: 168, 1: 169}, {0: 170, 1: 171}      # l: two pairs per group (alternating), running max, reference
@@ -91,7 +91,14 @@ def valu_ops(g, kh):
     Ls = lambda i: Ins("v_pk_add_f32 %s, %s, %s" % (vr(l2 + 2 * (i & 1), 2), vr(l2 + 2 * (i & 1), 2), vr(x + 2 * i, 2)), "valu",
                        reads=regs(l2 + 2 * (i & 1), 2) + regs(x + 2 * i, 2), writes=regs(l2 + 2 * (i & 1), 2), cost=1)
     Dp = lambda i: Ins("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (pb + i, x + 2 * i, x + 2 * i + 1), "valu", reads=regs(x + 2 * i, 2), writes=["v%d" % (pb + i)], cost=1)
-    o = [M3(i) for i in range(8)]
+    o = []
+    if MASKED:      # score register r of key half kh holds key 32 kh + (r & 3) + 8 (r >> 2) (+ 4 h, folded into RANGE): visible iff that is < RANGE
+        for r in range(16):
+            key = 32 * kh + (r & 3) + 8 * (r >> 2)
+            # (ONE unit: the pair shares VCC, and the two groups' vector work is interleaved gap by gap)
+            o += [Ins("v_cmp_lt_i32_e32 vcc, %d, v%d\\n\\tv_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (key, RANGE[g], x + r, V_NINF, x + r), "valu",
+                      reads=["v%d" % RANGE[g], "v%d" % (x + r), "v%d" % V_NINF], writes=["v%d" % (x + r)], cost=2)]
+    o += [M3(i) for i in range(8)]
     o += [A(0), A(1), A(2), A(3)]
     for r in range(12):
         o += [B(r), A(r + 4)]
@@ -115,6 +122,9 @@ def addr_update(which):
 
 
 DMA = False                   # fwd_step_dma_asm.inc: K / V tiles streamed from global memory through the ring of four LDS slots
+MASKED = False                # fwd_step_masked_asm.inc: every score tested against the lane's visible-key count (diagonal / tail / branch-edge tiles)
+RANGE = {0: 172, 1: 173}      # per group: keys of the CURRENT S tile this lane's query may see, minus 4 h (the lane half's row offset); -= 64 per step
+V_NINF = 174
 S_SLOT, S_M0SAVE, S_DST = "s95", "s96", "s97"
 KP, VP = (98, 99), (100, 101)      # next tile to request (this wave's first piece)
 
@@ -148,12 +158,15 @@ def build_body():
     # address updates: V after the last V read of the iteration (pair 23: MFMA 46, gap 40), K after the last K read (pair 31: gap 56)
     gaps[41] += addr_update("v"); used[41] += 3
     gaps[57] += addr_update("k"); used[57] += 2
+    if MASKED:      # the next S tile lies 64 keys further on
+        gaps[31] += [Ins("v_subrev_u32_e32 v%d, 64, v%d" % (RANGE[g], RANGE[g]), "valu", reads=["v%d" % RANGE[g]], writes=["v%d" % RANGE[g]], cost=1) for g in (0, 1)]
+        used[31] += 2
     # vector work: key half 0 (chains end at MFMA 30 / 31) in gaps 33..61; key half 1 (chains of the PREVIOUS iteration, end 62 / 63) in gaps 1..29
     for kh, first, last in ((1, 1, 30), (0, 33, 62)):
         for grp in (0, 1):
             g = first + grp      # (group 1's chain ends one MFMA later)
             for ins in valu_ops(grp, kh):
-                while used[g] + ins.cost > CAP:
+                while used[g] + ins.cost > (CAP_MASKED if MASKED else CAP):
                     g += 1
                 assert g <= last, "vector work of key half %d does not fit its window" % kh
                 gaps[g].append(ins)
@@ -219,8 +232,8 @@ def check(seq):
 
 
 def main():
-    global DMA
-    for DMA in (False, True):
+    global DMA, MASKED
+    for DMA, MASKED in ((False, False), (True, False), (False, True)):
         emit()
 
 
@@ -255,6 +268,8 @@ def emit():
     for g in (0, 1):
         pro += ["v_mov_b32_e32 v%d, 0xff800000" % (XS[(g, 1)] + r) for r in range(16)]
         pro += ["v_mov_b32_e32 v%d, 0" % (L2[g] + i) for i in range(4)] + ["v_mov_b32_e32 v%d, 0xff800000" % MX[g], "v_mov_b32_e32 v%d, 0" % MREF[g]]
+    if MASKED:
+        pro += ["v_mov_b32_e32 v%d, %%32" % RANGE[0], "v_mov_b32_e32 v%d, %%33" % RANGE[1], "v_mov_b32_e32 v%d, 0xff800000" % V_NINF]
     for m in range(32):
         if 2 * m - LOOKAHEAD < 0:
             pro += [l.text for l in a_loads(M[2 * m]["a"], m % 8)]
@@ -265,7 +280,7 @@ def emit():
     for g in (0, 1):
         epi += ["v_pk_add_f32 %s, %s, %s" % (vr(L2[g], 2), vr(L2[g], 2), vr(L2[g] + 2, 2)), "v_add_f32_e32 %%%d, v%d, v%d" % (8 + 2 * g, L2[g], L2[g] + 1),
                 "v_mov_b32_e32 %%%d, v%d" % (9 + 2 * g, MX[g])]
-    out = "fwd_step_dma_asm.inc" if DMA else "fwd_step_asm.inc"
+    out = "fwd_step_dma_asm.inc" if DMA else ("fwd_step_masked_asm.inc" if MASKED else "fwd_step_asm.inc")
     with open(out, "w") as f:
         f.write("// generated by gen_fwd_step.py - do not edit\n")
         for l in pro + body + epi:

@@ -5,6 +5,8 @@
 // Question: how many cycles per 64-key step does a hand-placed stream take (matrix work: 64 MFMAs = 2 048 cycles), against the ~5 100 cycles
 // per 64 MFMAs and SIMD of the shipped sdpa_causal_fwd (two 32-row waves per SIMD)?
 //   MODE 0: plain HIP, one tile after the other          MODE 2: the loop as one generated asm block (gen_fwd_step.py)
+//   MODE 1 / 4: MODE 0 / 2 with every score tested against the lane's visible-key count (causal diagonal at tile nsteps / 2: plain tiles,
+//           the diagonal tile and wholly hidden tiles all occur)
 //   MODE 3: MODE 2 with the K / V tiles streamed from global memory by LDS-DMA through the ring of four slots (8 requests per wave and
 //           step, one counted vmcnt + s_barrier per step), every workgroup its own run of tiles
 // build: python3 gen_fwd_step.py && hipcc -O3 --offload-arch=gfx950 -Wno-unused-value -o step_bench step_bench.hip ; run: ./step_bench [nsteps] [nwg]
@@ -74,8 +76,9 @@ struct State {
 };
 
 // one tile, plain order: for each query group the two key halves' scores, their softmax numerators, then the O products
-template <bool WITH_O>
-__device__ __forceinline__ void step_plain(State& st, const char* kt, const char* vt, float sc, int lane) {
+template <bool WITH_O, bool MASKED>
+__device__ __forceinline__ void step_plain(State& st, const char* kt, const char* vt, float sc, int lane, int vis0, int vis1) {
+    const int hh = lane >> 5;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         u32x4 pb[2][2];
@@ -86,6 +89,11 @@ __device__ __forceinline__ void step_plain(State& st, const char* kt, const char
             for (int r = 0; r < 16; ++r) x[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) x = mfma32(frag_rows(kt, 32 * kh, ks, lane), st.qf[g][ks], x);
+            if (MASKED) {      // key (32 kh + row of the register) of this tile is visible to the lane's query iff it is < vis
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (32 * kh + (r & 3) + 8 * (r >> 2) + 4 * hh >= (g ? vis1 : vis0)) x[r] = -INFINITY;
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 st.mx[g] = fmaxf(st.mx[g], fmaxf(x[2 * i], x[2 * i + 1]));
@@ -138,7 +146,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    if (MODE == 2 || MODE == 3) {
+    // masked modes: the lane's query 64 Td + 32 g + (lane & 31) sees the keys up to itself (causal), tile t holds the keys 64 t .. 64 t + 63
+    const int Td = nsteps / 2, v0 = 64 * Td + (lane & 31) + 1, v1 = v0 + 32;
+    if (MODE == 2 || MODE == 3 || MODE == 4) {
         const int r = lane & 31;
         const int rowrel = 2048 * (r >> 3) + 64 * (r & 7) + 16 * (h ^ ((r >> 2) & 3));
         const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3, h2 = g16 >> 1;
@@ -166,6 +176,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 :
 #include "fwd_step_dma_asm_clobbers.inc"
             );
+        } else if (MODE == 4) {
+            const int r0 = v0 + 64 - 4 * h, r1 = v1 + 64 - 4 * h;      // (the loop takes 64 off before the first tile; the lane half's row offset is folded in)
+            asm volatile(
+#include "fwd_step_masked_asm.inc"
+                : "+a"(st.acc[0][0]), "+a"(st.acc[0][1]), "+a"(st.acc[0][2]), "+a"(st.acc[0][3]), "+a"(st.acc[1][0]), "+a"(st.acc[1][1]), "+a"(st.acc[1][2]), "+a"(st.acc[1][3]),
+                  "=v"(st.l[0]), "=v"(st.mx[0]), "=v"(st.l[1]), "=v"(st.mx[1])
+                : "a"(q0[0]), "a"(q0[1]), "a"(q0[2]), "a"(q0[3]), "a"(q0[4]), "a"(q0[5]), "a"(q0[6]), "a"(q0[7]),
+                  "a"(q1[0]), "a"(q1[1]), "a"(q1[2]), "a"(q1[3]), "a"(q1[4]), "a"(q1[5]), "a"(q1[6]), "a"(q1[7]),
+                  "v"(rowrel), "v"(colrel), "s"(sc), "s"(iters), "v"(r0), "v"(r1)
+                :
+#include "fwd_step_masked_asm_clobbers.inc"
+            );
         } else
         asm volatile(
 #include "fwd_step_asm.inc"
@@ -179,8 +201,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         );
     } else {
 #pragma unroll 1
-        for (int t = 0; t < nsteps; ++t) step_plain<true>(st, k_lds + (t & (NTILE - 1)) * TILE_BYTES, v_lds + (t & (NTILE - 1)) * TILE_BYTES, sc, lane);
-        step_plain<false>(st, k_lds + (nsteps & (NTILE - 1)) * TILE_BYTES, v_lds, sc, lane);      // (the asm loop's last iteration scores one more tile)
+        for (int t = 0; t < nsteps; ++t)
+            step_plain<true, MODE == 1>(st, k_lds + (t & (NTILE - 1)) * TILE_BYTES, v_lds + (t & (NTILE - 1)) * TILE_BYTES, sc, lane, v0 - 64 * t, v1 - 64 * t);
+        step_plain<false, MODE == 1>(st, k_lds + (nsteps & (NTILE - 1)) * TILE_BYTES, v_lds, sc, lane, v0 - 64 * nsteps, v1 - 64 * nsteps);      // (the asm loop's last iteration scores one more tile)
     }
     asm volatile("" : "+v"(st.acc[0][0]), "+v"(st.acc[1][DT - 1]));
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -236,15 +259,20 @@ int main(int argc, char** argv) {
     hipFuncSetAttribute((const void*)step_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)step_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    float *out1, *out4, *st1, *st4; hipMalloc(&out1, outn * 4); hipMalloc(&out4, outn * 4); hipMalloc(&st1, stn * 4); hipMalloc(&st4, stn * 4);
     float *out3, *st3; hipMalloc(&out3, outn * 4); hipMalloc(&st3, stn * 4);
     std::vector<unsigned long long> hc(nwg * 4);
-    for (int mode = 0; mode < 4; mode += (mode == 2 ? 1 : 2)) {
+    for (int mode : {0, 2, 3, 1, 4}) {
         for (int rep = 0; rep < 3; ++rep) {
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             hipEventRecord(e0);
             if (mode == 0) hipLaunchKernelGGL(step_kernel<0>, dim3(nwg), dim3(256), lds, 0, q, k, v, out0, st0, cyc, nsteps, sc, ks, vs, stream_tiles);
             else if (mode == 2) hipLaunchKernelGGL(step_kernel<2>, dim3(nwg), dim3(256), lds, 0, q, k, v, out2, st2, cyc, nsteps, sc, ks, vs, stream_tiles);
-            else hipLaunchKernelGGL(step_kernel<3>, dim3(nwg), dim3(256), lds, 0, q, k, v, out3, st3, cyc, nsteps, sc, ks, vs, stream_tiles);
+            else if (mode == 3) hipLaunchKernelGGL(step_kernel<3>, dim3(nwg), dim3(256), lds, 0, q, k, v, out3, st3, cyc, nsteps, sc, ks, vs, stream_tiles);
+            else if (mode == 1) hipLaunchKernelGGL(step_kernel<1>, dim3(nwg), dim3(256), lds, 0, q, k, v, out1, st1, cyc, nsteps, sc, ks, vs, stream_tiles);
+            else hipLaunchKernelGGL(step_kernel<4>, dim3(nwg), dim3(256), lds, 0, q, k, v, out4, st4, cyc, nsteps, sc, ks, vs, stream_tiles);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             hipMemcpy(hc.data(), cyc, hc.size() * 8, hipMemcpyDeviceToHost);
@@ -266,6 +294,13 @@ int main(int argc, char** argv) {
         size_t d3 = 0;
         for (size_t i = 0; i < outn; ++i) if (memcmp(&h0[i], &h3[i], 4)) ++d3;
         printf("mode 3 (asm, tiles streamed by LDS-DMA) vs mode 0: %zu of %zu accumulator values differ bitwise\n", d3, outn);
+    }
+    {
+        std::vector<float> h1(outn), h4(outn);
+        hipMemcpy(h1.data(), out1, outn * 4, hipMemcpyDeviceToHost); hipMemcpy(h4.data(), out4, outn * 4, hipMemcpyDeviceToHost);
+        size_t d4 = 0, dm = 0;
+        for (size_t i = 0; i < outn; ++i) { if (memcmp(&h1[i], &h4[i], 4)) ++d4; if (memcmp(&h1[i], &h0[i], 4)) ++dm; }
+        printf("mode 4 (masked asm) vs mode 1 (masked HIP): %zu of %zu accumulator values differ bitwise (the masks change %zu values against mode 0)\n", d4, outn, dm);
     }
     double ml = 0, mm = 0;
     for (size_t i = 0; i < stn; ++i) { const double rel = fabs(s0[i] - s2[i]) / fmax(1e-30, fabs(s0[i])); if ((i / 64) % 2 == 0) ml = fmax(ml, rel); else mm = fmax(mm, fabs(s0[i] - s2[i])); }
