@@ -147,7 +147,7 @@ class CLIPVisionTower(nn.Module):
             x = x + F.linear(a, L.out_w, L.out_b)
             h = K.layernorm(x, L.ln2_w, L.ln2_b, eps)
             h = F.linear(h, L.fc1_w, L.fc1_b)
-            h = h * torch.sigmoid(1.702 * h)
+            h = K.quick_gelu_(h)                      # h * sigmoid(1.702 h), CLIPMLP's quick_gelu, in place
             x = x + F.linear(h, L.fc2_w, L.fc2_b)
         if self.select_feature == "patch":
             return x[:, 1:]

@@ -317,6 +317,29 @@ extern "C" int halva_swiglu_fwd_ld(const void* gu, void* out, int64_t ldo, int64
     return HALVA_OK;
 }
 
+// CLIP's quick_gelu, x * sigmoid(1.702 x), with the roundings of the three bf16 tensor ops it replaces (scale, sigmoid, product)
+__global__ __launch_bounds__(256) void quick_gelu_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[8];
+        unpack8(x[i], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = bf16_round(1.702f * v[j]);
+            v[j] = v[j] * bf16_round(1.f / (1.f + __expf(-t)));
+        }
+        out[i] = pack8(v);
+    }
+}
+
+extern "C" int halva_quick_gelu(const void* x, void* out, int64_t n, void* stream) {
+    HALVA_CHECK_ARG(x && out, "quick_gelu: null pointer");
+    HALVA_CHECK_ARG(n >= 0 && n % 8 == 0 && ((size_t)x | (size_t)out) % 16 == 0, "quick_gelu: n must be a multiple of 8 and the pointers 16-byte aligned");
+    if (n == 0) return HALVA_OK;
+    hipLaunchKernelGGL(quick_gelu_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, (u32x4*)out, n / 8);
+    HALVA_CHECK_LAUNCH("quick_gelu");
+    return HALVA_OK;
+}
+
 extern "C" int halva_swiglu_bwd(const void* dout, const void* gu, void* dgu, int64_t rows, int F, void* stream) {
     return halva_swiglu_bwd_ld(dout, F, gu, dgu, rows, F, stream);
 }

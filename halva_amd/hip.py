@@ -45,6 +45,7 @@ SIGNATURES = {
     "halva_image_preprocess": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "halva_gelu_bwd": [_P, _P, _P, _L, _I, _P],
     "halva_colsum": [_P, _P, _L, _I, _P],
+    "halva_quick_gelu": [_P, _P, _L, _P],
     "halva_transpose_bf16": [_P, _L, _P, _L, _I, _I, _P],
     "halva_splice_rows": [_P, _P, _P, _P, _L, _I, _P],
     "halva_token_logp_fwd": [_P, _I, _L, _P, _P, _P, _L, _I, _P],

@@ -650,6 +650,14 @@ def phrase_sum(logp, labels, signs, slot_ids):
     return _PhraseSum.apply(logp, labels, signs, slot_ids)
 
 
+def quick_gelu_(h):
+    """h <- h * sigmoid(1.702 h) in place (bf16, contiguous): CLIP's activation in one pass."""
+    _chk(h, torch.bfloat16, "h")
+    assert h.numel() % 8 == 0
+    call("halva_quick_gelu", ptr(h), ptr(h), h.numel(), stream_ptr())
+    return h
+
+
 def transpose_into(dst, src):
     """dst[c, r] = src[r, c] for 2-D bf16 tensors whose last dimension is contiguous (row strides free): the tiled transpose kernel
     instead of `dst.copy_(src.t())`, which runs the framework's element-wise strided copy (5x slower at weight-matrix sizes)."""

@@ -70,6 +70,11 @@ int halva_rmsnorm_bwd_res_ld(const void* dy, int64_t lddy, const void* x, const 
 int halva_rope_qk(void* qkv, const void* cos, const void* sin, const int32_t* pos, int64_t rows, int T, int H, int D,
                   int max_pos, int inverse, void* stream);
 
+/* ---- CLIP's activation.  replaces `input * torch.sigmoid(1.702 * input)` (transformers QuickGELUActivation, reached through
+ * llava/model/multimodal_encoder/clip_encoder.py:46 -> CLIPMLP) of the frozen tower: one pass instead of three element-wise kernels, with the
+ * same three bf16 roundings.  n elements (multiple of 8), out may be x. */
+int halva_quick_gelu(const void* x, void* out, int64_t n, void* stream);
+
 /* ---- SwiGLU.  replaces act_fn(gate_proj(x)) * up_proj(x) (modelling_llama.py:197).  gu = [rows, 2F] (gate | up). */
 int halva_swiglu_fwd(const void* gu, void* out, int64_t rows, int F, void* stream);
 int halva_swiglu_bwd(const void* dout, const void* gu, void* dgu, int64_t rows, int F, void* stream);

@@ -587,3 +587,18 @@ def test_transpose_bf16_matches_torch(rows, cols, ld_src, ld_dst):
     torch.cuda.synchronize()
     assert torch.equal(dst[:, :rows], src[:, :cols].t())
     assert bool((dst[:, rows:] == 7.0).all())
+
+
+def test_quick_gelu_matches_the_three_bf16_tensor_ops():
+    """halva_quick_gelu = `x * torch.sigmoid(1.702 * x)` in bf16 (transformers QuickGELUActivation of the CLIP tower) with the same three
+    roundings: equal to torch's result up to one bf16 ulp (the fast exponential), and within 1e-2 of the fp32 function."""
+    g = torch.Generator().manual_seed(4)
+    x = bf(4.0 * torch.randn(577 * 4096 // 8 * 8, generator=g)).to(DEV)
+    ref = x * torch.sigmoid(1.702 * x)
+    y = K().quick_gelu_(x.clone())
+    torch.cuda.synchronize()
+    d = (y.float() - ref.float()).abs()
+    assert float((d / ref.float().abs().clamp_min(1e-3)).max()) < 1.6e-2      # <= 2 bf16 ulp
+    assert float((d > 0).float().mean()) < 0.05
+    xf = x.float()
+    assert rel_err(y.float().cpu(), (xf * torch.sigmoid(1.702 * xf)).cpu()) < 1e-2
