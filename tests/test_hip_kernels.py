@@ -522,7 +522,7 @@ def test_splice_rows_against_golden():
 
 
 @pytest.mark.parametrize("rows,M,N,lda,ldb", [(1000, 128, 256, 640, 384), (3428, 512, 128, 1536, 4224), (77, 8, 8, 8, 8),
-                                                (27424, 384, 4096, 4480, 4480),
+                                                (27424, 384, 4096, 4480, 4480), (3000, 256, 4096, 4352, 4352), (1500, 320, 1032, 512, 1104),      # short M: one workgroup takes all of M
                                                 (2000, 128, 13824, 13952, 13952), (2000, 5120, 128, 15360, 5248)])      # 13B factor shapes
 def test_wgrad_accumulate_matches_fp32_reference(rows, M, N, lda, ldb):
     """C += alpha * A^T B over column windows of wider buffers (the LoRA weight gradients), accumulated into an f32 sink; two runs agree bitwise."""
