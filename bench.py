@@ -293,57 +293,118 @@ def in_step_roofline(probe, layout, micro):
     return out
 
 
-def cpu_baseline(budget_s=25.0):
-    """The oracle (CPU restatement of the reference's path, oracle/) timed on this box's host cores: ONE sequence of the
-    7B geometry at T = 2048 through a bounded number of decoder layers (fwd + bwd, LoRA r = 128, bf16) and the
-    lm_head + loss on its 1419 response rows; extrapolated to a pair as 3*(fwd+bwd) + 1*fwd over 32 layers."""
+def physical_cores():
+    """(threads to use, note): the CPUs this process may run on (sched_getaffinity) divided by the SMT width read from sysfs -
+    one thread per physical core; oversubscribing the SMT siblings (round 3: 256 threads) slowed the GEMMs several-fold."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    smt = 1
+    try:
+        with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % cpus[0]) as f:
+            txt = f.read().strip()
+        smt = 0
+        for part in txt.split(","):
+            lo, _, hi = part.partition("-")
+            smt += (int(hi) - int(lo) + 1) if hi else 1
+        smt = max(1, smt)
+    except Exception:
+        pass
+    n = max(1, len(cpus) // smt)
+    return n, "%d logical CPUs in the affinity mask / SMT width %d" % (len(cpus), smt)
+
+
+def _median_time(fn, reps=3):
+    fn()                       # warm-up: first-touch allocation, oneDNN primitive creation, thread pool start
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
+
+
+def cpu_baseline():
+    """The oracle (CPU restatement of the reference's path, oracle/) timed on this box's host cores, in fp32 AND bf16:
+    ONE sequence of the 7B geometry at T = 2048 through one decoder layer (fwd, and fwd + bwd, LoRA r = 128) and the lm_head +
+    loss on its 1419 response rows; warm-up call first, median of 3, one thread per physical core; extrapolated to a pair as
+    3 x (fwd+bwd) + 1 x fwd over 32 layers + 4 heads.  A plain F.linear of the same box is timed beside it so that the implied
+    GFLOP/s of the sample can be judged (`linear_gflops`)."""
     import torch.nn.functional as F
     from oracle import dpa as odpa
     from oracle import nets
-    cores = os.cpu_count() or 1
+    cores, how = physical_cores()
     torch.set_num_threads(cores)
     cfg = dict(LLAMA_7B)
     d, Fd, T, r, V = cfg["hidden_size"], cfg["intermediate_size"], 2048, 128, cfg["vocab_size"]
-    g = torch.Generator().manual_seed(0)
-    bf = torch.bfloat16
-    W, lora = {}, {}
-    p = "L."
-    for n, (o, i) in {"self_attn.q_proj": (d, d), "self_attn.k_proj": (d, d), "self_attn.v_proj": (d, d), "self_attn.o_proj": (d, d),
-                      "mlp.gate_proj": (Fd, d), "mlp.up_proj": (Fd, d), "mlp.down_proj": (d, Fd)}.items():
-        W[p + n + ".weight"] = (torch.randn(o, i, generator=g) * 0.02).to(bf)
-        lora[p + n + ".A"] = (torch.randn(r, i, generator=g) * 0.02).to(bf).requires_grad_(True)
-        lora[p + n + ".B"] = (torch.randn(o, r, generator=g) * 0.01).to(bf).requires_grad_(True)
-    W[p + "input_layernorm.weight"] = torch.ones(d, dtype=bf)
-    W[p + "post_attention_layernorm.weight"] = torch.ones(d, dtype=bf)
-    x = torch.randn(1, T, d, generator=g).to(bf).requires_grad_(True)
-    keep = torch.ones(1, T, dtype=torch.bool)
-    t0 = time.time()
-    with torch.no_grad():
-        nets.decoder_layer(x, W, p, keep, cfg, lora, 2.0, varlen=True)
-    t_fwd = time.time() - t0
-    t0 = time.time()
-    y = nets.decoder_layer(x, W, p, keep, cfg, lora, 2.0, varlen=True)
-    y.float().sum().backward()
-    t_fb = time.time() - t0
-    # lm_head + token log-prob + KL on the response rows
-    R = 1419
-    Wlm = (torch.randn(V, d, generator=g) * 0.02).to(bf)
-    h = torch.randn(1, R + 1, d, generator=g).to(bf).requires_grad_(True)
-    labels = torch.randint(3, V, (1, R + 1), generator=g)
-    t0 = time.time()
-    logits = F.linear(h, Wlm).float()
-    lp = odpa.cal_batch_logp(logits, labels)
-    ref_logits = logits.detach() + 0.01
-    kl = odpa.kl_to_reference(logits[:, :-1], ref_logits[:, :-1], labels[:, 1:])
-    (lp.sum() + kl).backward()
-    t_head = time.time() - t0
     L = cfg["num_hidden_layers"]
-    pair_s = 3 * (L * t_fb) + 1 * (L * t_fwd) + 4 * t_head
-    return {"value": round(1.0 / pair_s, 6), "unit": "paired-samples/sec", "cores": cores,
+    R = 1419
+    # FLOPs of the sample (forward): linears 2 T (4 d^2 + 3 d F) + LoRA 2 T r (sum of in + out) + causal attention 2 T^2 d
+    lin = 2.0 * T * (4 * d * d + 3 * d * Fd)
+    lora_f = 2.0 * T * r * (4 * 2 * d + 3 * (d + Fd))
+    att = 2.0 * T * T * d
+    fwd_flop = lin + lora_f + att
+    fb_flop = 2.0 * lin + 3.0 * lora_f + 3.5 * att           # frozen base: dX only; LoRA dX + dW; attention backward 2.5 x
+    out = {}
+    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        g = torch.Generator().manual_seed(0)
+        W, lora = {}, {}
+        p = "L."
+        for n, (o, i) in {"self_attn.q_proj": (d, d), "self_attn.k_proj": (d, d), "self_attn.v_proj": (d, d), "self_attn.o_proj": (d, d),
+                          "mlp.gate_proj": (Fd, d), "mlp.up_proj": (Fd, d), "mlp.down_proj": (d, Fd)}.items():
+            W[p + n + ".weight"] = (torch.randn(o, i, generator=g) * 0.02).to(dt)
+            lora[p + n + ".A"] = (torch.randn(r, i, generator=g) * 0.02).to(dt).requires_grad_(True)
+            lora[p + n + ".B"] = (torch.randn(o, r, generator=g) * 0.01).to(dt).requires_grad_(True)
+        W[p + "input_layernorm.weight"] = torch.ones(d, dtype=dt)
+        W[p + "post_attention_layernorm.weight"] = torch.ones(d, dtype=dt)
+        x = torch.randn(1, T, d, generator=g).to(dt).requires_grad_(True)
+        keep = torch.ones(1, T, dtype=torch.bool)
+        xa = torch.randn(T, d, generator=g).to(dt)
+        t_lin = _median_time(lambda: F.linear(xa, W[p + "mlp.gate_proj.weight"]))
+
+        def fwd():
+            with torch.no_grad():
+                nets.decoder_layer(x, W, p, keep, cfg, lora, 2.0, varlen=True)
+
+        def fb():
+            x.grad = None
+            for v in lora.values():
+                v.grad = None
+            nets.decoder_layer(x, W, p, keep, cfg, lora, 2.0, varlen=True).float().sum().backward()
+
+        t_fwd, t_fb = _median_time(fwd), _median_time(fb)
+        Wlm = (torch.randn(V, d, generator=g) * 0.02).to(dt)
+        h = torch.randn(1, R + 1, d, generator=g).to(dt).requires_grad_(True)
+        labels = torch.randint(3, V, (1, R + 1), generator=g)
+
+        def head():
+            h.grad = None
+            logits = F.linear(h, Wlm).float()
+            lp = odpa.cal_batch_logp(logits, labels)
+            ref_logits = logits.detach() + 0.01
+            kl = odpa.kl_to_reference(logits[:, :-1], ref_logits[:, :-1], labels[:, 1:])
+            (lp.sum() + kl).backward()
+
+        t_head = _median_time(head)
+        pair_s = 3 * (L * t_fb) + 1 * (L * t_fwd) + 4 * t_head
+        out[name] = {"pairs_per_s": 1.0 / pair_s, "s_per_pair": round(pair_s, 1), "layer_fwd_s": round(t_fwd, 3), "layer_fwd_bwd_s": round(t_fb, 3),
+                     "head_s": round(t_head, 3), "layer_fwd_gflops": round(fwd_flop / t_fwd / 1e9, 1),
+                     "layer_fwd_bwd_gflops": round(fb_flop / t_fb / 1e9, 1),
+                     "linear_gflops": round(2.0 * T * d * Fd / t_lin / 1e9, 1)}
+        del W, lora, Wlm
+    best = max(out, key=lambda k: out[k]["pairs_per_s"])
+    desc = "; ".join("%s: layer fwd %.3fs (%.0f GFLOP/s) fwd+bwd %.3fs (%.0f GFLOP/s), lm_head+logp+KL on %d rows %.3fs, a plain F.linear "
+                     "[%d x %d] x [%d x %d]^T on the same box %.0f GFLOP/s => %.0f s/pair"
+                     % (k, v["layer_fwd_s"], v["layer_fwd_gflops"], v["layer_fwd_bwd_s"], v["layer_fwd_bwd_gflops"], R, v["head_s"],
+                        T, d, Fd, d, v["linear_gflops"], v["s_per_pair"]) for k, v in out.items())
+    return {"value": round(out[best]["pairs_per_s"], 6), "unit": "paired-samples/sec", "cores": cores,
             "kind": "port (extrapolated: one decoder layer + one lm_head/loss call timed, scaled to a pair)",
-            "sample": "oracle (torch-CPU bf16 restatement): 1 decoder layer of the 7B geometry at T=2048 timed fwd (%.2fs) and "
-                      "fwd+bwd (%.2fs), lm_head+logp+KL on 1419 rows (%.2fs); pair = 3x32 fwd+bwd + 1x32 fwd layers + 4 heads "
-                      "(CLIP tower omitted, <1%%) => %.0f s/pair" % (t_fwd, t_fb, t_head, pair_s)}
+            "dtype_of_value": best,
+            "by_dtype": {k: {kk: (round(vv, 6) if kk == "pairs_per_s" else vv) for kk, vv in v.items()} for k, v in out.items()},
+            "sample": "oracle (torch-CPU restatement, oracle/nets.py + oracle/dpa.py), %d threads (%s), each timing = median of 3 after a "
+                      "warm-up call, 1 decoder layer of the 7B geometry at T=2048 + LoRA r=128: %s; pair = 3x32 fwd+bwd + 1x32 fwd "
+                      "layers + 4 heads (CLIP tower omitted, <1%%); value = the faster dtype (%s)" % (cores, how, desc, best)}
 
 
 def spawn_ranks(n, argv):
@@ -474,12 +535,14 @@ def main():
     batch["ref_images"] = batch["ref_images"].to(dev, torch.bfloat16)
 
     # the gradient exchange starts inside the step's last backward (layer bucket by layer bucket) and is finished before AdamW
-    reducer = dp.GradReducer.for_flat(flat, ctx) if ctx.world > 1 else None
+    # (ctx.active: N > 1, or HALVA_DP_FORCE=1 = a ONE-rank RCCL communicator, so that a 1-GPU box executes the exchange path too)
+    reducer = dp.GradReducer.for_flat(flat, ctx) if ctx.active else None
     comm_probe = []
 
     exchanged = [True]
 
-    def step():
+    def grads():
+        """zero_grad, 4 forward + 3 backward passes, loss, gradient exchange: everything of a step but the optimizer update."""
         exchanged[0] = reducer is None
         flat.zero_grad()
         loss = eng.loss(batch, backward=True, reducer=reducer)
@@ -490,6 +553,10 @@ def main():
             exchanged[0] = True
             e1.record()
             comm_probe.append((e0, e1, reducer.issued_early))
+        return loss
+
+    def step():
+        loss = grads()
         opt.step()
         return loss
 
@@ -497,13 +564,15 @@ def main():
     # (another tenant, a larger runtime footprint, RCCL's buffers), halve the groups BEFORE anything is timed.  With N > 1 the decision
     # is COLLECTIVE: a rank that runs out of memory mid-step has already handed some gradient buckets to RCCL while the others hand
     # over all of theirs, so it first completes that exchange (GradReducer.drain: the same collectives, contents discarded), then
-    # every rank joins a MAX all-reduce of the flag after EVERY warm-up step and all of them switch together.
+    # every rank joins a MAX all-reduce of the flag after EVERY warm-up step and all of them switch together.  The optimizer update
+    # of a warm-up step comes BEHIND that agreement: the healthy ranks' sums contain the failed rank's discarded buffer, and a
+    # replica stepped on them would carry different master weights and Adam moments for the rest of the run.
     oom_fallbacks = 0
     done, need = 0, args.warmup
     while done < need:
         oom = False
         try:
-            last = step()
+            last = grads()
         except torch.cuda.OutOfMemoryError:
             oom = True      # (handled below: inside the handler the traceback still pins the failed step's tensors)
         if oom and reducer is not None and not exchanged[0]:
@@ -523,6 +592,7 @@ def main():
                 print("bench: out of memory in the warm-up (%s); every rank continues with %d pairs per group"
                       % ("this rank" if oom else "another rank", args.pairs_per_group), file=sys.stderr)
             continue
+        opt.step()
         done += 1
     if os.environ.get("HALVA_BENCH_COPY_TRACE"):      # diagnostic: which .contiguous() / .reshape() calls of a step really copy (strided source)
         import collections, traceback
@@ -628,6 +698,7 @@ def main():
                 "exposed_ms_per_step": round(sum(a.elapsed_time(b) for a, b, _ in comm_probe) / len(comm_probe), 3),
                 "backend": torch.distributed.get_backend(), "world": torch.distributed.get_world_size(),
                 "ranks_on_distinct_gpus": os.environ.get("HALVA_SHARE_GPU") != "1",
+                "forced_one_rank_communicator": ctx.world == 1,
                 "note": "exposed = compute-stream time between the end of the last backward and the averaged gradient being ready "
                         "(rank 0); the buckets of the upper layers are reduced while the lower layers are still being differentiated"}
     if ctx.rank == 0:
@@ -663,7 +734,13 @@ def main():
                                           "global batch %d pairs per optimizer step over %d GPUs = %d pairs per GPU per step "
                                           % (B * ctx.world, ctx.world, B))),
                           "pairs_per_gpu": B, "global_pairs": B * ctx.world, "seq_len": seq if not args.resp_len else n_patch + 53 + args.resp_len, "parallelism": "dp%d" % ctx.world,
-                          "pairs_per_group": args.pairs_per_group, "oom_fallbacks_in_warmup": oom_fallbacks, "recompute": "none",
+                          "pairs_per_group": args.pairs_per_group,
+                          "pairs_per_group_rationale": "pairs differentiated together (one group's activations alive at a time). N = 1: all 16 "
+                          "pairs as one group (265 of 288 GiB).  N > 1: groups of 8 (174 GiB) - RCCL's buffers and kernel scratch share "
+                          "the HBM; at N = 8 the recipe's global 64 is 8 pairs per GPU = one group of 8, so the like-for-like single-GPU "
+                          "denominator of the N > 1 lines is `--pairs-per-gpu 8` (profiles/r04_bench_denominators.json), not the N = 1 "
+                          "default's 16-pair group",
+                          "oom_fallbacks_in_warmup": oom_fallbacks, "recompute": "none",
                           "parity_note": PARITY_NOTE,
                           "prefix_sharing": None if eng.last_packing is None else
                           {"rows_run": eng.last_packing[0], "rows_of_the_two_separate_sequences": eng.last_packing[1],
@@ -688,7 +765,7 @@ def main():
                "clock_trace": clock,
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(rec), flush=True)
-    if ctx.world > 1:
+    if ctx.active:
         torch.distributed.destroy_process_group()
 
 

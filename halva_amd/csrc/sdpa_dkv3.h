@@ -341,6 +341,9 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
     Dkv3Geom cur, nxt;
     collect(0, cur);
     collect(1, nxt);
+    // every wave has READ both slots before thread 0 overwrites slot 0 in round 0 (later rounds: the end-of-round barrier separates a
+    // slot's last read from its next write; here nothing did - a delayed wave could have taken the third item's geometry for its first)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     const unsigned q_piece = dkv3_uni((unsigned)(16 * p.ld_qkv * 2)), do_piece = dkv3_uni((unsigned)(16 * p.ld_do * 2));
     const unsigned wave_u = dkv3_uni((unsigned)wave);

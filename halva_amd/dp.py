@@ -33,8 +33,14 @@ def local_device_index():
 
 
 class DistContext:
-    def __init__(self, rank=0, world=1, local_rank=0, group=None):
+    """rank / world / device of this process.  `active` says whether the collectives are really issued: always with world > 1,
+    and with world == 1 when HALVA_DP_FORCE=1 asked for a ONE-RANK communicator (RCCL accepts one): every bucket of the gradient
+    exchange, the scalar reductions and the barriers then go through torch.distributed on the one GPU a build box has - the code
+    an 8-GPU run executes, with sums over a single rank (bit-identical to not exchanging at all)."""
+
+    def __init__(self, rank=0, world=1, local_rank=0, group=None, active=None):
         self.rank, self.world, self.local_rank, self.group = rank, world, local_rank, group
+        self.active = (world > 1) if active is None else bool(active)
 
     @classmethod
     def from_env(cls, backend=None):
@@ -44,7 +50,8 @@ class DistContext:
         world = int(os.environ.get("WORLD_SIZE", "1"))
         rank = int(os.environ.get("RANK", "0"))
         local = local_device_index()
-        if world > 1 and not dist.is_initialized():
+        force = os.environ.get("HALVA_DP_FORCE") == "1"
+        if (world > 1 or force) and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             backend = os.environ.get("HALVA_DIST_BACKEND") or ("gloo" if os.environ.get("HALVA_SHARE_GPU") == "1" else backend)
@@ -53,7 +60,7 @@ class DistContext:
             if backend == "nccl":
                 torch.cuda.set_device(local)
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
-        return cls(rank, world, local)
+        return cls(rank, world, local, active=world > 1 or (force and dist.is_initialized()))
 
 
 def _is_gloo(ctx):
@@ -79,7 +86,7 @@ def _allreduce_sum_async(t, ctx):
 def broadcast_(t, ctx, src=0):
     """Every rank ends up with rank `src`'s values of `t` (replica initialisation: what DeepSpeed's engine does for the reference at
     start-up - randomly initialised LoRA factors must not differ between the replicas)."""
-    if ctx.world == 1:
+    if not ctx.active:
         return t
     if t.is_cuda and _is_gloo(ctx):
         host = t.detach().cpu()
@@ -92,7 +99,7 @@ def broadcast_(t, ctx, src=0):
 
 def allreduce_mean_(flat, ctx):
     """In-place mean over ranks of a flat gradient buffer, bucketed, after the fact (no overlap).  Returns the buffer."""
-    if ctx.world == 1:
+    if not ctx.active:
         return flat
     fins = [_allreduce_sum_async(flat[lo:lo + BUCKET_ELEMS], ctx) for lo in range(0, flat.numel(), BUCKET_ELEMS)]
     for f in fins:
@@ -190,7 +197,7 @@ class GradReducer:
         memory" flag).  Must not be called for a step whose finish() has returned."""
         if not self._open:
             self._next, self._fins = 0, []
-        if self.ctx.world > 1:
+        if self.ctx.active:
             while self._next < len(self.buckets):
                 self._issue(*self.buckets[self._next])
                 self._next += 1
@@ -211,7 +218,7 @@ class GradReducer:
         self._fins.append(_allreduce_sum_async(self.g[lo:hi], self.ctx))
 
     def ready_from(self, lo):
-        if self.ctx.world == 1:
+        if not self.ctx.active:
             return
         while self._next < len(self.buckets) and self.buckets[self._next][0] >= lo:
             self._issue(*self.buckets[self._next])
@@ -219,7 +226,7 @@ class GradReducer:
             self.issued_early += 1
 
     def finish(self):
-        if self.ctx.world == 1:
+        if not self.ctx.active:
             self._open = False
             return self.g
         if not self._open:                     # a step without begin() (no reducer handed to the backward): exchange everything now
@@ -233,7 +240,7 @@ class GradReducer:
             f()
         self._fins = []
         self._open = False
-        self.g.div_(self.ctx.world)
+        self.g.div_(self.ctx.world)            # (a forced one-rank communicator: x / 1 is exact)
         return self.g
 
 
@@ -245,11 +252,11 @@ def _scalar(x, ctx, op):
 
 
 def mean_scalar(x, ctx):
-    return float(x) if ctx.world == 1 else _scalar(x, ctx, dist.ReduceOp.SUM) / ctx.world
+    return float(x) if not ctx.active else _scalar(x, ctx, dist.ReduceOp.SUM) / ctx.world
 
 
 def max_scalar(x, ctx):
-    return float(x) if ctx.world == 1 else _scalar(x, ctx, dist.ReduceOp.MAX)
+    return float(x) if not ctx.active else _scalar(x, ctx, dist.ReduceOp.MAX)
 
 
 def shard_batches(n_batches, ctx):
@@ -258,5 +265,5 @@ def shard_batches(n_batches, ctx):
 
 
 def barrier(ctx):
-    if ctx.world > 1:
+    if ctx.active:
         dist.barrier(group=ctx.group)

@@ -222,7 +222,7 @@ class HalvaTrainer:
             return
         a = self.args
         self._flat = dpa.FlatTrainables(dpa.trainable_named_parameters(self.model))
-        if self.dist.world > 1:      # replicas start from rank 0's trainable tensors (the LoRA A factors are random)
+        if self.dist.active:         # replicas start from rank 0's trainable tensors (the LoRA A factors are random)
             dp.broadcast_(self._flat.master, self.dist)
             self._flat.flat.copy_(self._flat.master)
         dpa.bind_model(self._flat, self.model)
@@ -313,7 +313,8 @@ class HalvaTrainer:
             torch.save({"master": self._flat.master.detach().cpu(), "names": list(self._flat.names),
                         "optimizer": self.optimizer.state_dict(), "global_step": self.state.global_step,
                         "epoch_index": self._pos["epoch"], "micro_in_epoch": self._pos["micro"],
-                        "micro_total": self._pos["total"], "epoch_rng_state": self._pos["rng"], "log_history": self.state.log_history,
+                        "micro_total": self._pos["total"], "pending_micro": self._pos.get("pending", 0),
+                        "epoch_rng_state": self._pos["rng"], "log_history": self.state.log_history,
                         "world": self.dist.world},
                        os.path.join(folder, "halva_state.pt"))
             with open(os.path.join(folder, "trainer_state.json"), "w") as f:
@@ -327,10 +328,13 @@ class HalvaTrainer:
         # An end-of-epoch checkpoint can fall INSIDE an accumulation group (micro-batches are counted across epochs, 4.31's
         # total_batched_samples): the fp32 accumulator then holds the group's first micro-batches, which the resumed run must not lose.
         # Every rank's accumulator is its own (nothing has been exchanged yet), so every rank writes its own file.
-        accum = max(1, int(getattr(a, "gradient_accumulation_steps", 1)))
-        if self._pos["total"] % accum != 0:
-            dp.barrier(self.dist)                                 # (rank 0 has created the folder)
-            torch.save({"grad": self._flat.grad.detach().cpu(), "pending_micro": self._pos["total"] % accum},
+        # `pending` counts the micro-batches accumulated since the last optimizer step (NOT total % accum: a step forced by an epoch
+        # shorter than one group zeroes the accumulator at any count).  The folder is created by every rank: on a multi-node run
+        # without a shared output_dir rank 0's makedirs is not visible to the other nodes.
+        pending = int(self._pos.get("pending", 0))
+        if pending:
+            os.makedirs(folder, exist_ok=True)
+            torch.save({"grad": self._flat.grad.detach().cpu(), "pending_micro": pending},
                        os.path.join(folder, "halva_pending_grad_rank%d.pt" % self.dist.rank))
         dp.barrier(self.dist)
         return folder
@@ -364,7 +368,7 @@ class HalvaTrainer:
 
     def _restore_pending_gradient(self, st, accum):
         """The accumulator of a checkpoint written inside an accumulation group (see _save_checkpoint); call after zero_grad()."""
-        pending = int(st["micro_total"]) % accum
+        pending = int(st["pending_micro"]) if "pending_micro" in st else int(st["micro_total"]) % accum
         if pending == 0:
             return
         path = os.path.join(st["_folder"], "halva_pending_grad_rank%d.pt" % self.dist.rank)
@@ -396,7 +400,7 @@ class HalvaTrainer:
         torch.manual_seed(getattr(a, "seed", 42))
         self.create_optimizer()
         accum = max(1, int(a.gradient_accumulation_steps))
-        reducer = dp.GradReducer.for_flat(self._flat, self.dist) if self.dist.world > 1 else None
+        reducer = dp.GradReducer.for_flat(self._flat, self.dist) if self.dist.active else None
         resume = None
         if resume_from_checkpoint:
             folder = resume_from_checkpoint if isinstance(resume_from_checkpoint, str) else None
@@ -409,10 +413,13 @@ class HalvaTrainer:
             self.log({"resumed_from": folder, "step": self.state.global_step})
         t0 = time.time()
         n_epochs = int(math.ceil(a.num_train_epochs))
-        self._pos = {"epoch": 0, "micro": 0, "total": 0, "rng": None}
+        self._pos = {"epoch": 0, "micro": 0, "total": 0, "rng": None, "pending": 0}
         self._max_steps = None
         done = False
         total_micro = int(resume["micro_total"]) if resume is not None else 0
+        since_step = 0          # micro-batches in the accumulator
+        if resume is not None:
+            since_step = int(resume["pending_micro"]) if "pending_micro" in resume else total_micro % accum
         self._flat.zero_grad()
         if resume is not None:
             self._restore_pending_gradient(resume, accum)
@@ -445,6 +452,7 @@ class HalvaTrainer:
                     continue
                 resume = None
                 total_micro += 1
+                since_step += 1
                 steps_now = total_micro % accum == 0 or (n_micro <= accum and (i + 1) == n_micro)
                 batch = self._to_device(batch)
                 loss = self.training_step(batch, scale=1.0 / accum, reducer=reducer if steps_now else None)
@@ -457,9 +465,10 @@ class HalvaTrainer:
                                                                     getattr(a, "warmup_ratio", 0.0)))
                 self.optimizer.step()
                 self._flat.zero_grad()
+                since_step = 0
                 self.state.global_step += 1
                 self.state.epoch = epoch + (i + 1) / n_micro
-                self._pos = {"epoch": epoch, "micro": i + 1, "total": total_micro, "rng": rng}
+                self._pos = {"epoch": epoch, "micro": i + 1, "total": total_micro, "rng": rng, "pending": 0}
                 if os.environ.get("HALVA_TRAIN_DEBUG"):
                     print("debug step %d epoch %d micro %d ids-sum %d master-sum %.9f grad-state %s" % (
                         self.state.global_step, epoch, i, int(batch["input_ids"].sum()), float(self._flat.master.double().sum()),
@@ -476,7 +485,7 @@ class HalvaTrainer:
                     break
             if done:
                 break
-            self._pos = {"epoch": epoch + 1, "micro": 0, "total": total_micro, "rng": None}
+            self._pos = {"epoch": epoch + 1, "micro": 0, "total": total_micro, "rng": None, "pending": since_step}
             if self._should_save(end_of_epoch=True):
                 self._save_checkpoint()
         for cb in self.callbacks:

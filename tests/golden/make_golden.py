@@ -523,8 +523,57 @@ TINY128 = dict(vocab_size=160, hidden_size=256, intermediate_size=384, num_hidde
                num_key_value_heads=2, max_position_embeddings=256, rms_norm_eps=1e-5, pad_token_id=0)
 
 
+# Multi-block length (round 4): post-splice rows of 300-1024 tokens, so that a row spans >= 4 row blocks of 256 and >= 8 key blocks
+# of 128, packed rows [prefix | correct | pad | hallucinated] cross 256-row blocks INSIDE branch B, the correct and the hallucinated
+# answer differ in length (phrases of different lengths), and one sample is cut at tokenizer_model_max_length.
+TINY128L = dict(TINY128, max_position_embeddings=2048)
+
+
+def make_batch_long(B, seed, n_patch, vis=None, vocab=None, resp_base=None):
+    """Collated batch (train_halva.py:963-989) of LONG responses: sample b's correct answer has RESP[b] tokens; its phrases sit at
+    PHR[b] = [(offset in the correct answer, correct length, hallucinated length)], so the hallucinated answer is the correct one
+    with every phrase replaced by a phrase of another length - everything behind the first phrase is shifted."""
+    vis = vis or VIS
+    g = torch.Generator().manual_seed(seed)
+    V = vocab or TINY["vocab_size"]
+    RESP = [300, 517, 806, 1100][:B]
+    PHR = [[(40, 3, 5), (200, 2, 2)], [(9, 2, 6), (260, 4, 1), (400, 3, 3)], [(150, 5, 2), (700, 2, 4)],
+           [(64, 3, 3), (500, 2, 7), (900, 4, 2)]][:B]
+    inst = []
+    for b in range(B):
+        pre = torch.randint(3, V, (4,), generator=g).tolist()
+        q = torch.randint(3, V, (5,), generator=g).tolist()
+        resp = torch.randint(3, V, (RESP[b],), generator=g).tolist()
+        head = [1] + pre + [-200] + q
+        ids, signs = list(head), [0] * len(head)
+        nids, nsigns = list(head), [0] * len(head)
+        at = 0
+        for k, (off, lp, ln) in enumerate(PHR[b]):
+            ids += resp[at:off + lp]
+            signs += [0] * (off - at) + [k + 1] * lp
+            nids += resp[at:off] + torch.randint(3, V, (ln,), generator=g).tolist()
+            nsigns += [0] * (off - at) + [k + 1] * ln
+            at = off + lp
+        ids += resp[at:] + [2]
+        signs += [0] * (len(resp) - at + 1)
+        nids += resp[at:] + [2]
+        nsigns += [0] * (len(resp) - at + 1)
+        labels = [-100] * len(head) + ids[len(head):]
+        nlabels = [-100] * len(head) + nids[len(head):]
+        rresp = torch.randint(3, V, (190 + 240 * b,), generator=g).tolist()
+        rids = [1] + torch.randint(3, V, (4,), generator=g).tolist() + [-200] + torch.randint(3, V, (5,), generator=g).tolist() + rresp + [2]
+        rlabels = [-100] * 11 + rresp + [2]
+        inst.append(dict(input_ids=torch.tensor(ids), labels=torch.tensor(labels), neg_input_ids=torch.tensor(nids),
+                         neg_labels=torch.tensor(nlabels), pos_signs=torch.tensor(signs), neg_signs=torch.tensor(nsigns),
+                         ref_input_ids=torch.tensor(rids), ref_labels=torch.tensor(rlabels),
+                         image=torch.randn(3, vis["image_size"], vis["image_size"], generator=g).bfloat16().float(),
+                         ref_image=torch.randn(3, vis["image_size"], vis["image_size"], generator=g).bfloat16().float()))
+    tok = FakeLlamaTokenizer(model_max_length=2048)
+    return TH.DataCollatorForHallDataset(tokenizer=tok)(inst)
+
+
 def gen_dpa_step_d64(name="dpa_step_d64", std=0.06, lora_std=0.05, TINY64=TINY64, B=3, seed=51, max_len=64, resp_base=None,
-                     model_seed=300):
+                     model_seed=300, make_batch=None):
     """Geometry the HIP kernels support (head_dim 64; TINY128: head_dim 128) with bf16-representable weights/images, so the GPU
     path (bf16) and the reference (fp32 here) start from identical numbers.  Weights are stored as raw bf16 bits (uint16)."""
     def bits(t):
@@ -545,7 +594,7 @@ def gen_dpa_step_d64(name="dpa_step_d64", std=0.06, lora_std=0.05, TINY64=TINY64
     for k, v in fac.items():
         packs[k] = bits(torch.from_numpy(v))
     packs["lora_cfg"] = np.array([4, 8.0])
-    batch = make_batch(B, seed, n_patch, vis=VIS64, vocab=TINY64["vocab_size"], resp_base=resp_base)
+    batch = (make_batch or globals()["make_batch"])(B, seed, n_patch, vis=VIS64, vocab=TINY64["vocab_size"], resp_base=resp_base)
     stub = trainer_stub(policy, ref, alpha)
     policy.zero_grad()
     pos_logps, neg_logps, batch_labels, all_logits, batch_signs = stub.concatenated_forward(policy, batch)
@@ -717,13 +766,22 @@ def main():
     gen_dpa_step_d64("dpa_step_d64_init", std=0.02, lora_std=0.02)
     gen_dpa_step_d64("dpa_step_d128_init", std=0.02, lora_std=0.02, TINY64=TINY128, B=4, seed=61, max_len=192, resp_base=118,
                      model_seed=310)
+    gen_dpa_step_long()
     gen_llama_layer()
     gen_clip_d64()
     gen_peft_names()
 
 
+def gen_dpa_step_long():
+    gen_dpa_step_d64("dpa_step_d128_long", std=0.02, lora_std=0.02, TINY64=TINY128L, B=4, seed=71, max_len=1024, model_seed=320,
+                     make_batch=make_batch_long)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "peft":          # only the fixture added in round 3
+    if len(sys.argv) > 1 and sys.argv[1] == "long":           # only the fixture added in round 4
+        torch.set_num_threads(4)
+        gen_dpa_step_long()
+    elif len(sys.argv) > 1 and sys.argv[1] == "peft":          # only the fixture added in round 3
         gen_peft_names()
     elif len(sys.argv) > 1 and sys.argv[1] == "d128":          # only the fixtures added in round 2 (the others reproduce bit for bit)
         torch.set_num_threads(4)

@@ -96,6 +96,40 @@ def test_two_ranks_over_rccl_match_one_rank(tmp_path):
     _check(got, _single_process_reference())
 
 
+def test_one_rank_rccl_communicator_runs_the_exchange_and_changes_nothing(tmp_path):
+    """HALVA_DP_FORCE=1 + WORLD_SIZE=1 + backend nccl: a ONE-rank RCCL communicator.  The code an 8-GPU run executes
+    (dist.all_reduce(async_op=True) on slices of the flat device buffer, issued from the backward hooks on RCCL's stream behind
+    the compute stream; wait; divide; the nccl branch of the scalar reductions; the barrier) runs on the one GPU of this box.
+    A sum over one rank is the identity: flat gradient, weights after AdamW and loss must equal the reducer-less step's BIT FOR
+    BIT, with every bucket but the last issued inside the backward."""
+    from golden_util import load_npz
+    from model_util import batch_of, build_product_models
+    from dp_worker import micro_batch
+    from halva_amd import dpa
+    out = str(tmp_path / "dp1_rccl.pt")
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HALVA_DIST_BACKEND="nccl", HALVA_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("HALVA_SHARE_GPU", None)
+    rc = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out], env=env, timeout=600).returncode
+    assert rc == 0
+    got = torch.load(out, weights_only=False)
+    assert got["backend"] == "nccl" and got["world"] == 1
+    assert len(got["buckets"]) >= 3 and got["issued_early"] >= len(got["buckets"]) - 1
+    z = load_npz("dpa_step_d64_init.npz")
+    pol, ref, _ = build_product_models(z, device="cuda:0")
+    flat = dpa.FlatTrainables(dpa.trainable_named_parameters(pol))
+    dpa.bind_model(flat, pol)
+    dpa.set_grad_sink(pol, True)
+    opt = dpa.AdamWFlat(flat, lr=1e-3, weight_decay=0.0, mm_projector_lr=1e-3)
+    eng = dpa.DPAEngine(pol, ref, float(z["alpha"]), pairs_per_group=1, ref_rows_per_group=1)
+    flat.zero_grad()
+    loss = float(eng.loss(micro_batch(batch_of(z), [0, 1]), backward=True))
+    assert torch.equal(got["grad"], flat.grad.detach().cpu())
+    opt.step()
+    assert torch.equal(got["master"], flat.master.detach().cpu())
+    assert got["loss"] == loss
+
+
 def test_bench_spawns_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` (no launcher): the parent starts two fresh rank processes before touching the GPU and rank 0
     prints the JSON line.  Two layers of the 7B geometry; on a 1-GPU box the ranks share the device (HALVA_BENCH_SHARE_GPU)."""

@@ -172,3 +172,44 @@ def test_two_rank_gloo():
         p.join(120)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert q.get(timeout=5) == "ok"
+
+
+def _forced_worker(port, out):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HALVA_DP_FORCE="1")
+    from halva_amd import dp
+    ctx = dp.DistContext.from_env("gloo")
+    assert ctx.world == 1 and ctx.active and dist.is_initialized() and dist.get_world_size() == 1
+    g = torch.arange(1000, dtype=torch.float32) * 0.37
+    want = g.clone()
+    red = dp.GradReducer(g, ctx, boundaries=[0, 200, 400, 600, 800], min_bucket=1)
+    calls = []
+    real = dp._allreduce_sum_async
+    dp._allreduce_sum_async = lambda t, c: (calls.append(t.numel()), real(t, c))[1]
+    red.begin()
+    for lo in (800, 600, 400, 200):
+        red.ready_from(lo)
+    assert red.issued_early == 4 and len(calls) == 4        # the collectives really went out from "the backward"
+    red.finish()
+    assert len(calls) == 5 and torch.equal(g, want)         # a one-rank sum / 1: bit-identical
+    assert dp.max_scalar(3.0, ctx) == 3.0 and dp.mean_scalar(2.5, ctx) == 2.5
+    dp.barrier(ctx)
+    dist.destroy_process_group()
+    out.put("ok")
+
+
+def test_forced_one_rank_communicator_issues_the_collectives():
+    """HALVA_DP_FORCE=1: world == 1 still initialises a process group and every bucket / scalar / barrier goes through it (the
+    hardware twin is tests/test_dp_engine_gpu.py::test_one_rank_rccl_communicator_...); without the flag a world of one issues none."""
+    from halva_amd import dp
+    ctx = dp.DistContext(0, 1, 0)
+    assert not ctx.active and dp.max_scalar(1.0, ctx) == 1.0
+    red = dp.GradReducer(torch.ones(10), ctx, boundaries=[0, 5], min_bucket=1)
+    red.begin()
+    red.ready_from(5)
+    assert red.issued_early == 0
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    p = mpctx.Process(target=_forced_worker, args=(_free_port(), q))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0 and q.get(timeout=5) == "ok"

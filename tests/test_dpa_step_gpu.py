@@ -29,23 +29,29 @@ def _engine(z, pairs_per_group, ref_rows_per_group, share_prefix=None):
 #                      8e-3 (3x the bf16 noise floor); used for the gradient checks (large, well-conditioned gradients).
 #   dpa_step_d128_init head_dim 128 (2 heads x 128, hidden 256) - the headline attention instantiation - N(0, 0.02) weights,
 #                      4 pairs with ~120-token responses (T ~ 140: the causal kernel crosses 64-key tile boundaries); 1e-3.
-FIXTURES = {"dpa_step_d64_init": (1e-3, 1e-3, 1e-3), "dpa_step_d64": (8e-3, 8e-3, 8e-3), "dpa_step_d128_init": (1e-3, 1e-3, 1e-3)}
+#   dpa_step_d128_long (round 4) the same geometry at MULTI-BLOCK length: responses of 300 / 517 / 806 / 1100 tokens (the last one cut at
+#                      tokenizer_model_max_length 1024), correct and hallucinated phrases of different lengths (everything behind the
+#                      first phrase is shifted between the two rows), 2-3 phrases per sample: post-splice rows span 4 row blocks of
+#                      256 and 8 key blocks of 128, packed rows cross 256-row blocks inside branch B - the block pairing of the
+#                      forward / dQ kernels and sdpa_bwd_dkv3's queues run INSIDE a step checked against the reference's own numbers.
+FIXTURES = {"dpa_step_d64_init": (1e-3, 1e-3, 1e-3), "dpa_step_d64": (8e-3, 8e-3, 8e-3), "dpa_step_d128_init": (1e-3, 1e-3, 1e-3),
+            "dpa_step_d128_long": (1e-3, 1e-3, 1e-3)}
 # Per-phrase log-prob sums (values ~ -10 nat: two-token phrases at vocab 160) are held to 1e-3 RELATIVE on the realistic-init
 # fixtures.  The margins neg_acc - pos_acc are differences of two such sums; their absolute error is bounded by the bf16 noise
 # floor of the reference's OWN arithmetic: the oracle (CPU restatement, pinned to the reference at 1e-6 in fp32) re-run with bf16
 # tensors moves the margins by 3.9e-3 (d64_init) / 1.1e-2 (d128_init) / 2.2e-2 (d64 stress) - a residual stream held in bf16 carries
 # 2^-9 relative noise per rounding, whatever executes it.  The product (fp32 accumulation inside every kernel) must not be worse
 # than that floor (observed 2.9e-3 / 5.4e-3 / 1.6e-2), and never worse than 1e-3 where the floor is lower.
-REL_TOL = {"dpa_step_d64_init": 1e-3, "dpa_step_d128_init": 1e-3, "dpa_step_d64": 2e-3}
+REL_TOL = {"dpa_step_d64_init": 1e-3, "dpa_step_d128_init": 1e-3, "dpa_step_d64": 2e-3, "dpa_step_d128_long": 1e-3}
 # max |margin error| of the oracle run in bf16 (measured in the build container by _bf16_floor below; the CPU test
 # tests/test_oracle_vs_golden.py::test_bf16_floor_constants re-measures it and fails if these are more than 2x a live measurement)
-MARGIN_FLOOR = {"dpa_step_d64_init": 3.9e-3, "dpa_step_d128_init": 1.13e-2, "dpa_step_d64": 2.2e-2}
+MARGIN_FLOOR = {"dpa_step_d64_init": 3.9e-3, "dpa_step_d128_init": 1.13e-2, "dpa_step_d64": 2.2e-2, "dpa_step_d128_long": 5.6e-3}
 # Gradients (LoRA factors through the chain rule from the reference's dense dL/dW, projector directly), relative Frobenius error per
 # tensor: the same floor argument.  The oracle re-run in bf16 on the CPU is 1.27e-2 / 1.50e-2 / 2.03e-2 away from the reference's fp32
 # gradients on the three fixtures (max over the tensors; _bf16_grad_floor below re-measures it, tests/test_oracle_vs_golden.py holds
 # the constants to a live measurement); the product is bound by 1.25 x that floor on every fixture (round 2 checked only the stress
 # fixture, at a flat 3e-2).
-GRAD_FLOOR = {"dpa_step_d64_init": 1.27e-2, "dpa_step_d128_init": 1.50e-2, "dpa_step_d64": 2.03e-2}
+GRAD_FLOOR = {"dpa_step_d64_init": 1.27e-2, "dpa_step_d128_init": 1.50e-2, "dpa_step_d64": 2.03e-2, "dpa_step_d128_long": 1.46e-2}
 _floor_cache = {}
 _gfloor_cache = {}
 

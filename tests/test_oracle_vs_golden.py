@@ -168,7 +168,7 @@ def _models_from(z):
 
 
 @pytest.mark.parametrize("name", ["dpa_step_a", "dpa_step_trunc", "dpa_step_identity", "dpa_step_d64", "dpa_step_d64_init",
-                                  "dpa_step_d128_init"])
+                                  "dpa_step_d128_init", "dpa_step_d128_long"])
 def test_compute_loss(name):
     z = load_npz(name + ".npz")
     pol, ref, lora = _models_from(z)
@@ -202,7 +202,7 @@ def test_compute_loss(name):
             np.testing.assert_allclose(Bm.grad.numpy(), (s * dW @ A.detach().T).numpy(), atol=3e-5, err_msg=k)
 
 
-@pytest.mark.parametrize("name", ["dpa_step_d64_init", "dpa_step_d128_init", "dpa_step_d64"])
+@pytest.mark.parametrize("name", ["dpa_step_d64_init", "dpa_step_d128_init", "dpa_step_d64", "dpa_step_d128_long"])
 def test_bf16_floor_constants(name):
     """The GPU step test bounds the product's phrase-margin error by the bf16 noise floor of the reference arithmetic itself
     (this oracle re-run with bf16 tensors).  The committed constants must not be inflated: at most 2x a live measurement."""

@@ -1,7 +1,9 @@
 """Build-time check of sdpa_bwd_dkv3's generated-asm kernel (device assembly from `hipcc -S --cuda-device-only sdpa.hip`):
   * no compiler-generated instruction touches a128-a191 (the K / V fragments are fetched by hand into those registers and may still be in
-    flight while the compiler's code runs: a copy would read them too early), nor - between the asm statements of an item - a0-a127;
+    flight while the compiler's code runs: a copy would read them too early);
   * no scratch (a scratch reload waits, in order, for every tile request in flight).
+(a0-a127, the accumulators, are NOT checked: the compiler legitimately reads them for the store tail behind the last asm statement.)
+Run by halva_amd/csrc/Makefile on the device assembly of the same command line that builds sdpa.o; a failure fails the build.
 usage: python tools/check_dkv3_isa.py <file.s>"""
 import re, sys
 txt = open(sys.argv[1]).read().split("\n")
