@@ -1,0 +1,471 @@
+#!/usr/bin/env python3
+"""Generates sdpa_fwd3_loop.inc: ONE row block (item) of the causal forward, sdpa_fwd3 (sdpa_fwd3.h), as one inline-asm block.
+
+A wave is alone on its SIMD (512 registers) and owns 64 QUERIES - two groups g of 32: their Q fragments (B operands, a[128:191]) and their
+O^T accumulators (a[0:127]) - and per 64-key tile t of the workgroup's K / V ring computes
+    S^T_g[key][query] = K Q_g^T      A = K tile rows from LDS (one A operand serves both groups), B = Q fragments; lane = query, registers = keys:
+                                      a query's row statistics are per LANE, no cross-lane work inside the loop
+    P = exp2(S^T sc - m_ref)         in place; m_ref is a per-query REFERENCE fixed for the whole item (set in the prologue from the first half
+                                      tile's row maximum, or handed in); the running maximum is only tracked (v_max3) - the caller repeats the
+                                      item with m_ref = the true maximum in the rare case that it outgrew the reference by more than 2^64
+    O^T_g[d][query] += V^T P_g       A = V^T by transposed LDS reads (shared by both groups again), B = P packed to bf16
+= 64 MFMAs per tile.  The stream is the one measured in experiments/fwd3 (2 804 cycles per step; 3 020-3 042 with the tiles streamed by LDS-DMA;
+masked variant 3 339), ROTATED by half a step so that ALL vector work of an iteration belongs to ONE tile (its mask state is per iteration):
+    n =  0..15  O(t-1) keys 32..63        gaps  1..30: vector work of S(t) keys  0..31 (chain: n = 48..63 of the previous iteration)
+    n = 16..31  S(t)   keys 32..63        gaps 33..62: vector work of S(t) keys 32..63
+    n = 32..47  O(t)   keys  0..31
+    n = 48..63  S(t+1) keys  0..31
+K / V tiles: a ring of FOUR slots (K at 0, V at 64 KiB, 16 KiB per tile) fed by LDS-DMA: the item's prologue requests tiles 0..2, iteration t waits
+for tile t+1 (ONE counted vmcnt + s_barrier, gap 25) and then requests tile t+3 into the slot tile t-1 left (gaps 32..39); requests past the
+item's last tile still go out (into a dummy chunk) so that every iteration has the same eight vector-memory operations.  The tile WALK may
+jump once (a row block wholly inside branch B of a packed row skips the tiles of [br.a, br.b)); the sequence's partial last tile is fetched
+with per-piece clamped lane offsets (out of line).
+Iterations come in two bodies: PLAIN (every key of the tile visible to every query of the wave) and MASKED (every score compared with the lane's
+visible-key count: causal diagonal, sequence tail, branch edge, wholly hidden tiles); an item is [plain n0][masked n1, rsA][plain n2][masked n3, rsB].
+Machinery as gen_dkv3_loop.py: 8-slot A-operand ring filled LOOKAHEAD MFMAs ahead, <= CAP issue units of vector work per MFMA gap, every
+s_waitcnt lgkmcnt(N) from a simulation of the in-order LDS queue, hazard checks.
+
+Operands (by NAME): o0-o7 the O^T accumulators of group 0 / 1 ("=a", fixed a[0:127]: zeroed here), q0-q15 the Q fragments ("a", fixed a[128:191]:
+possibly still in flight at entry - the block's first wait covers them), l0 / mx0 / mr0, l1 / mx1 / mr1 outputs: row sum, running maximum (raw
+scores), reference used (log2 units) per lane ("=&v"); rowrel / colrel row-read / transposed-read lane offsets, voff the lane offset of a wave's tile
+piece, alt0-alt3 the same for the four pieces of a partial last tile ("v"); rsA, rsB0/1 per-lane visible-key counts (minus 4 h) of the first tile of
+masked run 1 (the same for both groups: br.a) / of masked run 2; mri0/1 the reference handed in (ctl bit 3); k_lo/k_hi first K row of the first
+tile (a uniform value in VECTOR registers), vdlo / vdhi = v - k in bytes, safe_k always-valid K rows for the dummy requests ("s", 64 bit); sc = scale * log2 e, n01 =
+n0 | n1 << 16, n23, nreq = tiles to request | requests before the walk's jump << 16 (0xffff: no jump), jlo / jhi the jump in bytes, wave,
+piece = bytes between a wave's pieces (16 rows), ctl: bits 0-1 ring slot of tile 0, bit 2 the last tile is partial, bit 3 reference handed in,
+bit 4 tiles 0..2 were requested by the previous item's block, bits 5-6 tiles of the NEXT item (first rows nk_lo.. / nv_lo.., "v") that this
+block's last iterations request once its own are all under way, bit 7 (with bit 4) the predecessor issued exactly 18 stores behind this
+item's Q loads, bits 8-9 the first tile's mask state (0 plain, 1 masked run 1, 2 masked run 2) ("s")."""
+import os
+import re
+import sys
+
+LOOKAHEAD, CAP, CAP_MASKED = 6, 5, 8
+XS = {(0, 0): 64, (0, 1): 80, (1, 0): 96, (1, 1): 112}      # score tiles [group][key half]: 16 registers each
+PB = {(0, 0): 128, (0, 1): 136, (1, 0): 144, (1, 1): 152}   # packed P: 8 registers each
+L2, MX, MREF, RANGE = {0: 160, 1: 164}, {0: 168, 1: 169}, {0: 170, 1: 171}, {0: 172, 1: 173}
+V_NINF, V_T0, V_T1 = 174, 175, 212
+RING = 176
+KRE, KRO, VC0, VC1 = 208, 209, 210, 211
+V_LAST = 215
+S_T, S_CNT, S_TMP, S_TMP2, S_TOFFK, S_TOFFV, S_M0SAVE, S_DST = "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77"
+S_RLEFT, S_TOJUMP, S_ISSUED, S_USEALT, S_SEG, S_FLD, S_PART, S_NPF = "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85"
+KP, VP, KORG, VORG, SRC, SAFEK, SAFEV = (86, 87), (88, 89), (90, 91), (92, 93), (94, 95), (96, 97), (98, 99)
+S_FIRST, S_LAST = 70, 99      # (s85 = S_NPF)
+K_LDS, V_LDS, DUMMY_LDS = 0, 65536, 131072
+WAIT_GAP, V_UPD_GAP = 25, 9
+DMA_PRE_GAPS, DMA_GAPS = [26, 27, 28, 29, 30, 31], [32, 33, 34, 35, 36, 37, 38, 39]
+MASKED, PHASE = False, "p"
+
+
+def vr(lo, n):
+    return "v[%d:%d]" % (lo, lo + n - 1) if n > 1 else "v%d" % lo
+
+
+def sp(pair):
+    return "s[%d:%d]" % pair
+
+
+def regs(lo, n):
+    return ["v%d" % i for i in range(lo, lo + n)]
+
+
+class Ins:
+    def __init__(self, text, kind, reads=(), writes=(), lds_defs=None, cost=0):
+        self.text, self.kind, self.reads, self.writes, self.lds_defs, self.cost = text, kind, set(reads), set(writes), lds_defs, cost
+
+
+def raw(t):
+    return Ins(t, "raw")
+
+
+def mfma_list():
+    out = []
+    for j in range(8):                       # O(t-1), keys 32..63
+        for g in (0, 1):
+            out.append(dict(prod="O", g=g, kh=1, j=j, a=("col", 1, j)))
+    for ks in range(8):                      # S(t), keys 32..63
+        for g in (0, 1):
+            out.append(dict(prod="S", g=g, kh=1, ks=ks, a=("row", 1, ks)))
+    for j in range(8):                       # O(t), keys 0..31
+        for g in (0, 1):
+            out.append(dict(prod="O", g=g, kh=0, j=j, a=("col", 0, j)))
+    for ks in range(8):                      # S(t+1), keys 0..31
+        for g in (0, 1):
+            out.append(dict(prod="S", g=g, kh=0, ks=ks, a=("row", 0, ks)))
+    return out
+
+
+def a_loads(desc, slot):
+    kind, kh, j = desc
+    base = RING + 4 * slot
+    if kind == "row":
+        addr = (KRE, KRO)[j & 1]
+        return [Ins("ds_read_b128 %s, v%d offset:%d" % (vr(base, 4), addr, 8192 * kh + 512 * (j >> 1)), "lds", reads=["v%d" % addr], writes=regs(base, 4), lds_defs=regs(base, 4))]
+    k16, dt = j // 4, j % 4
+    o0 = 2048 * (4 * kh + 2 * k16) + 512 * dt
+    return [Ins("ds_read_b64_tr_b16 %s, v%d offset:%d" % (vr(base, 2), VC0, o0), "lds", reads=["v%d" % VC0], writes=regs(base, 2), lds_defs=regs(base, 2)),
+            Ins("ds_read_b64_tr_b16 %s, v%d offset:%d" % (vr(base + 2, 2), VC1, o0 + 2048), "lds", reads=["v%d" % VC1], writes=regs(base + 2, 2), lds_defs=regs(base + 2, 2))]
+
+
+def mfma_ins(n, m):
+    slot = RING + 4 * ((n // 2) % 8)
+    a = vr(slot, 4)
+    if m["prod"] == "S":
+        x = XS[(m["g"], m["kh"])]
+        d = vr(x, 16)
+        return Ins("v_mfma_f32_32x32x16_bf16 %s, %s, %%[q%d], %s" % (d, a, 8 * m["g"] + m["ks"], "0" if m["ks"] == 0 else d), "mfma",
+                   reads=regs(slot, 4) + (regs(x, 16) if m["ks"] else []), writes=regs(x, 16))
+    k16 = m["j"] // 4
+    dt = m["j"] % 4
+    b = PB[(m["g"], m["kh"])] + 4 * k16
+    acc = 4 * m["g"] + dt
+    return Ins("v_mfma_f32_32x32x16_bf16 %%[o%d], %s, %s, %%[o%d]" % (acc, a, vr(b, 4), acc), "mfma", reads=regs(slot, 4) + regs(b, 4))
+
+
+def mask_ops(g, kh, rng):
+    """score register r of key half kh holds key 32 kh + (r & 3) + 8 (r >> 2) (+ 4 h, folded into the range): visible iff that is < range"""
+    x = XS[(g, kh)]
+    o = []
+    for r in range(16):
+        key = 32 * kh + (r & 3) + 8 * (r >> 2)
+        o.append(Ins("v_cmp_lt_i32_e32 vcc, %d, v%d\\n\\tv_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (key, rng, x + r, V_NINF, x + r), "valu",
+                     reads=["v%d" % rng, "v%d" % (x + r), "v%d" % V_NINF], writes=["v%d" % (x + r)], cost=2))
+    return o
+
+
+def valu_ops(g, kh):
+    """ordered vector work of one score tile (16 registers): (mask,) running maximum, P = exp2(S sc - m_ref) in place, l += P, bf16 packs"""
+    x, pb, l2, mx, mref = XS[(g, kh)], PB[(g, kh)], L2[g], MX[g], MREF[g]
+    M3 = lambda i: Ins("v_max3_f32 v%d, v%d, v%d, v%d" % (mx, x + 2 * i, x + 2 * i + 1, mx), "valu", reads=["v%d" % (x + 2 * i), "v%d" % (x + 2 * i + 1), "v%d" % mx], writes=["v%d" % mx], cost=1)
+    A = lambda r: Ins("v_fma_f32 v%d, v%d, %%[sc], -v%d" % (x + r, x + r, mref), "valu", reads=["v%d" % (x + r), "v%d" % mref], writes=["v%d" % (x + r)], cost=1)
+    B = lambda r: Ins("v_exp_f32_e32 v%d, v%d" % (x + r, x + r), "trans", reads=["v%d" % (x + r)], writes=["v%d" % (x + r)], cost=2)
+    Ls = lambda i: Ins("v_pk_add_f32 %s, %s, %s" % (vr(l2 + 2 * (i & 1), 2), vr(l2 + 2 * (i & 1), 2), vr(x + 2 * i, 2)), "valu",
+                       reads=regs(l2 + 2 * (i & 1), 2) + regs(x + 2 * i, 2), writes=regs(l2 + 2 * (i & 1), 2), cost=1)
+    Dp = lambda i: Ins("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (pb + i, x + 2 * i, x + 2 * i + 1), "valu", reads=regs(x + 2 * i, 2), writes=["v%d" % (pb + i)], cost=1)
+    o = []
+    if MASKED:
+        o += mask_ops(g, kh, RANGE[g])
+    o += [M3(i) for i in range(8)]
+    o += [A(0), A(1), A(2), A(3)]
+    for r in range(12):
+        o += [B(r), A(r + 4)]
+        if r % 2 == 1 and r >= 3:
+            i = (r - 3) // 2
+            o += [Ls(i), Dp(i)]
+    o += [B(12), B(13), B(14), B(15)]
+    o += [Ls(5), Dp(5), Ls(6), Dp(6), Ls(7), Dp(7)]
+    return o
+
+
+def k_addr_from_toff():
+    return [Ins("v_add_u32_e32 v%d, %s, %%[rowrel]" % (KRE, S_TOFFK), "valu", writes=["v%d" % KRE], cost=1),
+            Ins("v_xor_b32_e32 v%d, 32, v%d" % (KRO, KRE), "valu", reads=["v%d" % KRE], writes=["v%d" % KRO], cost=1)]
+
+
+def v_addr_from_toff():
+    return [Ins("v_add_u32_e32 v%d, %s, %%[colrel]" % (VC0, S_TOFFV), "valu", writes=["v%d" % VC0], cost=1),
+            Ins("v_add_u32_e32 v%d, %d, v%d" % (VC0, V_LDS, VC0), "valu", reads=["v%d" % VC0], writes=["v%d" % VC0], cost=1),
+            Ins("v_xor_b32_e32 v%d, 32, v%d" % (VC1, VC0), "valu", reads=["v%d" % VC0], writes=["v%d" % VC1], cost=1)]
+
+
+def addr_update(which):
+    if which == "v":      # V tile of the O products: the tile the S chains have been reading (t)
+        return [Ins("s_mov_b32 %s, %s" % (S_TOFFV, S_TOFFK), "salu")] + v_addr_from_toff()
+    return [Ins("s_add_u32 %s, %s, 1" % (S_T, S_T), "salu"), Ins("s_and_b32 %s, %s, 3" % (S_TMP, S_T), "salu"), Ins("s_lshl_b32 %s, %s, 14" % (S_TOFFK, S_TMP), "salu")] + k_addr_from_toff()
+
+
+def request_tile(tag, dst_plus):
+    """(pre, [8 piece groups], post, out-of-line) - instruction texts - of ONE tile request: the next tile of the walk (or a dummy when none is
+    left) into ring slot (S_T + dst_plus) & 3.  Without a taken branch on the common path."""
+    # no tile of this item left: the requests go on with the workgroup's NEXT item's first tiles (S_NPF of them; same slot rotation, so that item
+    # simply starts on a rotated ring with its first tiles under way), then to the dummy chunk
+    pre = ["s_cmp_eq_u32 %s, 0" % S_RLEFT, "s_cbranch_scc1 .Lf3_sw%s_%%=" % tag, ".Lf3_swb%s_%%=:" % tag,
+           "s_add_u32 %s, %s, %d" % (S_DST, S_T, dst_plus), "s_and_b32 %s, %s, 3" % (S_DST, S_DST), "s_lshl_b32 %s, %s, 14" % (S_DST, S_DST),
+           "s_lshl_b32 %s, %%[wave], 10" % S_TMP2, "s_add_u32 %s, %s, %s" % (S_DST, S_DST, S_TMP2),
+           "s_min_u32 %s, %s, 1" % (S_ISSUED, S_RLEFT),
+           "s_cmp_eq_u32 %s, 1" % S_RLEFT, "s_cselect_b32 %s, %s, 0" % (S_USEALT, S_PART),
+           "s_cmp_eq_u32 %s, 0" % S_TOJUMP, "s_cselect_b32 %s, %%[jlo], 0" % S_TMP, "s_cselect_b32 %s, %%[jhi], 0" % S_TMP2,
+           "s_add_u32 s%d, s%d, %s" % (KP[0], KP[0], S_TMP), "s_addc_u32 s%d, s%d, %s" % (KP[1], KP[1], S_TMP2),
+           "s_add_u32 s%d, s%d, %s" % (VP[0], VP[0], S_TMP), "s_addc_u32 s%d, s%d, %s" % (VP[1], VP[1], S_TMP2),
+           "s_sub_u32 %s, %s, 1" % (S_TOJUMP, S_TOJUMP),
+           "s_mov_b64 %s, %s" % (sp(KORG), sp(KP)), "s_mov_b64 %s, %s" % (sp(VORG), sp(VP))]
+    groups = []
+    ool = [".Lf3_sw%s_%%=:" % tag, "s_cmp_eq_u32 %s, 0" % S_NPF, "s_cbranch_scc1 .Lf3_swb%s_%%=" % tag,
+           "v_readfirstlane_b32 s%d, %%[nk_lo]" % KP[0], "v_readfirstlane_b32 s%d, %%[nk_hi]" % KP[1],
+           "s_mov_b32 %s, %s" % (S_RLEFT, S_NPF), "s_mov_b32 %s, 0" % S_NPF, "s_mov_b32 %s, 0" % S_PART, "s_mov_b32 %s, -1" % S_TOJUMP,
+           "s_nop 3", "s_add_u32 s%d, s%d, %%[vdlo]" % (VP[0], KP[0]), "s_addc_u32 s%d, s%d, %%[vdhi]" % (VP[1], KP[1]), "s_branch .Lf3_swb%s_%%=" % tag]
+    k = 0
+    for ptr, org, base, safe in ((KP, KORG, K_LDS, SAFEK), (VP, VORG, V_LDS, SAFEV)):
+        for i in range(4):
+            g = ["s_add_u32 %s, %s, %d" % (S_TMP, S_DST, base + 4096 * i), "s_cmp_lg_u32 %s, 0" % S_ISSUED, "s_cselect_b32 m0, %s, %d" % (S_TMP, DUMMY_LDS),
+                 "s_cselect_b64 %s, %s, %s" % (sp(SRC), sp(ptr), sp(safe)), "s_cmp_lg_u32 %s, 0" % S_USEALT, "s_cbranch_scc1 .Lf3_a%d%s_%%=" % (k, tag),
+                 "global_load_lds_dwordx4 %%[voff], %s" % sp(SRC), ".Lf3_j%d%s_%%=:" % (k, tag),
+                 "s_add_u32 s%d, s%d, %%[piece]" % (ptr[0], ptr[0]), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])]
+            ool += [".Lf3_a%d%s_%%=:" % (k, tag), "global_load_lds_dwordx4 %%[alt%d], %s" % (i, sp(org)), "s_branch .Lf3_j%d%s_%%=" % (k, tag)]
+            groups.append(g)
+            k += 1
+    post = ["s_sub_u32 %s, %s, %s" % (S_RLEFT, S_RLEFT, S_ISSUED)]
+    return pre, groups, post, ool
+
+
+def build_body():
+    M = mfma_list()
+    gaps = [[] for _ in range(64)]
+    used = [0] * 64
+    pre, groups, post, ool = request_tile(PHASE, 2)      # (behind gap 25's increment S_T = tile t+1: tile t+3 goes to slot S_T + 2)
+    per = (len(pre) + len(DMA_PRE_GAPS) - 1) // len(DMA_PRE_GAPS)
+    for k, gp in enumerate(DMA_PRE_GAPS):
+        gaps[gp] += [raw(t) for t in pre[k * per:(k + 1) * per]]
+    for k, grp in enumerate(groups):
+        gaps[DMA_GAPS[k]] += [raw(t) for t in grp]
+    gaps[DMA_GAPS[-1]] += [raw(t) for t in post]
+    # tile t+1 (its K rows are read from gap 42 on) has landed for every wave: only tile t+2's 8 requests may stay in flight; behind this
+    # barrier every wave has issued its last read of tile t-1 (V rows 32..63, n <= 15)
+    gaps[WAIT_GAP] += [raw("s_waitcnt vmcnt(8)"), raw("s_barrier")]
+    # A operands: pair m = MFMAs 2m, 2m+1; its read(s) go out in gap 2m - LOOKAHEAD (of the previous iteration for the first pairs)
+    for m in range(32):
+        g = (2 * m - LOOKAHEAD) % 64
+        gaps[g] += a_loads(M[2 * m]["a"], m % 8)
+    gaps[V_UPD_GAP] += addr_update("v"); used[V_UPD_GAP] += 3
+    gaps[WAIT_GAP] += addr_update("k"); used[WAIT_GAP] += 2
+    for kh, first, last in ((0, 1, 30), (1, 33, 62)):
+        for grp in (0, 1):
+            g = first + grp
+            for ins in valu_ops(grp, kh):
+                while used[g] + ins.cost > (CAP_MASKED if MASKED else CAP):
+                    g += 1
+                assert g <= last, "vector work of key half %d does not fit its window" % kh
+                gaps[g].append(ins)
+                used[g] += ins.cost
+    if MASKED:      # the next tile lies 64 keys further on
+        gaps[63] += [Ins("v_subrev_u32_e32 v%d, 64, v%d" % (RANGE[g], RANGE[g]), "valu", reads=["v%d" % RANGE[g]], writes=["v%d" % RANGE[g]], cost=1) for g in (0, 1)]
+        used[63] += 2
+    return M, gaps, used, ool
+
+
+def linearize(M, gaps):
+    seq = []
+    for n in range(64):
+        seq.append(mfma_ins(n, M[n]))
+        seq += gaps[n]
+    return seq
+
+
+def insert_waits(seq, carried):
+    fifo, pending, lines, prev = list(carried), {}, [], None
+    for e in fifo:
+        for r in e["defs"]:
+            pending[r] = e
+    for ins in seq:
+        need = [pending[r] for r in (ins.reads | ins.writes) if r in pending]
+        if need:
+            last = max(fifo.index(e) for e in need)
+            cnt = len(fifo) - 1 - last
+            assert cnt <= 15
+            lines.append("s_waitcnt lgkmcnt(%d)" % cnt)
+            for e in fifo[:last + 1]:
+                for r in e["defs"]:
+                    if pending.get(r) is e:
+                        del pending[r]
+            fifo = fifo[last + 1:]
+        if prev is not None and prev.kind == "trans" and ins.kind in ("valu", "trans", "mfma") and (prev.writes & ins.reads):
+            lines.append("s_nop 0")
+        lines.append(ins.text)
+        if ins.kind == "lds":
+            e = {"defs": set(ins.lds_defs)}
+            fifo.append(e)
+            for r in e["defs"]:
+                pending[r] = e
+        assert len(fifo) <= 15, "more than 15 LDS reads in flight"
+        if ins.kind not in ("salu", "raw"):
+            prev = ins
+    return lines, fifo
+
+
+def check(seq):
+    pos_mfma = [i for i, s in enumerate(seq) if s.kind == "mfma"]
+    last_writer = {}
+    for i, s in enumerate(seq):
+        if s.kind in ("valu", "trans"):
+            for r in s.reads:
+                if r in last_writer and last_writer[r][0] == "mfma":
+                    assert sum(1 for p in pos_mfma if last_writer[r][1] < p < i) >= 2, "%s reads %s too close behind its MFMA chain" % (s.text, r)
+        if s.kind == "mfma":
+            for r in s.reads:
+                if r in last_writer and last_writer[r][0] in ("valu", "trans"):
+                    assert i - last_writer[r][1] >= 4, "%s reads %s right behind the vector write" % (s.text, r)
+        for r in s.writes:
+            last_writer[r] = (s.kind, i)
+
+
+def carried_reads(M):
+    c = []
+    for m in range(32):
+        if 2 * m - LOOKAHEAD < 0:
+            for l in a_loads(M[2 * m]["a"], m % 8):
+                c.append({"defs": set(l.lds_defs)})
+    return c
+
+
+def variant(masked, phase):
+    global MASKED, PHASE
+    MASKED, PHASE = masked, phase
+    M, gaps, used, ool = build_body()
+    seq = linearize(M, gaps)
+    check(seq + seq)
+    lines1, fifo1 = insert_waits(seq, carried_reads(M))
+    lines2, fifo2 = insert_waits(seq, fifo1)
+    assert lines1 == lines2 and [sorted(e["defs"]) for e in fifo1] == [sorted(e["defs"]) for e in fifo2], "loop is not in steady state"
+    assert [sorted(e["defs"]) for e in fifo1] == [sorted(e["defs"]) for e in carried_reads(M)], "the bodies must leave the same LDS queue"
+    nv = sum(1 for s in seq if s.kind in ("valu", "trans"))
+    nl = sum(1 for s in seq if s.kind == "lds")
+    print("body %s (%s): 64 MFMAs, %d vector (%d issue units, busiest gap %d), %d LDS reads, %d asm lines" % (phase, "masked" if masked else "plain", nv, sum(used), max(used), nl, len(lines1)))
+    return M, lines1, ool
+
+
+def chain_block(M, ns, first_reads_issued, carried):
+    """a stretch of the body's MFMAs outside the loop (prologue: S(0) keys 0..31 = n 48..63; drain: O(last) keys 32..63 = n 0..15) with its own
+    LOOKAHEAD pipeline of A-operand reads; pairs < first_reads_issued have their reads in flight already (`carried`)"""
+    pairs = sorted({n // 2 for n in ns})
+    seq = []
+    la = LOOKAHEAD // 2
+    for k in range(first_reads_issued, min(la, len(pairs))):
+        seq += a_loads(M[2 * pairs[k]]["a"], pairs[k] % 8)
+    for k, m in enumerate(pairs):
+        seq.append(mfma_ins(2 * m, M[2 * m]))
+        seq.append(mfma_ins(2 * m + 1, M[2 * m + 1]))
+        if k + la < len(pairs):
+            seq += a_loads(M[2 * pairs[k + la]]["a"], pairs[k + la] % 8)
+    lines, fifo = insert_waits(seq, carried)
+    return lines, fifo
+
+
+STAMP = False
+
+
+def stamp(k):
+    """diagnostic builds (sdpa_fwd3_loop_stamp.inc, -DHALVA_STAMP): the low word of s_memtime into output operand st<k>"""
+    return ["s_memtime s[68:69]", "s_waitcnt lgkmcnt(0)", "v_mov_b32_e32 %%[st%d], s68" % k] if STAMP else []
+
+
+def main():
+    global STAMP
+    STAMP = False
+    emit(os.environ.get("FWD3_OUT", "sdpa_fwd3_loop.inc"))
+    STAMP = True
+    emit(os.environ.get("FWD3_OUT", "sdpa_fwd3_loop.inc").replace(".inc", "_stamp.inc"))
+
+
+def emit(out):
+    global MASKED, PHASE
+    M, body_p, ool_p = variant(False, "b")
+    _, body_m, ool_m = variant(True, "m")
+    L = []
+    # ---------------- entry: scalars, first requests
+    L += stamp(0)
+    L += ["s_mov_b32 %s, m0" % S_M0SAVE]
+    L += ["v_readfirstlane_b32 s%d, %%[k_lo]" % KP[0], "v_readfirstlane_b32 s%d, %%[k_hi]" % KP[1], "s_mov_b64 %s, %%[safe_k]" % sp(SAFEK), "s_nop 3",
+          "s_add_u32 s%d, s%d, %%[vdlo]" % (VP[0], KP[0]), "s_addc_u32 s%d, s%d, %%[vdhi]" % (VP[1], KP[1]),             # V rows = K rows + (v - k)
+          "s_add_u32 s%d, s%d, %%[vdlo]" % (SAFEV[0], SAFEK[0]), "s_addc_u32 s%d, s%d, %%[vdhi]" % (SAFEV[1], SAFEK[1])]
+    L += ["s_and_b32 %s, %%[ctl], 3" % S_T,                                   # ring slot of tile 0
+          "s_bfe_u32 %s, %%[ctl], 0x10002" % S_PART,
+          "s_bfe_u32 %s, %%[ctl], 0x20005" % S_NPF,                              # tiles of the next item to request behind this item's last
+          "s_and_b32 %s, %%[nreq], 0xffff" % S_RLEFT,
+          "s_lshr_b32 %s, %%[nreq], 16" % S_TOJUMP, "s_cmp_eq_u32 %s, 0xffff" % S_TOJUMP, "s_cselect_b32 %s, -1, %s" % (S_TOJUMP, S_TOJUMP),
+          "s_nop 3"]
+    ool_pro = []
+    # ctl bit 4: the previous item's block has requested this item's tiles 0..2 already (nreq / k / v then describe the walk from tile 3 on)
+    L += ["s_bitcmp1_b32 %[ctl], 4", "s_cbranch_scc1 .Lf3_noreq_%="]
+    for i in range(3):      # tiles 0..2 of the walk into slots S_T + i (the caller has passed the barrier behind the previous item's last reads)
+        pre, groups, post, ool = request_tile("p%d" % i, i)
+        L += pre
+        for g in groups:
+            L += g
+        L += post
+        ool_pro += ool
+    L += [".Lf3_noreq_%=:"]
+    L += stamp(1)
+    # ---------------- while they fly: zero O^T, state
+    L += ["v_mov_b32_e32 v%d, 0" % (RING + j) for j in range(4)] + ["s_nop 4"]
+    for o in range(8):
+        L += ["v_mfma_f32_32x32x16_bf16 %%[o%d], v[%d:%d], v[%d:%d], 0" % (o, RING, RING + 3, RING, RING + 3)]
+    for g in (0, 1):
+        L += ["v_mov_b32_e32 v%d, 0" % (PB[(g, 1)] + i) for i in range(8)]
+        L += ["v_mov_b32_e32 v%d, 0" % (L2[g] + i) for i in range(4)] + ["v_mov_b32_e32 v%d, 0xff800000" % MX[g]]
+    L += ["v_mov_b32_e32 v%d, 0xff800000" % V_NINF]
+    L += ["s_and_b32 %s, %s, 3" % (S_TMP, S_T), "s_lshl_b32 %s, %s, 14" % (S_TOFFK, S_TMP), "s_mov_b32 %s, %s" % (S_TOFFV, S_TOFFK)]      # V "tile -1" := tile 0's slot (finite data; its P is zero)
+    L += [i.text for i in k_addr_from_toff()] + [i.text for i in v_addr_from_toff()]
+    # ---------------- Q fragments (16 loads in front of the requests) and tile 0 have landed: the 16 requests of tiles 1, 2 may stay in flight
+    L += stamp(2)
+    # (an item prepared by its predecessor's block - tiles 0..2 from its last iterations, then the Q loads: only the rows the predecessor stored
+    # behind them may stay in flight - 18 store instructions when every row group had a row to store (ctl bit 7), else everything has to land)
+    L += ["s_bitcmp1_b32 %[ctl], 4", "s_cbranch_scc1 .Lf3_pfwait_%=", "s_waitcnt vmcnt(16)", "s_branch .Lf3_landed_%=", ".Lf3_pfwait_%=:",
+          "s_bitcmp1_b32 %[ctl], 7", "s_cbranch_scc1 .Lf3_pfwait18_%=", "s_waitcnt vmcnt(0)", "s_branch .Lf3_landed_%=", ".Lf3_pfwait18_%=:", "s_waitcnt vmcnt(18)",
+          ".Lf3_landed_%=:", "s_barrier"]
+    L += stamp(3)
+    lines, fifo = chain_block(M, range(48, 64), 0, [])      # S(0), keys 0..31
+    assert not fifo
+    L += lines
+    L += ["s_nop 7", "s_nop 7", "s_nop 7"]
+    # its mask (always applied here: rsP = 64 passes everything) and the reference: m_ref = sc * max over the half tile (0 for a lane that sees nothing)
+    # (which: ctl bits 8-9 - 0: the first tile is a plain one (64 passes everything), 1: it opens masked run 1, 2: masked run 2)
+    L += ["s_bfe_u32 %s, %%[ctl], 0x20008" % S_TMP, "v_mov_b32_e32 v%d, 64" % RANGE[0], "v_mov_b32_e32 v%d, 64" % RANGE[1],
+          "s_cmp_eq_u32 %s, 1" % S_TMP, "s_cbranch_scc0 .Lf3_rsp1_%=", "v_mov_b32_e32 v%d, %%[rsA]" % RANGE[0], "v_mov_b32_e32 v%d, %%[rsA]" % RANGE[1], ".Lf3_rsp1_%=:",
+          "s_cmp_eq_u32 %s, 2" % S_TMP, "s_cbranch_scc0 .Lf3_rsp2_%=", "v_mov_b32_e32 v%d, %%[rsB0]" % RANGE[0], "v_mov_b32_e32 v%d, %%[rsB1]" % RANGE[1], ".Lf3_rsp2_%=:"]
+    MASKED = True
+    for g in (0, 1):
+        L += [i.text.replace("\\n\\t", "\n") for i in mask_ops(g, 0, RANGE[g])]
+    MASKED = False
+    L = [x for l in L for x in l.split("\n")]
+    L += ["s_bitcmp1_b32 %[ctl], 3", "s_cbranch_scc1 .Lf3_mrgiven_%="]
+    for g, t in ((0, V_T0), (1, V_T1)):
+        x = XS[(g, 0)]
+        L += ["v_max3_f32 v%d, v%d, v%d, v%d" % (t, x, x + 1, V_NINF)] + ["v_max3_f32 v%d, v%d, v%d, v%d" % (t, x + 2 * i, x + 2 * i + 1, t) for i in range(1, 8)]
+        L += ["v_mov_b32_e32 v%d, v%d" % (MREF[g], t), "s_nop 1", "v_permlane32_swap_b32_e32 v%d, v%d" % (t, MREF[g]), "s_nop 1",
+              "v_max_f32_e32 v%d, v%d, v%d" % (t, t, MREF[g]), "v_mul_f32_e32 v%d, %%[sc], v%d" % (MREF[g], t),
+              "v_cmp_lt_f32_e32 vcc, v%d, v%d" % (V_NINF, MREF[g]), "v_cndmask_b32_e32 v%d, 0, v%d, vcc" % (MREF[g], MREF[g])]
+    L += ["s_branch .Lf3_mrdone_%=", ".Lf3_mrgiven_%=:", "v_mov_b32_e32 v%d, %%[mri0]" % MREF[0], "v_mov_b32_e32 v%d, %%[mri1]" % MREF[1], ".Lf3_mrdone_%=:"]
+    # the loop's first A operands
+    for c in range(LOOKAHEAD // 2):
+        L += [l.text for l in a_loads(M[2 * c]["a"], c % 8)]
+    L += stamp(4)
+    # ---------------- the item's iterations: [plain n0][masked n1 from rsA][plain n2][masked n3 from rsB]
+    L += ["s_mov_b32 %s, 0" % S_SEG, ".Lf3_seg_%=:", "s_cmp_eq_u32 %s, 0" % S_SEG, "s_cselect_b32 %s, %%[n01], %%[n23]" % S_FLD,
+          "s_and_b32 %s, %s, 0xffff" % (S_CNT, S_FLD), "s_cmp_eq_u32 %s, 0" % S_CNT, "s_cbranch_scc1 .Lf3_noplain_%=", ".Lf3_plain_%=:"]
+    L += body_p
+    L += ["s_sub_u32 %s, %s, 1" % (S_CNT, S_CNT), "s_cmp_lg_u32 %s, 0" % S_CNT, "s_cbranch_scc1 .Lf3_plain_%=", ".Lf3_noplain_%=:",
+          "s_lshr_b32 %s, %s, 16" % (S_CNT, S_FLD), "s_cmp_eq_u32 %s, 0" % S_CNT, "s_cbranch_scc1 .Lf3_nomasked_%=",
+          "s_cmp_eq_u32 %s, 0" % S_SEG, "s_cbranch_scc0 .Lf3_rsb_%=",
+          "v_mov_b32_e32 v%d, %%[rsA]" % RANGE[0], "v_mov_b32_e32 v%d, %%[rsA]" % RANGE[1], "s_branch .Lf3_masked_%=",
+          ".Lf3_rsb_%=:", "v_mov_b32_e32 v%d, %%[rsB0]" % RANGE[0], "v_mov_b32_e32 v%d, %%[rsB1]" % RANGE[1], ".Lf3_masked_%=:"]
+    L += body_m
+    L += ["s_sub_u32 %s, %s, 1" % (S_CNT, S_CNT), "s_cmp_lg_u32 %s, 0" % S_CNT, "s_cbranch_scc1 .Lf3_masked_%=", ".Lf3_nomasked_%=:",
+          "s_add_u32 %s, %s, 1" % (S_SEG, S_SEG), "s_cmp_lt_u32 %s, 2" % S_SEG, "s_cbranch_scc1 .Lf3_seg_%="]
+    L += stamp(5)
+    # ---------------- drain: O(last), keys 32..63 (its first A operands are in flight)
+    lines, fifo = chain_block(M, range(0, 16), LOOKAHEAD // 2, carried_reads(M))
+    L += lines
+    L += ["s_branch .Lf3_end_%="] + ool_pro + ool_p + ool_m + [".Lf3_end_%=:", "s_waitcnt lgkmcnt(0)", "s_mov_b32 m0, %s" % S_M0SAVE]
+    for g in (0, 1):
+        L += ["v_pk_add_f32 %s, %s, %s" % (vr(L2[g], 2), vr(L2[g], 2), vr(L2[g] + 2, 2)), "v_add_f32_e32 %%[l%d], v%d, v%d" % (g, L2[g], L2[g] + 1),
+              "v_mov_b32_e32 %%[mx%d], v%d" % (g, MX[g]), "v_mov_b32_e32 %%[mr%d], v%d" % (g, MREF[g])]
+    L += stamp(6)
+    L = [x for l in L for x in l.replace("\\n\\t", "\n").split("\n")]
+    diag = os.environ.get("FWD3_DIAG", "")      # timing experiments only (results are wrong): nodma / nobar, comma separated
+    if "nodma" in diag:
+        L = [l for l in L if not l.startswith("global_load_lds")]
+    if "nobar" in diag:
+        L = [l for l in L if l != "s_barrier" and not l.startswith("s_waitcnt vmcnt")]
+    with open(out, "w") as f:
+        f.write("// generated by gen_fwd3_loop.py - do not edit (python3 gen_fwd3_loop.py)\n")
+        for l in L:
+            f.write('"%s\\n\\t"\n' % l)
+    with open(out.replace(".inc", "_clobbers.inc"), "w") as f:
+        f.write("// generated by gen_fwd3_loop.py - do not edit\n")
+        f.write(", ".join('"v%d"' % i for i in range(64, V_LAST + 1)) + ",\n" + ", ".join('"s%d"' % i for i in range(S_FIRST - 2, S_LAST + 1)) + ', "vcc", "scc", "memory"\n')
+    print("%s: %d asm lines" % (out, len(L)))
+
+
+if __name__ == "__main__":
+    main()

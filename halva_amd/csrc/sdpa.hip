@@ -1596,6 +1596,7 @@ __global__ __launch_bounds__(512) void sdpa_bwd_dq2_kernel(const SdpaParams p) {
 }
 
 #include "sdpa_dkv3.h"
+#include "sdpa_fwd3.h"
 
 // HALVA_SDPA_DKV3=0: the two-role dK/dV kernel of rounds 1-2 instead of sdpa_bwd_dkv3; HALVA_DKV3_ASM=0: sdpa_bwd_dkv3 with every step in
 // plain HIP (the generated loop off) - A/B and debugging switches, read on every call like the one below.
@@ -1646,6 +1647,39 @@ int launch_one(KernelT kern, SdpaParams p, bool causal, int rows_per_block, int 
     return HALVA_OK;
 }
 
+// sdpa_fwd3: 4 waves, one per SIMD (512 registers), 256 query rows per workgroup, 129 KiB of LDS (four K / V tile slots); persistent
+// workgroups, one per CU, over the virtual blocks of the static launch (sdpa_fwd3.h)
+int launch_fwd3(SdpaParams p, int S, hipStream_t st) {
+    p.nblk = (p.T + 255) / 256;
+    p.npairs = S * p.H;
+    static std::atomic<int> attr_set[64];
+    static std::atomic<int> n_cu[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const bool slot = dev >= 0 && dev < 64;
+    if (!slot || !attr_set[dev].load(std::memory_order_acquire)) {
+        const hipError_t ea = hipFuncSetAttribute((const void*)sdpa_fwd3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD3_LDS);
+        if (ea != hipSuccess) {
+            halva_set_error("sdpa_fwd3: hipFuncSetAttribute(%d B of LDS) failed: %s", FWD3_LDS, hipGetErrorString(ea));
+            return HALVA_ERR_LAUNCH;
+        }
+        if (slot) attr_set[dev].store(1, std::memory_order_release);
+    }
+    int cus = slot ? n_cu[dev].load(std::memory_order_acquire) : 0;
+    if (cus == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        if (slot) n_cu[dev].store(cus, std::memory_order_release);
+    }
+    {
+        const char* e = getenv("HALVA_FWD3_GRID");      // diagnostic: workgroups of the persistent launch (0 = one per virtual block: no pipelining across items)
+        if (e) cus = atoi(e) > 0 ? atoi(e) : (1 << 30);
+    }
+    const int64_t total = (int64_t)((p.nblk + 1) / 2) * p.npairs;
+    hipLaunchKernelGGL((sdpa_fwd3_kernel<true>), dim3((unsigned)std::min<int64_t>(total, cus)), dim3(256), FWD3_LDS, st, p);
+    HALVA_CHECK_LAUNCH("sdpa_fwd3");
+    return HALVA_OK;
+}
+
 template <int D, bool CAUSAL>
 int launch_fwd(const SdpaParams& p_in, int S, hipStream_t st) {
     const size_t lds = 4 * 64 * D * 2;
@@ -1653,6 +1687,12 @@ int launch_fwd(const SdpaParams& p_in, int S, hipStream_t st) {
 #ifdef HALVA_STAMP
     p.dbg = halva_dbg_buffer();
 #endif
+    if constexpr (D == 128 && CAUSAL) {
+        // sdpa_fwd3: one wave per SIMD, the tile loop in generated asm (sdpa_fwd3.h).  HALVA_SDPA_FWD3=0: the two-waves-per-SIMD kernel of
+        // rounds 1-3 (A/B and debugging switch, read on every call).  (Its tile counts travel as 16-bit fields; its dummy requests read the
+        // tensors' first 64 rows.)
+        if (!slow_tr_requested() && (int64_t)S * p.T >= 64 && p.T < (1 << 21) && env_flag_on("HALVA_SDPA_FWD3")) return launch_fwd3(p, S, st);
+    }
     return slow_tr_requested() ? launch_one(sdpa_fwd_kernel<D, CAUSAL, true>, p, CAUSAL, 256, 512, lds, S, st, "sdpa_fwd")
                                : launch_one(sdpa_fwd_kernel<D, CAUSAL, false>, p, CAUSAL, 256, 512, lds, S, st, "sdpa_fwd");
 }

@@ -1,0 +1,315 @@
+// sdpa_fwd3: the causal forward (head_dim 128) with ONE wave per SIMD - included by sdpa.hip inside its anonymous namespace.
+//
+// Replaces sdpa_fwd_kernel<128, true> for flash_attn_varlen_qkvpacked_func's forward (reference llava/train/llama_flash_attn_monkey_patch.py:85-91).
+// Why another structure: sdpa_fwd_kernel puts two 256-register waves of 32 query rows on every SIMD; they meet at the matrix pipe, in
+// their softmax stretches and at the tile's barrier in lock step: ~5 100 cycles per 64 MFMAs and SIMD for 2 048 cycles of matrix work (DESIGN
+// 6, 6b).  Here a workgroup is 4 waves = 256 query rows, a wave owns 64 rows (two groups of 32) with the Q fragments (64 registers) and the
+// O^T accumulators (128) in the accumulator file and runs the whole tile step itself, alone on its SIMD: S^T = K Q^T puts the QUERY on the
+// lane, so the softmax statistics need no cross-lane work inside the loop, and both groups share every K / V^T operand read from LDS.
+// hipcc cannot schedule that (experiments/fwd3: 3 565 cycles per step against 2 804 hand-placed), so every tile step of a row block runs
+// inside ONE generated inline-asm block (sdpa_fwd3_loop.inc <- gen_fwd3_loop.py): prologue (requests of the first three K / V tiles, zeroed
+// accumulators, the first score half-tile, the exponent reference), the iterations (plain | masked bodies), the last O product.
+// The exponent reference m_ref of a query is FIXED for the row block: P = exp2(S sc - m_ref), O^T and l accumulate un-rescaled (O^T lives in the
+// accumulator file, which the vector unit cannot touch), the running maximum is only tracked.  m_ref comes from the row's first 32 visible
+// keys; a later score may exceed it by 2^64 (RESCALE_AT of the two-wave kernel) before anything is lost.  In the rare case that one does, the
+// WHOLE row block is repeated with m_ref = the true row maximum, which the first pass has just measured exactly - no approximation, no other
+// kernel involved (test_sdpa_exponent_reference_moves_when_later_keys_dominate).
+// LDS: K ring [4][64][128] bf16 at 0, V ring at 64 KiB, 1 KiB dummy chunk (requests past the last tile), the workgroup's vote words.
+
+constexpr int FWD3_TILE = 64 * 128 * 2;
+constexpr int FWD3_DUMMY = 8 * FWD3_TILE;
+constexpr int FWD3_MAIL = FWD3_DUMMY + 1024;
+constexpr int FWD3_LDS = FWD3_MAIL + 64;
+constexpr float FWD3_RESCALE_AT = 64.f;      // log2 units
+
+// Everything the generated block needs to know about one (sequence, head, 256-row block) item; wave-uniform unless noted.
+struct Fwd3Geom {
+    int N;                 // tiles of the walk (0: the block sees no key)
+    int kv_first;          // first key of the first walked tile (local)
+    int n1req;             // requests before the walk's jump (0xffff: none)
+    int64_t jump_rows;     // rows the walk jumps over
+    int partial, lr;       // the last walked tile is the sequence's partial last tile: lr of its 64 rows exist
+    int n0, n1, n2, n3;    // per WAVE: [plain n0][masked n1][plain n2][masked n3]
+    int kvA, kvB;          // first key of the first tile of masked run 1 / 2
+    int wave_in_b, wq_min;
+};
+
+__device__ __forceinline__ Fwd3Geom fwd3_geom(const SdpaParams& p, int qb, int start, int len, const Branch& br, int wave) {
+    constexpr int BN = 64, BM = 256;
+    Fwd3Geom g;
+    const int g0 = qb * BM;
+    const int kv_end = min(len, g0 + BM - start);
+    const int ntiles = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
+    int skip_lo = ntiles, skip_hi = ntiles;
+    const bool wholly_b = g0 - start >= br.b;
+    if (wholly_b) {
+        skip_lo = min(ntiles, (br.a + BN - 1) / BN);
+        skip_hi = max(skip_lo, min(ntiles, br.b / BN));
+    }
+    g.N = skip_lo + (ntiles - skip_hi);
+    g.kv_first = skip_lo > 0 ? 0 : skip_hi * BN;
+    const bool jumps = skip_lo > 0 && skip_hi > skip_lo && skip_hi < ntiles;
+    g.n1req = jumps ? skip_lo : 0xffff;
+    g.jump_rows = jumps ? (int64_t)(skip_hi - skip_lo) * BN : 0;
+    const int last_kv0 = (skip_hi < ntiles ? ntiles - 1 : skip_lo - 1) * BN;      // (N > 0)
+    g.partial = g.N > 0 && last_kv0 + BN > len;
+    g.lr = g.partial ? len - last_kv0 : BN;
+    // this wave's rows: wq_min .. wq_min + 63 (local)
+    g.wq_min = g0 + 64 * wave - start;
+    g.wave_in_b = g.wq_min >= br.b;
+    int cntA = 0, kvB0 = 0;
+    if (g.wave_in_b) {      // the tiles in front of br.b are seen "up to br.a"
+        cntA = wholly_b ? skip_lo : min(ntiles, br.b / BN);
+        kvB0 = wholly_b ? skip_hi * BN : br.b;
+    }
+    const int cntB = g.N - cntA;
+    g.n0 = min(cntA, br.a / BN);
+    g.n1 = cntA - g.n0;
+    g.kvA = BN * g.n0;
+    const int fullB = min(len, g.wq_min + 1);      // keys every row of the wave sees
+    g.n2 = min(cntB, max(0, fullB - kvB0) / BN);
+    g.n3 = cntB - g.n2;
+    g.kvB = kvB0 + BN * g.n2;
+    return g;
+}
+
+// A workgroup's position in its static sequence of row blocks: virtual block vb = blockIdx.x + k * gridDim.x (the blocks the static launch of
+// sdpa_fwd_kernel would have started: map_block / paired_blocks - heavy block first, then the light one), all wave-uniform.
+struct Fwd3Cursor {
+    int vb, which, first, second, cur_qb, s, hd, start, len;
+    Branch br;
+    __device__ __forceinline__ int qb() const { return cur_qb; }      // (a stored scalar: `which ? second : first` was compiled into a scratch array)
+};
+__device__ __forceinline__ void fwd3_cursor_load(const SdpaParams& p, Fwd3Cursor& c, int total) {
+    if (c.vb >= total) return;
+    int b;
+    map_block(c.vb, (p.nblk + 1) / 2, p.H, p.npairs, false, c.s, c.hd, b);
+    // the sequence's geometry by SCALAR loads (they return through lgkmcnt): as vector loads the compiler waits for each of them with vmcnt(0) - it
+    // knows nothing of what the asm blocks have in flight -, i.e. for the rows just stored and the tiles requested for the next item
+    const int sq = (int)dkv3_uni((unsigned)c.s);
+    auto sload = [&](const int32_t* base, int dflt) {
+        if (base == nullptr) return dflt;
+        int v;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(dkv3_uni64(base + sq)) : "memory");
+        return v;
+    };
+    c.start = sload(p.seq_start, 0), c.len = sload(p.seq_len, p.T), c.br.a = sload(p.br_a, 0x7fffffff), c.br.b = sload(p.br_b, 0x7fffffff);
+    paired_blocks(p.nblk, c.start, c.br, b, c.first, c.second);
+    c.which = 0, c.cur_qb = c.first;
+}
+__device__ __forceinline__ void fwd3_cursor_advance(const SdpaParams& p, Fwd3Cursor& c, int total) {
+    if (c.which == 0 && c.second != c.first) {
+        c.which = 1, c.cur_qb = c.second;
+    } else {
+        c.vb += gridDim.x;
+        fwd3_cursor_load(p, c, total);
+    }
+}
+
+// The Q fragments of one item, asked for by hand straight into the registers the block reads them from (a row outside the sequence reads the
+// nearest one inside: its result is not stored): for the workgroup's first item in front of the loop, for every other one behind its
+// predecessor's block, in front of the predecessor's row stores.  Nobody waits for them before the block's own counted wait.
+__device__ __forceinline__ const bf16_t* fwd3_q_row(const SdpaParams& p, const Fwd3Cursor& c, int wave, int lane, int gi) {
+    const int ql = c.qb() * 256 + 64 * wave + 32 * gi + (lane & 31) - c.start;
+    return p.q + ((int64_t)c.s * p.T + c.start + min(max(ql, 0), max(c.len - 1, 0))) * p.ld_qkv + c.hd * 128 + 8 * (lane >> 5);
+}
+__device__ __forceinline__ void fwd3_load_q(u32x4 (&qf)[16], const bf16_t* q0, const bf16_t* q1) {
+    asm volatile(
+        "global_load_dwordx4 %0, %16, off\n\tglobal_load_dwordx4 %1, %16, off offset:32\n\tglobal_load_dwordx4 %2, %16, off offset:64\n\t"
+        "global_load_dwordx4 %3, %16, off offset:96\n\tglobal_load_dwordx4 %4, %16, off offset:128\n\tglobal_load_dwordx4 %5, %16, off offset:160\n\t"
+        "global_load_dwordx4 %6, %16, off offset:192\n\tglobal_load_dwordx4 %7, %16, off offset:224\n\t"
+        "global_load_dwordx4 %8, %17, off\n\tglobal_load_dwordx4 %9, %17, off offset:32\n\tglobal_load_dwordx4 %10, %17, off offset:64\n\t"
+        "global_load_dwordx4 %11, %17, off offset:96\n\tglobal_load_dwordx4 %12, %17, off offset:128\n\tglobal_load_dwordx4 %13, %17, off offset:160\n\t"
+        "global_load_dwordx4 %14, %17, off offset:192\n\tglobal_load_dwordx4 %15, %17, off offset:224"
+        : "={a[128:131]}"(qf[0]), "={a[132:135]}"(qf[1]), "={a[136:139]}"(qf[2]), "={a[140:143]}"(qf[3]), "={a[144:147]}"(qf[4]), "={a[148:151]}"(qf[5]),
+          "={a[152:155]}"(qf[6]), "={a[156:159]}"(qf[7]), "={a[160:163]}"(qf[8]), "={a[164:167]}"(qf[9]), "={a[168:171]}"(qf[10]), "={a[172:175]}"(qf[11]),
+          "={a[176:179]}"(qf[12]), "={a[180:183]}"(qf[13]), "={a[184:187]}"(qf[14]), "={a[188:191]}"(qf[15])
+        : "v"(q0), "v"(q1)
+        : "memory");
+}
+
+// One row block.  `parity` alternates between a workgroup's consecutive items (the vote words are double buffered).  nxt (valid: nxt.vb < total)
+// is the workgroup's next item: this item's block requests its first three K / V tiles from its last iterations (which have no tile of their
+// own left to ask for) when they are three whole ordinary tiles.  prefetched / ring_base: in - what the previous item did for this one; out - for the next.
+__device__ __forceinline__ void sdpa_fwd3_item(const SdpaParams& p, char* smem, const Fwd3Cursor& cur, const Fwd3Cursor& nxt, bool nxt_valid, bool& prefetched,
+                                               bool& stores18, int& ring_base, u32x4 (&qf)[16], int wave, int lane_in, int parity) {
+    constexpr int D = 128, BM = 256;
+#ifdef HALVA_STAMP
+    unsigned long long stamp_t0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t0)::"memory");
+#endif
+    typedef __attribute__((address_space(3))) volatile int LdsInt;
+    LdsInt* mail = (LdsInt*)(__attribute__((address_space(3))) char*)(smem + FWD3_MAIL);
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int h = lane >> 5, r = lane & 31;
+    const int s = cur.s, hd = cur.hd, qb = cur.qb(), start = cur.start, len = cur.len;
+    const Branch br = cur.br;
+    Fwd3Geom g = fwd3_geom(p, qb, start, len, br, wave);
+    const int N = (int)dkv3_uni((unsigned)g.N);
+    const int64_t seq_row0 = (int64_t)s * p.T;
+    const int g0 = qb * BM;
+    int ql[2];
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) ql[gi] = g0 + 64 * wave + 32 * gi + r - start;
+    // (a block that sees no key, N == 0, takes the same road: no iteration, O^T = 0, l = 0 -> zero rows; its requests go straight to the next item's tiles)
+    // ---- lane constants of the generated block (formed per item: kept across it they are spilled, and a scratch reload waits for every request in flight)
+    const unsigned rowrel = 2048 * (r >> 3) + 64 * (r & 7) + 16 * (h ^ ((r >> 2) & 3));
+    const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3, h2 = g16 >> 1;
+    const unsigned colrel = 64 * (4 * h2 + q4) + 16 * ((2 * (g16 & 1) + (pp >> 1)) ^ h2) + 8 * (pp & 1);
+    const unsigned voff = dkv3_piece_voff(p.ld_qkv, wave, lane, 0, 64);
+    unsigned alt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) alt[i] = dkv3_piece_voff(p.ld_qkv, wave, lane, i, g.lr);
+    // visible-key counts (minus the lane half's row offset 4 h) of the first tile of each masked run, and of the item's first tile
+    const int rsA = br.a - g.kvA - 4 * h;
+    int rsB[2];
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) rsB[gi] = min(len, ql[gi] + 1) - g.kvB - 4 * h;
+    const unsigned first_state = (g.n0 + g.n1 > 0) ? (g.n0 > 0 ? 0u : 1u) : (g.n2 > 0 ? 0u : 2u);      // the first tile: plain | opens masked run 1 | run 2
+    const float sc = p.scale * kLog2e;
+    const unsigned n01 = dkv3_uni((unsigned)g.n0 | ((unsigned)g.n1 << 16)), n23 = dkv3_uni((unsigned)g.n2 | ((unsigned)g.n3 << 16));
+    const unsigned long long jump = (unsigned long long)(g.jump_rows * p.ld_qkv * 2);
+    const unsigned jlo = dkv3_uni((unsigned)jump), jhi = dkv3_uni((unsigned)(jump >> 32));
+    const unsigned wave_u = dkv3_uni((unsigned)wave), piece = dkv3_uni((unsigned)(16 * p.ld_qkv * 2));
+    const bf16_t* kp = p.k + hd * D;
+    const unsigned long long safe_k = dkv3_uni64(kp);      // (the dummy requests read the tensor's first 64 rows: the launcher requires S * T >= 64)
+    const unsigned long long vdelta = (unsigned long long)((const char*)p.v - (const char*)p.k);
+    const unsigned vdlo = dkv3_uni((unsigned)vdelta), vdhi = dkv3_uni((unsigned)(vdelta >> 32));
+    // the walk as the block is to request it: from tile 0 (cold), or from tile 3 when the previous item's block has requested tiles 0..2
+    const bool pf = prefetched;
+    const int t_req = pf ? 3 : 0;
+    const unsigned nreq = dkv3_uni((unsigned)(N - t_req) | ((unsigned)(g.n1req == 0xffff ? 0xffff : g.n1req - t_req) << 16));
+    const unsigned long long k_ptr = (unsigned long long)(size_t)(kp + (seq_row0 + start + g.kv_first + 64 * t_req) * p.ld_qkv);
+    // the next item's first three tiles (requested by this block's last iterations when they are three whole ordinary tiles)
+    unsigned npf = 0;
+    unsigned long long nk_ptr = safe_k;
+    if (nxt_valid) {
+        const Fwd3Geom gn = fwd3_geom(p, nxt.qb(), nxt.start, nxt.len, nxt.br, wave);
+        if (gn.N >= 3 && (gn.n1req == 0xffff || gn.n1req >= 3) && !(gn.partial && gn.N <= 3)) {
+            npf = 3;
+            const int64_t nrow = (int64_t)nxt.s * p.T + nxt.start + gn.kv_first;
+            nk_ptr = (unsigned long long)(size_t)(p.k + nxt.hd * D + nrow * p.ld_qkv);
+        }
+    }
+    npf = dkv3_uni(npf);
+    const unsigned ctl0 = dkv3_uni((unsigned)((ring_base & 3) | (g.partial ? 4 : 0) | (pf ? 16 : 0) | ((pf && stores18) ? 128 : 0)) | (npf << 5) | (first_state << 8));
+
+    f32x16 acc[8];
+    float l[2], mx[2], mr[2];
+    float mri0 = 0.f, mri1 = 0.f;
+#ifdef HALVA_STAMP
+    unsigned st_[7];
+    unsigned long long tc_[6];
+    tc_[0] = stamp_t0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc_[1])::"memory");
+#endif
+#define FWD3_CTL ctl0
+#define FWD3_NREQ nreq
+#define FWD3_KPTR k_ptr
+#include "sdpa_fwd3_call.h"
+#undef FWD3_CTL
+#undef FWD3_NREQ
+#undef FWD3_KPTR
+#ifdef HALVA_STAMP
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc_[2])::"memory");
+#endif
+    int base_used = ring_base;
+    // ---- did any query's maximum outgrow its reference?  (workgroup-wide: the waves share the tile ring)
+    float mxs[2];
+    bool over = false;
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+        mxs[gi] = xhalf_max(mx[gi]) * sc;
+        over = over || (mxs[gi] > mr[gi] + FWD3_RESCALE_AT);
+    }
+    const int mine = __any(over) ? 1 : 0;
+    if (lane == 0) mail[4 * parity + wave] = mine;
+    // (the mail box is LDS: wait for the LDS write only; also: every wave is done with this pass's ring before anything is requested into it again)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int redo = (int)dkv3_uni((unsigned)(mail[4 * parity] | mail[4 * parity + 1] | mail[4 * parity + 2] | mail[4 * parity + 3]));
+#ifdef HALVA_STAMP
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc_[3])::"memory");
+#endif
+    if (__builtin_expect(redo != 0, 0)) {      // rare: the whole row block again, cold, against the true row maxima
+        mri0 = mxs[0] > -INFINITY ? mxs[0] : 0.f;
+        mri1 = mxs[1] > -INFINITY ? mxs[1] : 0.f;
+        const unsigned ctl1 = dkv3_uni((unsigned)((g.partial ? 4 : 0) | 8) | (npf << 5) | (first_state << 8));
+        const unsigned nreq1 = dkv3_uni((unsigned)N | ((unsigned)g.n1req << 16));
+        const unsigned long long k_ptr1 = (unsigned long long)(size_t)(kp + (seq_row0 + start + g.kv_first) * p.ld_qkv);
+        // (the first pass's requests for the next item's tiles must have landed before this pass requests into the same slots)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        base_used = 0;
+#define FWD3_CTL ctl1
+#define FWD3_NREQ nreq1
+#define FWD3_KPTR k_ptr1
+#include "sdpa_fwd3_call.h"
+#undef FWD3_CTL
+#undef FWD3_NREQ
+#undef FWD3_KPTR
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    // ---- the Q registers are free: the NEXT item's fragments, in front of this item's row stores (they land during the store tail; the next block
+    // waits for them with a COUNTED vmcnt that leaves exactly those stores in flight)
+    if (nxt_valid) fwd3_load_q(qf, fwd3_q_row(p, nxt, wave, lane, 0), fwd3_q_row(p, nxt, wave, lane, 1));
+#ifdef HALVA_STAMP
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc_[4])::"memory");
+#endif
+    prefetched = npf != 0;
+    ring_base = (base_used + N) & 3;
+    stores18 = g0 + 64 * wave + 32 < p.T;      // both row groups have a row to store: 2 x 8 row stores + 2 lse stores are issued below
+    // ---- the rows: O = O^T / l (the lane = row layout of store_rows_T), lse.  (Row numbers and pointers are formed HERE, from the lane number
+    // again: kept across the asm block they cost registers the block's operands need - spilled, and a scratch reload waits for every request in flight)
+    int lane2 = lane_in;
+    asm volatile("" : "+v"(lane2));
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+        const float l_tot = xhalf_sum(l[gi]);
+        const int gqs = g0 + 64 * wave + 32 * gi + (lane2 & 31), qls = gqs - start;
+        const bool in_T = gqs < p.T, valid = in_T && qls >= 0 && qls < len;
+        const float inv = (valid && l_tot > 0.f) ? 1.f / l_tot : 0.f;
+        if (in_T) {
+            const f32x16(&a4)[4] = *reinterpret_cast<const f32x16(*)[4]>(&acc[4 * gi]);
+            store_rows_T<D>(p.o + (seq_row0 + gqs) * p.ld_o + hd * D, a4, inv, true, lane2);
+            if ((lane2 >> 5) == 0 && p.lse) p.lse[((int64_t)s * p.H + hd) * p.T + gqs] = valid ? (mr[gi] + log2f(l_tot)) * kLn2 : 0.f;
+        }
+    }
+#ifdef HALVA_STAMP
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc_[5])::"memory");
+    if (p.dbg && lane == 0 && blockIdx.x % 9 == 0 && blockIdx.x / 9 < 30 && cur.vb < (int)(2 * gridDim.x)) {      // slot: [block][item][wave][16]: the first four items
+        unsigned long long* o_ = p.dbg + (((blockIdx.x / 9) * 4 + 2 * (cur.vb >= (int)gridDim.x) + cur.which) * 4 + wave) * 16;
+        for (int i = 0; i < 6; ++i) o_[i] = tc_[i];
+        for (int i = 0; i < 7; ++i) o_[6 + i] = st_[i];
+        o_[13] = (unsigned long long)N | ((unsigned long long)qb << 16) | ((unsigned long long)blockIdx.x << 32);
+        o_[14] = (unsigned long long)g.n0 | ((unsigned long long)g.n1 << 16) | ((unsigned long long)g.n2 << 32) | ((unsigned long long)g.n3 << 48);
+    }
+#endif
+}
+
+// Persistent workgroups, one per CU: workgroup w walks the virtual blocks w, w + G, w + 2 G, ... of the static launch (two row blocks each, ranked by
+// work: heavy with light), so that the blocks of one (sequence, head) pair - which stream the same K / V - still run side by side on one XCD, and
+// pipelines across them: an item's last iterations request the next item's first tiles.
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void sdpa_fwd3_kernel(const SdpaParams p) {
+    static_assert(CAUSAL, "sdpa_fwd3 is the causal head_dim-128 instantiation");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int total = ((p.nblk + 1) / 2) * p.npairs;
+    WG_CLOCK_BEGIN();
+    Fwd3Cursor cur;
+    cur.vb = blockIdx.x;
+    fwd3_cursor_load(p, cur, total);
+    bool prefetched = false, stores18 = false;
+    int ring_base = 0, parity = 0;
+    u32x4 qf[16];      // the Q fragments, in a[128:191] from here on: loaded here for the first item, by every block for its successor
+    if (cur.vb < total) fwd3_load_q(qf, fwd3_q_row(p, cur, wave, lane, 0), fwd3_q_row(p, cur, wave, lane, 1));
+#pragma unroll 1
+    while (cur.vb < total) {
+        Fwd3Cursor nxt = cur;
+        fwd3_cursor_advance(p, nxt, total);
+        sdpa_fwd3_item(p, smem, cur, nxt, nxt.vb < total, prefetched, stores18, ring_base, qf, wave, lane, parity);
+        cur = nxt;
+        parity ^= 1;
+    }
+    WG_CLOCK_END(p.dbg, 0);
+}
