@@ -49,10 +49,12 @@ RING = 176
 KRE, KRO, VC0, VC1 = 208, 209, 210, 211
 V_LAST = 215
 S_T, S_CNT, S_TMP, S_TMP2, S_TOFFK, S_TOFFV, S_M0SAVE, S_DST = "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77"
-S_RLEFT, S_TOJUMP, S_ISSUED, S_USEALT, S_SEG, S_FLD, S_PART, S_NPF = "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85"
-KP, VP, KORG, VORG, SRC, SAFEK, SAFEV = (86, 87), (88, 89), (90, 91), (92, 93), (94, 95), (96, 97), (98, 99)
-S_FIRST, S_LAST = 70, 99      # (s85 = S_NPF)
-K_LDS, V_LDS, DUMMY_LDS = 0, 65536, 131072
+S_RLEFT, S_TOJUMP, S_SEG, S_FLD, S_NPF = "s78", "s79", "s82", "s83", "s85"
+S_SOFFK, S_SOFFV, S_SOFF0 = "s86", "s87", "s92"
+DESC, DESC0, SRC = (88, 91), (96, 99), (94, 95)      # the K / V buffer descriptor of the walk (four SGPRs, aligned), the item's own (kept for the repeat), a scratch pair
+S_REDO, S_PF = "s66", "s67"
+S_FIRST, S_LAST = 70, 99
+K_LDS, V_LDS, MAIL_LDS = 0, 65536, 131072      # MAIL_LDS = FWD3_MAIL (sdpa_fwd3.h)
 WAIT_GAP, V_UPD_GAP = 25, 9
 DMA_PRE_GAPS, DMA_GAPS = [26, 27, 28, 29, 30, 31], [32, 33, 34, 35, 36, 37, 38, 39]
 MASKED, PHASE = False, "p"
@@ -175,38 +177,34 @@ def addr_update(which):
     return [Ins("s_add_u32 %s, %s, 1" % (S_T, S_T), "salu"), Ins("s_and_b32 %s, %s, 3" % (S_TMP, S_T), "salu"), Ins("s_lshl_b32 %s, %s, 14" % (S_TOFFK, S_TMP), "salu")] + k_addr_from_toff()
 
 
+def sq(quad):
+    return "s[%d:%d]" % quad
+
+
 def request_tile(tag, dst_plus):
-    """(pre, [8 piece groups], post, out-of-line) - instruction texts - of ONE tile request: the next tile of the walk (or a dummy when none is
-    left) into ring slot (S_T + dst_plus) & 3.  Without a taken branch on the common path."""
+    """(pre, [8 piece groups], post, out-of-line) - instruction texts - of ONE tile request: the next tile of the walk into ring slot
+    (S_T + dst_plus) & 3, by `buffer_load_dwordx4 ... offen lds` through a descriptor that spans the sequence's K / V rows [start, start + len) of
+    this head: a row beyond the sequence arrives as ZEROS (the range check covers the scalar offset - experiments/fwd3/oob_probe.hip), so
+    neither the partial last tile nor a request past the walk's end needs a case of its own.  Three instructions per 1-KiB piece."""
     # no tile of this item left: the requests go on with the workgroup's NEXT item's first tiles (S_NPF of them; same slot rotation, so that item
-    # simply starts on a rotated ring with its first tiles under way), then to the dummy chunk
+    # simply starts on a rotated ring with its first tiles under way)
     pre = ["s_cmp_eq_u32 %s, 0" % S_RLEFT, "s_cbranch_scc1 .Lf3_sw%s_%%=" % tag, ".Lf3_swb%s_%%=:" % tag,
            "s_add_u32 %s, %s, %d" % (S_DST, S_T, dst_plus), "s_and_b32 %s, %s, 3" % (S_DST, S_DST), "s_lshl_b32 %s, %s, 14" % (S_DST, S_DST),
            "s_lshl_b32 %s, %%[wave], 10" % S_TMP2, "s_add_u32 %s, %s, %s" % (S_DST, S_DST, S_TMP2),
-           "s_min_u32 %s, %s, 1" % (S_ISSUED, S_RLEFT),
-           "s_cmp_eq_u32 %s, 1" % S_RLEFT, "s_cselect_b32 %s, %s, 0" % (S_USEALT, S_PART),
-           "s_cmp_eq_u32 %s, 0" % S_TOJUMP, "s_cselect_b32 %s, %%[jlo], 0" % S_TMP, "s_cselect_b32 %s, %%[jhi], 0" % S_TMP2,
-           "s_add_u32 s%d, s%d, %s" % (KP[0], KP[0], S_TMP), "s_addc_u32 s%d, s%d, %s" % (KP[1], KP[1], S_TMP2),
-           "s_add_u32 s%d, s%d, %s" % (VP[0], VP[0], S_TMP), "s_addc_u32 s%d, s%d, %s" % (VP[1], VP[1], S_TMP2),
-           "s_sub_u32 %s, %s, 1" % (S_TOJUMP, S_TOJUMP),
-           "s_mov_b64 %s, %s" % (sp(KORG), sp(KP)), "s_mov_b64 %s, %s" % (sp(VORG), sp(VP))]
+           "s_cmp_eq_u32 %s, 0" % S_TOJUMP, "s_cselect_b32 %s, %%[jlo], 0" % S_TMP, "s_add_u32 %s, %s, %s" % (S_SOFFK, S_SOFFK, S_TMP),      # the walk's jump
+           "s_sub_u32 %s, %s, 1" % (S_TOJUMP, S_TOJUMP), "s_sub_u32 %s, %s, 1" % (S_RLEFT, S_RLEFT),
+           "s_add_u32 %s, %s, %%[vdlo]" % (S_SOFFV, S_SOFFK),                                                                                  # V rows = K rows + (v - k)
+           "s_mov_b32 m0, %s" % S_DST]
     groups = []
-    ool = [".Lf3_sw%s_%%=:" % tag, "s_cmp_eq_u32 %s, 0" % S_NPF, "s_cbranch_scc1 .Lf3_swb%s_%%=" % tag,
-           "v_readfirstlane_b32 s%d, %%[nk_lo]" % KP[0], "v_readfirstlane_b32 s%d, %%[nk_hi]" % KP[1],
-           "s_mov_b32 %s, %s" % (S_RLEFT, S_NPF), "s_mov_b32 %s, 0" % S_NPF, "s_mov_b32 %s, 0" % S_PART, "s_mov_b32 %s, -1" % S_TOJUMP,
-           "s_nop 3", "s_add_u32 s%d, s%d, %%[vdlo]" % (VP[0], KP[0]), "s_addc_u32 s%d, s%d, %%[vdhi]" % (VP[1], KP[1]), "s_branch .Lf3_swb%s_%%=" % tag]
-    k = 0
-    for ptr, org, base, safe in ((KP, KORG, K_LDS, SAFEK), (VP, VORG, V_LDS, SAFEV)):
+    for soff, base in ((S_SOFFK, K_LDS), (S_SOFFV, V_LDS)):
         for i in range(4):
-            g = ["s_add_u32 %s, %s, %d" % (S_TMP, S_DST, base + 4096 * i), "s_cmp_lg_u32 %s, 0" % S_ISSUED, "s_cselect_b32 m0, %s, %d" % (S_TMP, DUMMY_LDS),
-                 "s_cselect_b64 %s, %s, %s" % (sp(SRC), sp(ptr), sp(safe)), "s_cmp_lg_u32 %s, 0" % S_USEALT, "s_cbranch_scc1 .Lf3_a%d%s_%%=" % (k, tag),
-                 "global_load_lds_dwordx4 %%[voff], %s" % sp(SRC), ".Lf3_j%d%s_%%=:" % (k, tag),
-                 "s_add_u32 s%d, s%d, %%[piece]" % (ptr[0], ptr[0]), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])]
-            ool += [".Lf3_a%d%s_%%=:" % (k, tag), "global_load_lds_dwordx4 %%[alt%d], %s" % (i, sp(org)), "s_branch .Lf3_j%d%s_%%=" % (k, tag)]
+            g = (["s_add_u32 m0, %s, %d" % (S_DST, V_LDS), "s_nop 0"] if (base and i == 0) else [])
+            g += ["buffer_load_dwordx4 %%[voff], %s, %s offen lds" % (sq(DESC), soff), "s_add_u32 %s, %s, %%[piece]" % (soff, soff), "s_add_u32 m0, m0, 4096"]
             groups.append(g)
-            k += 1
-    post = ["s_sub_u32 %s, %s, %s" % (S_RLEFT, S_RLEFT, S_ISSUED)]
-    return pre, groups, post, ool
+    ool = [".Lf3_sw%s_%%=:" % tag, "s_mov_b32 %s, 0x7fffffff" % S_RLEFT, "s_cmp_eq_u32 %s, 0" % S_NPF, "s_cbranch_scc1 .Lf3_swb%s_%%=" % tag,
+           "v_readfirstlane_b32 s%d, %%[nk_lo]" % DESC[0], "v_readfirstlane_b32 s%d, %%[nk_hi]" % (DESC[0] + 1), "v_readfirstlane_b32 s%d, %%[nnrec]" % (DESC[0] + 2),
+           "v_readfirstlane_b32 %s, %%[nsoff0]" % S_SOFFK, "s_mov_b32 %s, 0" % S_NPF, "s_mov_b32 %s, -1" % S_TOJUMP, "s_nop 3", "s_branch .Lf3_swb%s_%%=" % tag]
+    return pre, groups, [], ool
 
 
 def build_body():
@@ -362,22 +360,34 @@ def emit(out):
     M, body_p, ool_p = variant(False, "b")
     _, body_m, ool_m = variant(True, "m")
     L = []
-    # ---------------- entry: scalars, first requests
+    # ---------------- entry
     L += stamp(0)
-    L += ["s_mov_b32 %s, m0" % S_M0SAVE]
-    L += ["v_readfirstlane_b32 s%d, %%[k_lo]" % KP[0], "v_readfirstlane_b32 s%d, %%[k_hi]" % KP[1], "s_mov_b64 %s, %%[safe_k]" % sp(SAFEK), "s_nop 3",
-          "s_add_u32 s%d, s%d, %%[vdlo]" % (VP[0], KP[0]), "s_addc_u32 s%d, s%d, %%[vdhi]" % (VP[1], KP[1]),             # V rows = K rows + (v - k)
-          "s_add_u32 s%d, s%d, %%[vdlo]" % (SAFEV[0], SAFEK[0]), "s_addc_u32 s%d, s%d, %%[vdhi]" % (SAFEV[1], SAFEK[1])]
-    L += ["s_and_b32 %s, %%[ctl], 3" % S_T,                                   # ring slot of tile 0
-          "s_bfe_u32 %s, %%[ctl], 0x10002" % S_PART,
+    L += ["s_mov_b32 %s, m0" % S_M0SAVE,
+          "v_readfirstlane_b32 s%d, %%[k_lo]" % DESC0[0], "v_readfirstlane_b32 s%d, %%[k_hi]" % (DESC0[0] + 1), "v_readfirstlane_b32 s%d, %%[nrec]" % (DESC0[0] + 2),
+          "s_mov_b32 s%d, 0x00020000" % (DESC0[0] + 3), "v_readfirstlane_b32 %s, %%[soff0]" % S_SOFF0,
+          "s_bfe_u32 %s, %%[ctl], 0x10004" % S_PF, "s_mov_b32 %s, 0" % S_REDO]
+    # the NEXT item's Q fragments, into the staging registers a[192:255]: they have the whole item to land and move into a[128:191] on the way out
+    # (16 loads of 64 rows x 32 bytes each: slow to issue - ~150 cycles apiece - and, issued in front of an item's row stores, they held those up too)
+    for g in (0, 1):
+        for ks in range(8):
+            r0 = 192 + 32 * g + 4 * ks
+            L += ["global_load_dwordx4 a[%d:%d], %%[nq%d], off%s" % (r0, r0 + 3, g, (" offset:%d" % (32 * ks)) if ks else "")]
+    # ---------------- one pass over the item (re-entered once, with S_REDO = 1, when a row maximum outgrew its reference)
+    L += [".Lf3_pass_%=:", "s_mov_b64 s[%d:%d], s[%d:%d]" % (DESC[0], DESC[0] + 1, DESC0[0], DESC0[0] + 1), "s_mov_b64 s[%d:%d], s[%d:%d]" % (DESC[0] + 2, DESC[0] + 3, DESC0[0] + 2, DESC0[0] + 3),
+          "s_mov_b32 %s, %s" % (S_SOFFK, S_SOFF0),
+          "s_and_b32 %s, %%[ctl], 3" % S_T,                                   # ring slot of tile 0
           "s_bfe_u32 %s, %%[ctl], 0x20005" % S_NPF,                              # tiles of the next item to request behind this item's last
-          "s_and_b32 %s, %%[nreq], 0xffff" % S_RLEFT,
-          "s_lshr_b32 %s, %%[nreq], 16" % S_TOJUMP, "s_cmp_eq_u32 %s, 0xffff" % S_TOJUMP, "s_cselect_b32 %s, -1, %s" % (S_TOJUMP, S_TOJUMP),
-          "s_nop 3"]
+          "s_and_b32 %s, %%[nreq], 0xffff" % S_RLEFT, "s_lshr_b32 %s, %%[nreq], 16" % S_TOJUMP,
+          # the repeat walks from tile 0 whatever the call said: give the three tiles the predecessor had requested back to the walk
+          "s_bitcmp1_b32 %[ctl], 4", "s_cselect_b32 %s, 3, 0" % S_TMP, "s_cmp_eq_u32 %s, 0" % S_REDO, "s_cselect_b32 %s, 0, %s" % (S_TMP, S_TMP),
+          "s_add_u32 %s, %s, %s" % (S_RLEFT, S_RLEFT, S_TMP),
+          "s_cmp_eq_u32 %s, 0xffff" % S_TOJUMP, "s_cselect_b32 %s, 0, %s" % (S_TMP2, S_TMP), "s_add_u32 %s, %s, %s" % (S_TOJUMP, S_TOJUMP, S_TMP2),
+          "s_cmp_eq_u32 %s, 0xffff" % S_TOJUMP, "s_cselect_b32 %s, -1, %s" % (S_TOJUMP, S_TOJUMP),
+          "s_mul_i32 %s, %%[piece], %s" % (S_TMP2, S_TMP), "s_lshl_b32 %s, %s, 2" % (S_TMP2, S_TMP2), "s_sub_u32 %s, %s, %s" % (S_SOFFK, S_SOFFK, S_TMP2)]
     ool_pro = []
-    # ctl bit 4: the previous item's block has requested this item's tiles 0..2 already (nreq / k / v then describe the walk from tile 3 on)
-    L += ["s_bitcmp1_b32 %[ctl], 4", "s_cbranch_scc1 .Lf3_noreq_%="]
-    for i in range(3):      # tiles 0..2 of the walk into slots S_T + i (the caller has passed the barrier behind the previous item's last reads)
+    # S_PF: the previous item's block has requested this item's tiles 0..2 already (nreq / k then describe the walk from tile 3 on)
+    L += ["s_cmp_eq_u32 %s, 1" % S_PF, "s_cbranch_scc1 .Lf3_noreq_%="]
+    for i in range(3):      # tiles 0..2 of the walk into slots S_T + i (every wave has passed the barrier behind the previous reads of the ring)
         pre, groups, post, ool = request_tile("p%d" % i, i)
         L += pre
         for g in groups:
@@ -396,36 +406,32 @@ def emit(out):
     L += ["v_mov_b32_e32 v%d, 0xff800000" % V_NINF]
     L += ["s_and_b32 %s, %s, 3" % (S_TMP, S_T), "s_lshl_b32 %s, %s, 14" % (S_TOFFK, S_TMP), "s_mov_b32 %s, %s" % (S_TOFFV, S_TOFFK)]      # V "tile -1" := tile 0's slot (finite data; its P is zero)
     L += [i.text for i in k_addr_from_toff()] + [i.text for i in v_addr_from_toff()]
-    # ---------------- Q fragments (16 loads in front of the requests) and tile 0 have landed: the 16 requests of tiles 1, 2 may stay in flight
+    # ---------------- this item's Q fragments and tile 0 have landed.  What may stay in flight, youngest last:
+    #   requested here:            [Q, first item only | the predecessor's row stores] [the 16 staging loads] [tiles 0, 1, 2]    -> tiles 1, 2: 16
+    #   requested by the predecessor: [tiles 0, 1, 2] [its row stores: 18 when ctl bit 7 says so, else fewer] [the 16 staging loads] -> 34, else 16
     L += stamp(2)
-    # (an item prepared by its predecessor's block - tiles 0..2 from its last iterations, then the Q loads: only the rows the predecessor stored
-    # behind them may stay in flight - 18 store instructions when every row group had a row to store (ctl bit 7), else everything has to land)
-    L += ["s_bitcmp1_b32 %[ctl], 4", "s_cbranch_scc1 .Lf3_pfwait_%=", "s_waitcnt vmcnt(16)", "s_branch .Lf3_landed_%=", ".Lf3_pfwait_%=:",
-          "s_bitcmp1_b32 %[ctl], 7", "s_cbranch_scc1 .Lf3_pfwait18_%=", "s_waitcnt vmcnt(0)", "s_branch .Lf3_landed_%=", ".Lf3_pfwait18_%=:", "s_waitcnt vmcnt(18)",
-          ".Lf3_landed_%=:", "s_barrier"]
+    L += ["s_cmp_eq_u32 %s, 1" % S_PF, "s_cbranch_scc0 .Lf3_w16_%=", "s_bitcmp1_b32 %[ctl], 7", "s_cbranch_scc0 .Lf3_w16_%=", "s_waitcnt vmcnt(34)", "s_branch .Lf3_landed_%=",
+          ".Lf3_w16_%=:", "s_waitcnt vmcnt(16)", ".Lf3_landed_%=:", "s_barrier"]
     L += stamp(3)
     lines, fifo = chain_block(M, range(48, 64), 0, [])      # S(0), keys 0..31
     assert not fifo
     L += lines
     L += ["s_nop 7", "s_nop 7", "s_nop 7"]
-    # its mask (always applied here: rsP = 64 passes everything) and the reference: m_ref = sc * max over the half tile (0 for a lane that sees nothing)
-    # (which: ctl bits 8-9 - 0: the first tile is a plain one (64 passes everything), 1: it opens masked run 1, 2: masked run 2)
+    # its mask (always applied here: 64 passes everything) and the reference: m_ref = sc * max over the half tile (0 for a lane that sees nothing)
+    # (which: ctl bits 8-9 - 0: the first tile is a plain one, 1: it opens masked run 1, 2: masked run 2)
     L += ["s_bfe_u32 %s, %%[ctl], 0x20008" % S_TMP, "v_mov_b32_e32 v%d, 64" % RANGE[0], "v_mov_b32_e32 v%d, 64" % RANGE[1],
           "s_cmp_eq_u32 %s, 1" % S_TMP, "s_cbranch_scc0 .Lf3_rsp1_%=", "v_mov_b32_e32 v%d, %%[rsA]" % RANGE[0], "v_mov_b32_e32 v%d, %%[rsA]" % RANGE[1], ".Lf3_rsp1_%=:",
           "s_cmp_eq_u32 %s, 2" % S_TMP, "s_cbranch_scc0 .Lf3_rsp2_%=", "v_mov_b32_e32 v%d, %%[rsB0]" % RANGE[0], "v_mov_b32_e32 v%d, %%[rsB1]" % RANGE[1], ".Lf3_rsp2_%=:"]
-    MASKED = True
     for g in (0, 1):
-        L += [i.text.replace("\\n\\t", "\n") for i in mask_ops(g, 0, RANGE[g])]
-    MASKED = False
-    L = [x for l in L for x in l.split("\n")]
-    L += ["s_bitcmp1_b32 %[ctl], 3", "s_cbranch_scc1 .Lf3_mrgiven_%="]
+        L += [i.text for i in mask_ops(g, 0, RANGE[g])]
+    L += ["s_cmp_eq_u32 %s, 1" % S_REDO, "s_cbranch_scc1 .Lf3_mrdone_%="]      # (the repeat: the reference is the measured row maximum)
     for g, t in ((0, V_T0), (1, V_T1)):
         x = XS[(g, 0)]
         L += ["v_max3_f32 v%d, v%d, v%d, v%d" % (t, x, x + 1, V_NINF)] + ["v_max3_f32 v%d, v%d, v%d, v%d" % (t, x + 2 * i, x + 2 * i + 1, t) for i in range(1, 8)]
         L += ["v_mov_b32_e32 v%d, v%d" % (MREF[g], t), "s_nop 1", "v_permlane32_swap_b32_e32 v%d, v%d" % (t, MREF[g]), "s_nop 1",
               "v_max_f32_e32 v%d, v%d, v%d" % (t, t, MREF[g]), "v_mul_f32_e32 v%d, %%[sc], v%d" % (MREF[g], t),
               "v_cmp_lt_f32_e32 vcc, v%d, v%d" % (V_NINF, MREF[g]), "v_cndmask_b32_e32 v%d, 0, v%d, vcc" % (MREF[g], MREF[g])]
-    L += ["s_branch .Lf3_mrdone_%=", ".Lf3_mrgiven_%=:", "v_mov_b32_e32 v%d, %%[mri0]" % MREF[0], "v_mov_b32_e32 v%d, %%[mri1]" % MREF[1], ".Lf3_mrdone_%=:"]
+    L += [".Lf3_mrdone_%=:"]
     # the loop's first A operands
     for c in range(LOOKAHEAD // 2):
         L += [l.text for l in a_loads(M[2 * c]["a"], c % 8)]
@@ -446,10 +452,37 @@ def emit(out):
     # ---------------- drain: O(last), keys 32..63 (its first A operands are in flight)
     lines, fifo = chain_block(M, range(0, 16), LOOKAHEAD // 2, carried_reads(M))
     L += lines
-    L += ["s_branch .Lf3_end_%="] + ool_pro + ool_p + ool_m + [".Lf3_end_%=:", "s_waitcnt lgkmcnt(0)", "s_mov_b32 m0, %s" % S_M0SAVE]
+    L += ["s_branch .Lf3_end_%="] + ool_pro + ool_p + ool_m + [".Lf3_end_%=:", "s_waitcnt lgkmcnt(0)"]
+    # ---------------- did any query's maximum outgrow its reference by more than 2^64?  Workgroup-wide (the waves share the tile ring): every wave leaves
+    # its answer in the item's vote words (LDS, double buffered by ctl bit 10), barrier, everybody reads all four.  The barrier is also the one
+    # behind which the ring may be requested into again.  (A repeat pass does not vote: its reference IS the maximum.)
+    T = (V_T0, V_T1)
+    R0, R1, R2 = RING, RING + 1, RING + 2
+    L += ["s_cmp_eq_u32 %s, 1" % S_REDO, "s_cbranch_scc1 .Lf3_exit_%="]
+    for g in (0, 1):
+        L += ["v_mov_b32_e32 v%d, v%d" % (T[g], MX[g]), "v_mov_b32_e32 v%d, v%d" % (R0, MX[g]), "s_nop 1", "v_permlane32_swap_b32_e32 v%d, v%d" % (T[g], R0), "s_nop 1",
+              "v_max_f32_e32 v%d, v%d, v%d" % (T[g], T[g], R0), "v_mul_f32_e32 v%d, %%[sc], v%d" % (T[g], T[g]),
+              "v_add_f32_e32 v%d, 0x42800000, v%d" % (R0, MREF[g]), "v_cmp_gt_f32_e32 vcc, v%d, v%d" % (T[g], R0),
+              ("s_mov_b64 %s, vcc" % sp(SRC)) if g == 0 else ("s_or_b64 %s, %s, vcc" % (sp(SRC), sp(SRC)))]
+    L += ["s_cmp_lg_u64 %s, 0" % sp(SRC), "s_cselect_b32 %s, 1, 0" % S_TMP, "v_mov_b32_e32 v%d, %s" % (R1, S_TMP),
+          "s_bfe_u32 %s, %%[ctl], 0x1000a" % S_TMP, "s_lshl_b32 %s, %s, 4" % (S_TMP, S_TMP), "s_add_u32 %s, %s, %d" % (S_TMP, S_TMP, MAIL_LDS),
+          "s_lshl_b32 %s, %%[wave], 2" % S_TMP2, "s_add_u32 %s, %s, %s" % (S_TMP2, S_TMP2, S_TMP), "v_mov_b32_e32 v%d, %s" % (R2, S_TMP2),
+          "ds_write_b32 v%d, v%d" % (R2, R1), "s_waitcnt lgkmcnt(0)", "s_barrier",
+          "v_mov_b32_e32 v%d, %s" % (R2, S_TMP), "ds_read_b128 v[%d:%d], v%d" % (RING + 4, RING + 7, R2), "s_waitcnt lgkmcnt(0)",
+          "v_or3_b32 v%d, v%d, v%d, v%d" % (R1, RING + 4, RING + 5, RING + 6), "v_or_b32_e32 v%d, v%d, v%d" % (R1, R1, RING + 7), "s_nop 1",
+          "v_readfirstlane_b32 %s, v%d" % (S_TMP, R1), "s_nop 3", "s_cmp_eq_u32 %s, 0" % S_TMP, "s_cbranch_scc1 .Lf3_exit_%="]
+    # rare: the whole row block again, cold, against the true row maxima; what the first pass requested for the next item must have landed
+    # before this pass requests into the same slots
+    for g in (0, 1):
+        L += ["v_cmp_lt_f32_e32 vcc, v%d, v%d" % (V_NINF, T[g]), "v_cndmask_b32_e32 v%d, 0, v%d, vcc" % (MREF[g], T[g])]
+    L += ["s_mov_b32 %s, 1" % S_REDO, "s_mov_b32 %s, 0" % S_PF, "s_waitcnt vmcnt(0)", "s_branch .Lf3_pass_%="]
+    # ---------------- way out: the next item's Q fragments move in (they landed long ago: every tile wait of the loop was behind them; an item
+    # without iterations waits here)
+    L += [".Lf3_exit_%=:", "s_mov_b32 m0, %s" % S_M0SAVE, "s_waitcnt vmcnt(0)"]
+    L += ["v_accvgpr_mov_b32 a%d, a%d" % (128 + i, 192 + i) for i in range(64)]
     for g in (0, 1):
         L += ["v_pk_add_f32 %s, %s, %s" % (vr(L2[g], 2), vr(L2[g], 2), vr(L2[g] + 2, 2)), "v_add_f32_e32 %%[l%d], v%d, v%d" % (g, L2[g], L2[g] + 1),
-              "v_mov_b32_e32 %%[mx%d], v%d" % (g, MX[g]), "v_mov_b32_e32 %%[mr%d], v%d" % (g, MREF[g])]
+              "v_mov_b32_e32 %%[mr%d], v%d" % (g, MREF[g])]
     L += stamp(6)
     L = [x for l in L for x in l.replace("\\n\\t", "\n").split("\n")]
     diag = os.environ.get("FWD3_DIAG", "")      # timing experiments only (results are wrong): nodma / nobar, comma separated
@@ -463,7 +496,8 @@ def emit(out):
             f.write('"%s\\n\\t"\n' % l)
     with open(out.replace(".inc", "_clobbers.inc"), "w") as f:
         f.write("// generated by gen_fwd3_loop.py - do not edit\n")
-        f.write(", ".join('"v%d"' % i for i in range(64, V_LAST + 1)) + ",\n" + ", ".join('"s%d"' % i for i in range(S_FIRST - 2, S_LAST + 1)) + ', "vcc", "scc", "memory"\n')
+        f.write(", ".join('"v%d"' % i for i in range(64, V_LAST + 1)) + ",\n" + ", ".join('"a%d"' % i for i in range(192, 256)) + ",\n" +
+                ", ".join('"s%d"' % i for i in range(S_FIRST - 4, S_LAST + 1)) + ', "vcc", "scc", "memory"\n')
     print("%s: %d asm lines" % (out, len(L)))
 
 

@@ -1689,9 +1689,9 @@ int launch_fwd(const SdpaParams& p_in, int S, hipStream_t st) {
 #endif
     if constexpr (D == 128 && CAUSAL) {
         // sdpa_fwd3: one wave per SIMD, the tile loop in generated asm (sdpa_fwd3.h).  HALVA_SDPA_FWD3=0: the two-waves-per-SIMD kernel of
-        // rounds 1-3 (A/B and debugging switch, read on every call).  (Its tile counts travel as 16-bit fields; its dummy requests read the
-        // tensors' first 64 rows.)
-        if (!slow_tr_requested() && (int64_t)S * p.T >= 64 && p.T < (1 << 21) && env_flag_on("HALVA_SDPA_FWD3")) return launch_fwd3(p, S, st);
+        // rounds 1-3 (A/B and debugging switch, read on every call).  (Its tile counts travel as 16-bit fields, a sequence's K / V rows are
+        // addressed through one 32-bit buffer descriptor.)
+        if (!slow_tr_requested() && p.T < (1 << 21) && (int64_t)p.T * p.ld_qkv * 2 < (1ll << 31) && env_flag_on("HALVA_SDPA_FWD3")) return launch_fwd3(p, S, st);
     }
     return slow_tr_requested() ? launch_one(sdpa_fwd_kernel<D, CAUSAL, true>, p, CAUSAL, 256, 512, lds, S, st, "sdpa_fwd")
                                : launch_one(sdpa_fwd_kernel<D, CAUSAL, false>, p, CAUSAL, 256, 512, lds, S, st, "sdpa_fwd");

@@ -14,11 +14,10 @@
 // keys; a later score may exceed it by 2^64 (RESCALE_AT of the two-wave kernel) before anything is lost.  In the rare case that one does, the
 // WHOLE row block is repeated with m_ref = the true row maximum, which the first pass has just measured exactly - no approximation, no other
 // kernel involved (test_sdpa_exponent_reference_moves_when_later_keys_dominate).
-// LDS: K ring [4][64][128] bf16 at 0, V ring at 64 KiB, 1 KiB dummy chunk (requests past the last tile), the workgroup's vote words.
+// LDS: K ring [4][64][128] bf16 at 0, V ring at 64 KiB, the workgroup's vote words.
 
 constexpr int FWD3_TILE = 64 * 128 * 2;
-constexpr int FWD3_DUMMY = 8 * FWD3_TILE;
-constexpr int FWD3_MAIL = FWD3_DUMMY + 1024;
+constexpr int FWD3_MAIL = 8 * FWD3_TILE;      // (gen_fwd3_loop.py: MAIL_LDS)
 constexpr int FWD3_LDS = FWD3_MAIL + 64;
 constexpr float FWD3_RESCALE_AT = 64.f;      // log2 units
 
@@ -138,8 +137,6 @@ __device__ __forceinline__ void sdpa_fwd3_item(const SdpaParams& p, char* smem, 
     unsigned long long stamp_t0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t0)::"memory");
 #endif
-    typedef __attribute__((address_space(3))) volatile int LdsInt;
-    LdsInt* mail = (LdsInt*)(__attribute__((address_space(3))) char*)(smem + FWD3_MAIL);
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
     const int h = lane >> 5, r = lane & 31;
@@ -158,9 +155,6 @@ __device__ __forceinline__ void sdpa_fwd3_item(const SdpaParams& p, char* smem, 
     const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3, h2 = g16 >> 1;
     const unsigned colrel = 64 * (4 * h2 + q4) + 16 * ((2 * (g16 & 1) + (pp >> 1)) ^ h2) + 8 * (pp & 1);
     const unsigned voff = dkv3_piece_voff(p.ld_qkv, wave, lane, 0, 64);
-    unsigned alt[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) alt[i] = dkv3_piece_voff(p.ld_qkv, wave, lane, i, g.lr);
     // visible-key counts (minus the lane half's row offset 4 h) of the first tile of each masked run, and of the item's first tile
     const int rsA = br.a - g.kvA - 4 * h;
     int rsB[2];
@@ -169,94 +163,51 @@ __device__ __forceinline__ void sdpa_fwd3_item(const SdpaParams& p, char* smem, 
     const unsigned first_state = (g.n0 + g.n1 > 0) ? (g.n0 > 0 ? 0u : 1u) : (g.n2 > 0 ? 0u : 2u);      // the first tile: plain | opens masked run 1 | run 2
     const float sc = p.scale * kLog2e;
     const unsigned n01 = dkv3_uni((unsigned)g.n0 | ((unsigned)g.n1 << 16)), n23 = dkv3_uni((unsigned)g.n2 | ((unsigned)g.n3 << 16));
-    const unsigned long long jump = (unsigned long long)(g.jump_rows * p.ld_qkv * 2);
-    const unsigned jlo = dkv3_uni((unsigned)jump), jhi = dkv3_uni((unsigned)(jump >> 32));
+    const unsigned jlo = dkv3_uni((unsigned)(g.jump_rows * p.ld_qkv * 2));
     const unsigned wave_u = dkv3_uni((unsigned)wave), piece = dkv3_uni((unsigned)(16 * p.ld_qkv * 2));
-    const bf16_t* kp = p.k + hd * D;
-    const unsigned long long safe_k = dkv3_uni64(kp);      // (the dummy requests read the tensor's first 64 rows: the launcher requires S * T >= 64)
-    const unsigned long long vdelta = (unsigned long long)((const char*)p.v - (const char*)p.k);
-    const unsigned vdlo = dkv3_uni((unsigned)vdelta), vdhi = dkv3_uni((unsigned)(vdelta >> 32));
+    // K / V tiles arrive through ONE buffer descriptor per (sequence, head): base = the sequence's first K row of this head, num_records = up to the
+    // end of its last V row; V rows = K rows + (v - k).  Rows past the sequence are out of range -> zeros (no clamped offsets, no dummy target).
+    const unsigned vdlo = dkv3_uni((unsigned)((const char*)p.v - (const char*)p.k));
+    auto kv_base = [&](const Fwd3Cursor& c) { return (unsigned long long)(size_t)(p.k + c.hd * D + ((int64_t)c.s * p.T + c.start) * p.ld_qkv); };
+    auto kv_records = [&](const Fwd3Cursor& c) { return c.len > 0 ? (unsigned)((int64_t)(c.len - 1) * p.ld_qkv * 2 + vdlo + D * 2) : 0u; };
+    const unsigned long long k_base = kv_base(cur);
+    const unsigned nrec = kv_records(cur);
     // the walk as the block is to request it: from tile 0 (cold), or from tile 3 when the previous item's block has requested tiles 0..2
     const bool pf = prefetched;
     const int t_req = pf ? 3 : 0;
     const unsigned nreq = dkv3_uni((unsigned)(N - t_req) | ((unsigned)(g.n1req == 0xffff ? 0xffff : g.n1req - t_req) << 16));
-    const unsigned long long k_ptr = (unsigned long long)(size_t)(kp + (seq_row0 + start + g.kv_first + 64 * t_req) * p.ld_qkv);
+    const unsigned soff0 = (unsigned)((int64_t)(g.kv_first + 64 * t_req) * p.ld_qkv * 2);
     // the next item's first three tiles (requested by this block's last iterations when they are three whole ordinary tiles)
-    unsigned npf = 0;
-    unsigned long long nk_ptr = safe_k;
+    unsigned npf = 0, nnrec = 0, nsoff0 = 0;
+    unsigned long long nk_base = k_base;
     if (nxt_valid) {
         const Fwd3Geom gn = fwd3_geom(p, nxt.qb(), nxt.start, nxt.len, nxt.br, wave);
-        if (gn.N >= 3 && (gn.n1req == 0xffff || gn.n1req >= 3) && !(gn.partial && gn.N <= 3)) {
+        if (gn.N >= 3 && (gn.n1req == 0xffff || gn.n1req >= 3)) {
             npf = 3;
-            const int64_t nrow = (int64_t)nxt.s * p.T + nxt.start + gn.kv_first;
-            nk_ptr = (unsigned long long)(size_t)(p.k + nxt.hd * D + nrow * p.ld_qkv);
+            nk_base = kv_base(nxt), nnrec = kv_records(nxt), nsoff0 = (unsigned)((int64_t)gn.kv_first * p.ld_qkv * 2);
         }
     }
     npf = dkv3_uni(npf);
-    const unsigned ctl0 = dkv3_uni((unsigned)((ring_base & 3) | (g.partial ? 4 : 0) | (pf ? 16 : 0) | ((pf && stores18) ? 128 : 0)) | (npf << 5) | (first_state << 8));
+    const unsigned ctl0 = dkv3_uni((unsigned)((ring_base & 3) | (pf ? 16 : 0) | ((pf && stores18) ? 128 : 0) | (parity ? 1024 : 0)) | (npf << 5) | (first_state << 8));
 
+    // the rows whose Q fragments the block stages for its successor (none: this item's again)
+    const bf16_t* nq0 = fwd3_q_row(p, nxt_valid ? nxt : cur, wave, lane, 0);
+    const bf16_t* nq1 = fwd3_q_row(p, nxt_valid ? nxt : cur, wave, lane, 1);
     f32x16 acc[8];
-    float l[2], mx[2], mr[2];
-    float mri0 = 0.f, mri1 = 0.f;
+    float l[2], mr[2];
 #ifdef HALVA_STAMP
     unsigned st_[7];
     unsigned long long tc_[6];
     tc_[0] = stamp_t0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc_[1])::"memory");
 #endif
-#define FWD3_CTL ctl0
-#define FWD3_NREQ nreq
-#define FWD3_KPTR k_ptr
 #include "sdpa_fwd3_call.h"
-#undef FWD3_CTL
-#undef FWD3_NREQ
-#undef FWD3_KPTR
 #ifdef HALVA_STAMP
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc_[2])::"memory");
-#endif
-    int base_used = ring_base;
-    // ---- did any query's maximum outgrow its reference?  (workgroup-wide: the waves share the tile ring)
-    float mxs[2];
-    bool over = false;
-#pragma unroll
-    for (int gi = 0; gi < 2; ++gi) {
-        mxs[gi] = xhalf_max(mx[gi]) * sc;
-        over = over || (mxs[gi] > mr[gi] + FWD3_RESCALE_AT);
-    }
-    const int mine = __any(over) ? 1 : 0;
-    if (lane == 0) mail[4 * parity + wave] = mine;
-    // (the mail box is LDS: wait for the LDS write only; also: every wave is done with this pass's ring before anything is requested into it again)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    const int redo = (int)dkv3_uni((unsigned)(mail[4 * parity] | mail[4 * parity + 1] | mail[4 * parity + 2] | mail[4 * parity + 3]));
-#ifdef HALVA_STAMP
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc_[3])::"memory");
-#endif
-    if (__builtin_expect(redo != 0, 0)) {      // rare: the whole row block again, cold, against the true row maxima
-        mri0 = mxs[0] > -INFINITY ? mxs[0] : 0.f;
-        mri1 = mxs[1] > -INFINITY ? mxs[1] : 0.f;
-        const unsigned ctl1 = dkv3_uni((unsigned)((g.partial ? 4 : 0) | 8) | (npf << 5) | (first_state << 8));
-        const unsigned nreq1 = dkv3_uni((unsigned)N | ((unsigned)g.n1req << 16));
-        const unsigned long long k_ptr1 = (unsigned long long)(size_t)(kp + (seq_row0 + start + g.kv_first) * p.ld_qkv);
-        // (the first pass's requests for the next item's tiles must have landed before this pass requests into the same slots)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        base_used = 0;
-#define FWD3_CTL ctl1
-#define FWD3_NREQ nreq1
-#define FWD3_KPTR k_ptr1
-#include "sdpa_fwd3_call.h"
-#undef FWD3_CTL
-#undef FWD3_NREQ
-#undef FWD3_KPTR
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    // ---- the Q registers are free: the NEXT item's fragments, in front of this item's row stores (they land during the store tail; the next block
-    // waits for them with a COUNTED vmcnt that leaves exactly those stores in flight)
-    if (nxt_valid) fwd3_load_q(qf, fwd3_q_row(p, nxt, wave, lane, 0), fwd3_q_row(p, nxt, wave, lane, 1));
-#ifdef HALVA_STAMP
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc_[4])::"memory");
+    tc_[3] = tc_[4] = tc_[2];
 #endif
     prefetched = npf != 0;
-    ring_base = (base_used + N) & 3;
+    ring_base = (ring_base + N) & 3;      // (a repeat pass starts from the same slot)
     stores18 = g0 + 64 * wave + 32 < p.T;      // both row groups have a row to store: 2 x 8 row stores + 2 lse stores are issued below
     // ---- the rows: O = O^T / l (the lane = row layout of store_rows_T), lse.  (Row numbers and pointers are formed HERE, from the lane number
     // again: kept across the asm block they cost registers the block's operands need - spilled, and a scratch reload waits for every request in flight)

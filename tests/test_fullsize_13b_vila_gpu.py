@@ -103,7 +103,10 @@ def test_grouping_and_prefix_sharing_invariance_at_13b_widths(build, alpha):
     assert e1.last_packing is None and e3.last_packing is not None and e3.last_packing[0] < e3.last_packing[1]
     for l, p in ((l2, p2), (l3, p3)):
         assert abs(l - l1) < 2e-3 * max(1.0, abs(l1)), (l, l1)
-        assert abs(p["alignment"] - p1["alignment"]) < 3e-3 * max(1.0, p1["alignment"])      # N(0, 0.02) at width 5120: alignment ~ 2
+        # N(0, 0.02) at width 5120: alignment ~ 2.  What moves it between groupings is the bf16 rounding of the GEMMs (their tiling follows the
+        # group's row count) and, with prefix sharing, the rows' position inside the attention tiles: measured over both forward kernels
+        # (tools/r04/inv_probe.py) 1.8e-3 .. 7.2e-3 on this batch - each number ONE draw of that noise, whichever kernel runs
+        assert abs(p["alignment"] - p1["alignment"]) < 6e-3 * max(1.0, p1["alignment"])
         assert abs(p["divergence"] - p1["divergence"]) < 2e-3 * max(1.0, p1["divergence"])
     for g in (g2, g3):
         assert float((g - g1).norm() / g1.norm()) < 2e-2

@@ -1,0 +1,68 @@
+"""Determinism / agreement of sdpa_fwd3 at the step's launch shapes: repeated launches must agree bit for bit, and with the two-wave kernel up to
+a bf16 rounding of the output (different summation order).  usage: python tools/check_fwd3_det.py"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from halva_amd import hip  # noqa: E402
+
+hip.load()
+DEV = "cuda:0"
+
+
+def run(qkv, lens, br_a, br_b, H, flag):
+    os.environ["HALVA_SDPA_FWD3"] = flag
+    S, T = qkv.shape[0], qkv.shape[1]
+    D = 128
+    mk = lambda v: None if v is None else torch.tensor(v, dtype=torch.int32, device=DEV)
+    ss, sl, ba, bb = mk([0] * S), mk(lens), mk(br_a), mk(br_b)
+    out = torch.empty(S, T, H * D, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(S, H, T, dtype=torch.float32, device=DEV)
+    hip.call("halva_sdpa_branch_fwd", hip.ptr(qkv), hip.ptr(out), H * D, hip.ptr(lse), hip.ptr(ss), hip.ptr(sl), hip.ptr(ba), hip.ptr(bb), S, T, H, D, 0.0,
+             hip.stream_ptr())
+    torch.cuda.synchronize()
+    return out, lse
+
+
+def check(name, S, T, H, lens=None, br_a=None, br_b=None, reps=6, scale=1.0):
+    g = torch.Generator(device=DEV).manual_seed(7)
+    qkv = (torch.randn(S, T, 3 * H * 128, generator=g, device=DEV) * scale).to(torch.bfloat16)
+    lens = lens or [T] * S
+    o0, l0 = run(qkv, lens, br_a, br_b, H, "1")
+    bad = 0
+    for r in range(reps):
+        # other work in between, so that caches / timing differ from launch to launch
+        junk = torch.randn(64, 1024, 1024, device=DEV).sum()
+        o, l = run(qkv, lens, br_a, br_b, H, "1")
+        nd = int((o.view(torch.int16) != o0.view(torch.int16)).sum())
+        nl = int((l != l0).sum())
+        if nd or nl:
+            bad += 1
+            d = (o.float() - o0.float()).abs()
+            rows = torch.nonzero(d.amax(dim=2) > 0)
+            print("   rep %d: %d output elements / %d lse differ, max |diff| %.3e, rows e.g. %s" % (r, nd, nl, float(d.max()), rows[:6].tolist()))
+    oo, lo = run(qkv, lens, br_a, br_b, H, "0")
+    d = (o0.float() - oo.float()).abs()
+    tol = 2.0 ** -7 * oo.float().abs() + 1e-3
+    nbig = int((d > tol).sum())
+    print("%-28s repeats %s | vs two-wave kernel: max |diff| %.3e, %d of %d elements beyond one bf16 rounding, lse max diff %.2e"
+          % (name, "BIT-IDENTICAL" if not bad else "%d of %d DIFFER" % (bad, reps), float(d.max()), nbig, d.numel(), float((l0 - lo).abs().max())))
+    if nbig:
+        rows = torch.nonzero((d > tol).any(dim=2))
+        print("   rows beyond tolerance e.g.", rows[:10].tolist())
+    return not bad and nbig == 0
+
+
+ok = True
+ok &= check("8 x 2048 H32", 8, 2048, 32)
+ok &= check("16 x 2048 H32", 16, 2048, 32)
+ok &= check("16 x 3428 packed H32", 16, 3428, 32, None, [668] * 16, [2048] * 16)
+ok &= check("2 x 2048 H40", 2, 2048, 40)
+ok &= check("4 x 4096 H40", 4, 4096, 40)
+ok &= check("1 x 2048 H40", 1, 2048, 40)
+ok &= check("4 x 1900 H40 ragged", 4, 1900, 40, [1900, 1733, 1500, 1811])
+ok &= check("3 x 700 H2 branch", 3, 700, 2, [700, 650, 300], [100, 257, 512], [384, 448, 512])
+print("ALL OK" if ok else "SOME FAILED")
