@@ -122,7 +122,7 @@ def mfma_ins(n, m):
     dt = m["j"] % 4
     b = PB[(m["g"], m["kh"])] + 4 * k16
     acc = 4 * m["g"] + dt
-    return Ins("v_mfma_f32_32x32x16_bf16 %%[o%d], %s, %s, %%[o%d]" % (acc, a, vr(b, 4), acc), "mfma", reads=regs(slot, 4) + regs(b, 4))
+    return Ins("v_mfma_f32_32x32x16_bf16 a[%d:%d], %s, %s, a[%d:%d]" % (16 * acc, 16 * acc + 15, a, vr(b, 4), 16 * acc, 16 * acc + 15), "mfma", reads=regs(slot, 4) + regs(b, 4))
 
 
 def mask_ops(g, kh, rng):
@@ -339,11 +339,120 @@ def chain_block(M, ns, first_reads_issued, carried):
     return lines, fifo
 
 
+QDESC, OB, LB = (88, 91), (96, 97), (98, 99)      # (the walk's descriptor and the item's own are dead behind the vote)
+S_QST, S_SOFFQ = "s86", "s87"
+T0 = 64                                               # temporaries of the tail: v64.. (the loop's registers are dead)
+
+
+OSTAGE_LDS = MAIL_LDS + 128     # (FWD3_OSTAGE, sdpa_fwd3.h; 128-byte aligned: the staging addresses are formed with XORs) 4 x 4 KiB: a wave's staging area for its output rows (half the head_dim of a row group at a time)
+S_OBJ = (92, 93)
+
+
+def tail_code():
+    """Behind the vote.  Per row group g:
+      [the NEXT item's Q rows of the group requested by LDS-DMA into this wave's 8 KiB of the ring slot the item's last tile has left - whole 1-KiB
+       pieces through a descriptor over the next sequence's Q rows; rows outside it arrive as zeros]
+      [this item's rows of the group: O = O^T / l as bf16, TRANSPOSED through 4 KiB of LDS (two passes of 64 head_dim columns) so that every store
+       instruction writes eight whole 128-byte row pieces instead of 16 bytes into each of 32 rows - the address unit takes a lane's address per
+       clock, and 16 such stores (plus 16 such loads for Q) of four waves were ~8 000 cycles per item; the lse]
+      [the fragments read back from LDS straight into the Q registers]."""
+    o = []
+    l3, l7off = T0 + 32, T0 + 33
+    lane = T0 + 7
+    # this wave's 8 KiB of the free slot (S_T - 1) & 3 - K area for waves 0 / 1, V area for waves 2 / 3 -, its 4 KiB output staging area
+    o += ["s_sub_u32 %s, %s, 1" % (S_TMP, S_T), "s_and_b32 %s, %s, 3" % (S_TMP, S_TMP), "s_lshl_b32 %s, %s, 14" % (S_QST, S_TMP),
+          "s_lshr_b32 %s, %%[wave], 1" % S_TMP, "s_lshl_b32 %s, %s, 16" % (S_TMP, S_TMP), "s_add_u32 %s, %s, %s" % (S_QST, S_QST, S_TMP),
+          "s_and_b32 %s, %%[wave], 1" % S_TMP, "s_lshl_b32 %s, %s, 13" % (S_TMP, S_TMP), "s_add_u32 %s, %s, %s" % (S_QST, S_QST, S_TMP),
+          "v_readfirstlane_b32 s%d, %%[nq_lo]" % QDESC[0], "v_readfirstlane_b32 s%d, %%[nq_hi]" % (QDESC[0] + 1), "v_readfirstlane_b32 s%d, %%[nqrec]" % (QDESC[0] + 2),
+          "s_mov_b32 s%d, 0x00020000" % (QDESC[0] + 3),
+          "v_readfirstlane_b32 s%d, %%[o_lo]" % OB[0], "v_readfirstlane_b32 s%d, %%[o_hi]" % OB[1],
+          "v_readfirstlane_b32 s%d, %%[lse_lo]" % LB[0], "v_readfirstlane_b32 s%d, %%[lse_hi]" % LB[1],
+          "v_add_u32_e32 v%d, %s, %%[rowrel]" % (KRE, S_QST), "v_xor_b32_e32 v%d, 32, v%d" % (KRO, KRE),
+          "v_mbcnt_lo_u32_b32 v%d, -1, 0" % lane, "v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (lane, lane), "v_lshrrev_b32_e32 v%d, 3, v%d" % (l3, lane), "s_nop 3"]
+    # staging addresses.  Write (lane = row r of the group, half h): row r, chunk c (16 bytes) at r * 128 + ((c ^ ((r >> 1) & 7)) << 4) + 8 h - the
+    # lane part is wbase = r * 128 + 8 h and the mask m = ((r >> 1) & 7) << 4; a piece's address = wbase + ((c << 4) ^ m)  (c is a constant).
+    # Read (lane l): row 8 j + (l >> 3), chunk l & 7 -> rbase = (l >> 3) * 128 + (((l & 7) ^ (((l >> 3) >> 1) & 7)) << 4), + 1024 j  (8 j is even: the mask of row
+    # 8 j + x is that of row x).
+    wbase, wmask, rbase, rbase_odd, t = T0 + 34, T0 + 35, T0 + 36, T0 + 37, T0 + 2
+    o += ["v_and_b32_e32 v%d, 31, v%d" % (t, lane), "v_lshlrev_b32_e32 v%d, 7, v%d" % (wbase, t), "v_lshrrev_b32_e32 v%d, 1, v%d" % (wmask, t),
+          "v_and_b32_e32 v%d, 7, v%d" % (wmask, wmask), "v_lshlrev_b32_e32 v%d, 4, v%d" % (wmask, wmask),
+          "v_lshrrev_b32_e32 v%d, 5, v%d" % (t, lane), "v_lshlrev_b32_e32 v%d, 3, v%d" % (t, t), "v_add_u32_e32 v%d, v%d, v%d" % (wbase, wbase, t),
+          "s_lshl_b32 %s, %%[wave], 12" % S_TMP, "s_add_u32 %s, %s, %d" % (S_TMP, S_TMP, OSTAGE_LDS), "v_add_u32_e32 v%d, %s, v%d" % (wbase, S_TMP, wbase),
+          "v_lshrrev_b32_e32 v%d, 1, v%d" % (t, l3), "v_and_b32_e32 v%d, 7, v%d" % (t, t), "v_and_b32_e32 v%d, 7, v%d" % (rbase, lane), "v_xor_b32_e32 v%d, v%d, v%d" % (rbase, rbase, t),
+          "v_lshlrev_b32_e32 v%d, 4, v%d" % (rbase, rbase), "v_lshlrev_b32_e32 v%d, 7, v%d" % (t, l3), "v_add_u32_e32 v%d, v%d, v%d" % (rbase, rbase, t),
+          "v_add_u32_e32 v%d, %s, v%d" % (rbase, S_TMP, rbase),
+          "v_xor_b32_e32 v%d, 64, v%d" % (rbase_odd, rbase)]      # rows 8 j + x with j odd: ((8 j + x) >> 1) & 7 = (x >> 1) ^ 4
+    for g in (0, 1):
+        # ---- request the group's 32 rows of the NEXT item: piece c = rows 8 (c / 2) .. + 7, chunks 8 (c % 2) .. + 7 of the half-tile image
+        # (ctl bit 11: the next row block begins in front of its sequence - left padding: its Q fragments are gathered row by row with clamped
+        # pointers behind the stores instead, as the workgroup's first item's are)
+        o += ["s_bitcmp1_b32 %[ctl], 11", "s_cbranch_scc1 .Lf3_noqdma%d_%%=" % g]
+        o += ["v_readfirstlane_b32 %s, %%[nqsoff%d]" % (S_SOFFQ, g), "s_mov_b32 m0, %s" % S_QST, "s_nop 2"]
+        for c in range(8):      # (no immediate offset: an LDS-DMA load adds it to the LDS address as well)
+            if c & 1:
+                o += ["s_add_u32 %s, %s, 128" % (S_TMP, S_SOFFQ)]
+            o += ["buffer_load_dwordx4 %%[nqv%s%d], %s, %s offen lds" % ("AB"[(c >> 1) & 1], g, sq(QDESC), S_TMP if c & 1 else S_SOFFQ),
+                  "s_add_u32 m0, m0, 1024", "s_nop 0"]
+            if c & 1:
+                o += ["s_add_u32 %s, %s, %%[rows8]" % (S_SOFFQ, S_SOFFQ)]
+        o += [".Lf3_noqdma%d_%%=:" % g]
+        # ---- this item's rows of the group
+        l, lt, lse, fl, loff, inv = T0, T0 + 1, T0 + 4, T0 + 5, T0 + 6, T0 + 30      # (inv: a pair, v_pk_mul's factor)
+        W, A, R = T0 + 8, T0 + 12, T0 + 40                                           # 4 packed words; 8 accumulator values; 4 x 4 registers read back
+        o += ["v_pk_add_f32 %s, %s, %s" % (vr(L2[g], 2), vr(L2[g], 2), vr(L2[g] + 2, 2)), "v_add_f32_e32 v%d, v%d, v%d" % (l, L2[g], L2[g] + 1),
+              "v_mov_b32_e32 v%d, v%d" % (lt, l), "s_nop 1", "v_permlane32_swap_b32_e32 v%d, v%d" % (l, lt), "s_nop 1", "v_add_f32_e32 v%d, v%d, v%d" % (lt, l, lt),      # l of the whole row
+              "v_and_b32_e32 v%d, 3, %%[loff%d]" % (fl, g), "v_and_b32_e32 v%d, -4, %%[loff%d]" % (loff, g),
+              "v_rcp_f32_e32 v%d, v%d" % (inv, lt), "v_log_f32_e32 v%d, v%d" % (lse, lt),
+              "v_cmp_lt_u32_e32 vcc, 1, v%d" % fl, "s_mov_b64 %s, vcc" % sp(SRC),                                       # bit 1: the row is a row of the sequence
+              "v_cmp_lt_f32_e32 vcc, 0, v%d" % lt, "s_and_b64 vcc, vcc, %s" % sp(SRC), "v_cndmask_b32_e32 v%d, 0, v%d, vcc" % (inv, inv),
+              "v_add_f32_e32 v%d, v%d, v%d" % (lse, lse, MREF[g]), "v_mul_f32_e32 v%d, 0x3f317218, v%d" % (lse, lse),
+              "s_mov_b64 vcc, %s" % sp(SRC), "v_cndmask_b32_e32 v%d, 0, v%d, vcc" % (lse, lse),
+              "v_mov_b32_e32 v%d, v%d" % (inv + 1, inv),
+              # the group's first output row (+ 8 rows per store), how many of its rows exist in the tensor (nt01: group 0 | group 1 << 8)
+              "s_mul_i32 %s, %%[rows8o], %d" % (S_TMP, 4 * g), "s_add_u32 s%d, s%d, %s" % (S_OBJ[0], OB[0], S_TMP), "s_addc_u32 s%d, s%d, 0" % (S_OBJ[1], OB[1]),
+              "s_bfe_u32 %s, %%[nt01], 0x8%04x" % (S_TMP2, 8 * g)]
+        for p in range(2):
+            for dtl in range(2):
+                for gp in range(2):
+                    acc0 = 16 * (4 * g + 2 * p + dtl) + 8 * gp
+                    o += ["v_accvgpr_read_b32 v%d, a%d" % (A + j, acc0 + j) for j in range(8)]
+                    o += ["v_pk_mul_f32 %s, %s, %s" % (vr(A + 2 * j, 2), vr(A + 2 * j, 2), vr(inv, 2)) for j in range(4)]
+                    o += ["v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (W + j, A + 2 * j, A + 2 * j + 1) for j in range(4)]
+                    for k in range(2):      # 8 bytes: head_dim 64 p + 32 dtl + 16 gp + 8 k + 4 h .. + 3 = chunk 4 dtl + 2 gp + k of the pass, half h
+                        c = 4 * dtl + 2 * gp + k
+                        o += ["v_xor_b32_e32 v%d, %d, v%d" % (t, 16 * c, wmask), "v_add_u32_e32 v%d, v%d, v%d" % (t, t, wbase), "ds_write_b64 v%d, %s" % (t, vr(W + 2 * k, 2))]
+            o += ["s_waitcnt lgkmcnt(0)"]
+            o += ["ds_read_b128 %s, v%d offset:%d" % (vr(R + 4 * j, 4), (rbase, rbase_odd)[j & 1], 1024 * j) for j in range(4)]
+            for j in range(4):      # rows 8 j .. 8 j + 7 of the group, 128 bytes each: lanes of rows beyond the tensor switched off
+                o += ["s_waitcnt lgkmcnt(%d)" % (3 - j), "s_sub_u32 %s, %s, %d" % (S_TMP, S_TMP2, 8 * j), "s_max_i32 %s, %s, 0" % (S_TMP, S_TMP),
+                      "v_cmp_gt_u32_e32 vcc, %s, v%d" % (S_TMP, l3), "s_and_saveexec_b64 %s, vcc" % sp(SRC),
+                      "global_store_dwordx4 %%[ooffc], %s, s[%d:%d] offset:%d" % (vr(R + 4 * j, 4), S_OBJ[0], S_OBJ[1], 128 * p),
+                      "s_mov_b64 exec, %s" % sp(SRC)]
+                if j < 3:
+                    o += ["s_add_u32 s%d, s%d, %%[rows8o]" % (S_OBJ[0], S_OBJ[0]), "s_addc_u32 s%d, s%d, 0" % (S_OBJ[1], S_OBJ[1])]
+            if p == 0:      # back to the group's first row for the second pass (3 x 8 rows down)
+                o += ["s_mul_i32 %s, %%[rows8o], 3" % S_TMP, "s_sub_u32 s%d, s%d, %s" % (S_OBJ[0], S_OBJ[0], S_TMP), "s_subb_u32 s%d, s%d, 0" % (S_OBJ[1], S_OBJ[1])]
+        # the lse of the rows that exist (bit 0 of the flags), from the lanes of half 0
+        o += ["v_and_b32_e32 v%d, 1, v%d" % (t, fl), "v_cmp_eq_u32_e32 vcc, 1, v%d" % t, "s_mov_b64 %s, vcc" % sp(SRC), "v_cmp_gt_u32_e32 vcc, 32, v%d" % lane,
+              "s_and_b64 vcc, vcc, %s" % sp(SRC), "s_and_saveexec_b64 %s, vcc" % sp(SRC), "global_store_dword v%d, v%d, %s" % (loff, lse, sp(LB)),
+              "s_mov_b64 exec, %s" % sp(SRC)]
+        # ---- the group's fragments, straight into the Q registers (lane (r, h): row r, chunk 2 ks + h of the half-tile image): the requests were
+        # issued in front of 8 row stores and the lse store
+        # (a group with rows beyond the tensor may have issued fewer: then everything has to land)
+        o += ["s_bitcmp1_b32 %[ctl], 11", "s_cbranch_scc1 .Lf3_qgather%d_%%=" % g, "s_cmp_lt_u32 %s, 32" % S_TMP2, "s_cbranch_scc1 .Lf3_qw0%d_%%=" % g,
+              "s_waitcnt vmcnt(9)", "s_branch .Lf3_qw%d_%%=" % g, ".Lf3_qw0%d_%%=:" % g, "s_waitcnt vmcnt(0)", ".Lf3_qw%d_%%=:" % g]
+        o += ["ds_read_b128 %%[q%d], v%d offset:%d" % (8 * g + ks, (KRE, KRO)[ks & 1], 512 * (ks >> 1)) for ks in range(8)]
+        o += ["s_waitcnt lgkmcnt(0)", "s_branch .Lf3_qdone%d_%%=" % g, ".Lf3_qgather%d_%%=:" % g]
+        o += ["global_load_dwordx4 %%[q%d], %%[nqg%d], off%s" % (8 * g + ks, g, (" offset:%d" % (32 * ks)) if ks else "") for ks in range(8)]
+        o += ["s_waitcnt vmcnt(0)", ".Lf3_qdone%d_%%=:" % g]
+    return o
+
+
 STAMP = False
 
 
 def stamp(k):
-    """diagnostic builds (sdpa_fwd3_loop_stamp.inc, -DHALVA_STAMP): the low word of s_memtime into output operand st<k>"""
+    """diagnostic builds (sdpa_fwd3_loop_stamp.inc, -DHALVA_STAMP): the low word of s_memtime into output operand st<k> (k = 0..7)"""
     return ["s_memtime s[68:69]", "s_waitcnt lgkmcnt(0)", "v_mov_b32_e32 %%[st%d], s68" % k] if STAMP else []
 
 
@@ -366,12 +475,6 @@ def emit(out):
           "v_readfirstlane_b32 s%d, %%[k_lo]" % DESC0[0], "v_readfirstlane_b32 s%d, %%[k_hi]" % (DESC0[0] + 1), "v_readfirstlane_b32 s%d, %%[nrec]" % (DESC0[0] + 2),
           "s_mov_b32 s%d, 0x00020000" % (DESC0[0] + 3), "v_readfirstlane_b32 %s, %%[soff0]" % S_SOFF0,
           "s_bfe_u32 %s, %%[ctl], 0x10004" % S_PF, "s_mov_b32 %s, 0" % S_REDO]
-    # the NEXT item's Q fragments, into the staging registers a[192:255]: they have the whole item to land and move into a[128:191] on the way out
-    # (16 loads of 64 rows x 32 bytes each: slow to issue - ~150 cycles apiece - and, issued in front of an item's row stores, they held those up too)
-    for g in (0, 1):
-        for ks in range(8):
-            r0 = 192 + 32 * g + 4 * ks
-            L += ["global_load_dwordx4 a[%d:%d], %%[nq%d], off%s" % (r0, r0 + 3, g, (" offset:%d" % (32 * ks)) if ks else "")]
     # ---------------- one pass over the item (re-entered once, with S_REDO = 1, when a row maximum outgrew its reference)
     L += [".Lf3_pass_%=:", "s_mov_b64 s[%d:%d], s[%d:%d]" % (DESC[0], DESC[0] + 1, DESC0[0], DESC0[0] + 1), "s_mov_b64 s[%d:%d], s[%d:%d]" % (DESC[0] + 2, DESC[0] + 3, DESC0[0] + 2, DESC0[0] + 3),
           "s_mov_b32 %s, %s" % (S_SOFFK, S_SOFF0),
@@ -399,19 +502,18 @@ def emit(out):
     # ---------------- while they fly: zero O^T, state
     L += ["v_mov_b32_e32 v%d, 0" % (RING + j) for j in range(4)] + ["s_nop 4"]
     for o in range(8):
-        L += ["v_mfma_f32_32x32x16_bf16 %%[o%d], v[%d:%d], v[%d:%d], 0" % (o, RING, RING + 3, RING, RING + 3)]
+        L += ["v_mfma_f32_32x32x16_bf16 a[%d:%d], v[%d:%d], v[%d:%d], 0" % (16 * o, 16 * o + 15, RING, RING + 3, RING, RING + 3)]
     for g in (0, 1):
         L += ["v_mov_b32_e32 v%d, 0" % (PB[(g, 1)] + i) for i in range(8)]
         L += ["v_mov_b32_e32 v%d, 0" % (L2[g] + i) for i in range(4)] + ["v_mov_b32_e32 v%d, 0xff800000" % MX[g]]
     L += ["v_mov_b32_e32 v%d, 0xff800000" % V_NINF]
     L += ["s_and_b32 %s, %s, 3" % (S_TMP, S_T), "s_lshl_b32 %s, %s, 14" % (S_TOFFK, S_TMP), "s_mov_b32 %s, %s" % (S_TOFFV, S_TOFFK)]      # V "tile -1" := tile 0's slot (finite data; its P is zero)
     L += [i.text for i in k_addr_from_toff()] + [i.text for i in v_addr_from_toff()]
-    # ---------------- this item's Q fragments and tile 0 have landed.  What may stay in flight, youngest last:
-    #   requested here:            [Q, first item only | the predecessor's row stores] [the 16 staging loads] [tiles 0, 1, 2]    -> tiles 1, 2: 16
-    #   requested by the predecessor: [tiles 0, 1, 2] [its row stores: 18 when ctl bit 7 says so, else fewer] [the 16 staging loads] -> 34, else 16
+    # ---------------- this item's Q fragments and tile 0 have landed.  Requested here: [Q, the workgroup's first item only | the predecessor's last
+    # row stores] [tiles 0, 1, 2]: the 16 requests of tiles 1, 2 may stay in flight.  Requested by the predecessor: it waited for its own Q requests,
+    # which were younger than the tiles - nothing to wait for (only its last row stores are still out).
     L += stamp(2)
-    L += ["s_cmp_eq_u32 %s, 1" % S_PF, "s_cbranch_scc0 .Lf3_w16_%=", "s_bitcmp1_b32 %[ctl], 7", "s_cbranch_scc0 .Lf3_w16_%=", "s_waitcnt vmcnt(34)", "s_branch .Lf3_landed_%=",
-          ".Lf3_w16_%=:", "s_waitcnt vmcnt(16)", ".Lf3_landed_%=:", "s_barrier"]
+    L += ["s_cmp_eq_u32 %s, 1" % S_PF, "s_cbranch_scc1 .Lf3_landed_%=", "s_waitcnt vmcnt(16)", ".Lf3_landed_%=:", "s_barrier"]
     L += stamp(3)
     lines, fifo = chain_block(M, range(48, 64), 0, [])      # S(0), keys 0..31
     assert not fifo
@@ -476,14 +578,17 @@ def emit(out):
     for g in (0, 1):
         L += ["v_cmp_lt_f32_e32 vcc, v%d, v%d" % (V_NINF, T[g]), "v_cndmask_b32_e32 v%d, 0, v%d, vcc" % (MREF[g], T[g])]
     L += ["s_mov_b32 %s, 1" % S_REDO, "s_mov_b32 %s, 0" % S_PF, "s_waitcnt vmcnt(0)", "s_branch .Lf3_pass_%="]
-    # ---------------- way out: the next item's Q fragments move in (they landed long ago: every tile wait of the loop was behind them; an item
-    # without iterations waits here)
-    L += [".Lf3_exit_%=:", "s_mov_b32 m0, %s" % S_M0SAVE, "s_waitcnt vmcnt(0)"]
-    L += ["v_accvgpr_mov_b32 a%d, a%d" % (128 + i, 192 + i) for i in range(64)]
-    for g in (0, 1):
-        L += ["v_pk_add_f32 %s, %s, %s" % (vr(L2[g], 2), vr(L2[g], 2), vr(L2[g] + 2, 2)), "v_add_f32_e32 %%[l%d], v%d, v%d" % (g, L2[g], L2[g] + 1),
-              "v_mov_b32_e32 %%[mr%d], v%d" % (g, MREF[g])]
+    # ---------------- way out.  Every wave has passed the vote's barrier: the ring slot of the item's last tile is free (the other three hold the next
+    # item's first tiles).  Per row group g: [the NEXT item's Q rows of the group requested by LDS-DMA into this wave's 8 KiB of that slot - whole
+    # 1-KiB pieces through a descriptor over the next sequence's Q rows, rows outside it arrive as zeros] [this item's rows of the group: O = O^T / l,
+    # bf16, 16-byte pieces traded between the two lanes of a row (v_permlane32_swap), 8 row stores + the lse - in the shadow of the request]
+    # [the fragments read back from LDS straight into the Q registers].  The 64 x 32-byte gather this replaces took the CU's address unit
+    # ~4 500 cycles per item for its four waves (and, issued in front of the row stores, held those up as well).
+    L += [".Lf3_exit_%=:"]
     L += stamp(6)
+    L += tail_code()
+    L += ["s_mov_b32 m0, %s" % S_M0SAVE]
+    L += stamp(7)
     L = [x for l in L for x in l.replace("\\n\\t", "\n").split("\n")]
     diag = os.environ.get("FWD3_DIAG", "")      # timing experiments only (results are wrong): nodma / nobar, comma separated
     if "nodma" in diag:
@@ -496,7 +601,7 @@ def emit(out):
             f.write('"%s\\n\\t"\n' % l)
     with open(out.replace(".inc", "_clobbers.inc"), "w") as f:
         f.write("// generated by gen_fwd3_loop.py - do not edit\n")
-        f.write(", ".join('"v%d"' % i for i in range(64, V_LAST + 1)) + ",\n" + ", ".join('"a%d"' % i for i in range(192, 256)) + ",\n" +
+        f.write(", ".join('"v%d"' % i for i in range(64, V_LAST + 1)) + ",\n" + ", ".join('"a%d"' % i for i in range(0, 128)) + ",\n" +
                 ", ".join('"s%d"' % i for i in range(S_FIRST - 4, S_LAST + 1)) + ', "vcc", "scc", "memory"\n')
     print("%s: %d asm lines" % (out, len(L)))
 

@@ -14,11 +14,12 @@
 // keys; a later score may exceed it by 2^64 (RESCALE_AT of the two-wave kernel) before anything is lost.  In the rare case that one does, the
 // WHOLE row block is repeated with m_ref = the true row maximum, which the first pass has just measured exactly - no approximation, no other
 // kernel involved (test_sdpa_exponent_reference_moves_when_later_keys_dominate).
-// LDS: K ring [4][64][128] bf16 at 0, V ring at 64 KiB, the workgroup's vote words.
+// LDS: K ring [4][64][128] bf16 at 0, V ring at 64 KiB, the workgroup's vote words, 4 KiB per wave for the transposition of its output rows.
 
 constexpr int FWD3_TILE = 64 * 128 * 2;
 constexpr int FWD3_MAIL = 8 * FWD3_TILE;      // (gen_fwd3_loop.py: MAIL_LDS)
-constexpr int FWD3_LDS = FWD3_MAIL + 64;
+constexpr int FWD3_OSTAGE = FWD3_MAIL + 128;      // (gen_fwd3_loop.py: OSTAGE_LDS) 4 x 4 KiB: the waves' staging areas for their output rows
+constexpr int FWD3_LDS = FWD3_OSTAGE + 4 * 4096;
 constexpr float FWD3_RESCALE_AT = 64.f;      // log2 units
 
 // Everything the generated block needs to know about one (sequence, head, 256-row block) item; wave-uniform unless noted.
@@ -131,7 +132,7 @@ __device__ __forceinline__ void fwd3_load_q(u32x4 (&qf)[16], const bf16_t* q0, c
 // is the workgroup's next item: this item's block requests its first three K / V tiles from its last iterations (which have no tile of their
 // own left to ask for) when they are three whole ordinary tiles.  prefetched / ring_base: in - what the previous item did for this one; out - for the next.
 __device__ __forceinline__ void sdpa_fwd3_item(const SdpaParams& p, char* smem, const Fwd3Cursor& cur, const Fwd3Cursor& nxt, bool nxt_valid, bool& prefetched,
-                                               bool& stores18, int& ring_base, u32x4 (&qf)[16], int wave, int lane_in, int parity) {
+                                               int& ring_base, u32x4 (&qf)[16], int wave, int lane_in, int parity) {
     constexpr int D = 128, BM = 256;
 #ifdef HALVA_STAMP
     unsigned long long stamp_t0;
@@ -188,15 +189,47 @@ __device__ __forceinline__ void sdpa_fwd3_item(const SdpaParams& p, char* smem, 
         }
     }
     npf = dkv3_uni(npf);
-    const unsigned ctl0 = dkv3_uni((unsigned)((ring_base & 3) | (pf ? 16 : 0) | ((pf && stores18) ? 128 : 0) | (parity ? 1024 : 0)) | (npf << 5) | (first_state << 8));
 
-    // the rows whose Q fragments the block stages for its successor (none: this item's again)
-    const bf16_t* nq0 = fwd3_q_row(p, nxt_valid ? nxt : cur, wave, lane, 0);
-    const bf16_t* nq1 = fwd3_q_row(p, nxt_valid ? nxt : cur, wave, lane, 1);
-    f32x16 acc[8];
-    float l[2], mr[2];
+    // the NEXT item's Q rows (none: a descriptor without records - zeros): fetched by the block's tail through LDS, one row group after the other.
+    // Piece c of a group's half-tile image = rows 8 (c / 2) .. + 7, chunks 8 (c % 2) .. + 7: the scalar offset carries the band, the
+    // instruction's immediate the chunk half, the lane offset row-in-band, chunk and the image's swizzle (two variants: band parity).  A row in
+    // front of the sequence (left padding) puts its lane beyond the descriptor's range through a negative lane offset: zeros, like a row behind it.
+    const Fwd3Cursor& qn = nxt_valid ? nxt : cur;
+    const unsigned long long nq_base = (unsigned long long)(size_t)(p.q + qn.hd * D + ((int64_t)qn.s * p.T + qn.start) * p.ld_qkv);
+    const unsigned nqrec = (nxt_valid && qn.len > 0) ? (unsigned)((int64_t)(qn.len - 1) * p.ld_qkv * 2 + D * 2) : 0u;
+    unsigned nqsoff[2], nqv[2][2];
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+        const int qlg0 = qn.qb() * BM + 64 * wave + 32 * gi - qn.start;
+        nqsoff[gi] = (unsigned)((int64_t)max(qlg0, 0) * p.ld_qkv * 2);
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+            nqv[gi][pb] = (unsigned)((int64_t)(min(qlg0, 0) + (r >> 2)) * p.ld_qkv * 2) + 16u * (4u * h + ((lane & 3) ^ ((2 * pb + (r >> 4)) & 3)));
+    }
+    const unsigned rows8 = dkv3_uni((unsigned)(8 * p.ld_qkv * 2));
+    // (a next row block that begins in front of its sequence - left padding - has its fragments gathered row by row with clamped pointers instead)
+    const bool q_gather = nxt_valid && qn.qb() * BM < qn.start;
+    const bf16_t* nqg0 = fwd3_q_row(p, qn, wave, lane, 0);
+    const bf16_t* nqg1 = fwd3_q_row(p, qn, wave, lane, 1);
+    // this item's rows: the wave's first output row / lse entry (uniform) + per-lane offsets; the lse offset's low bits say whether the row
+    // exists in the tensor (bit 0) and is a row of the sequence (bit 1)
+    const unsigned long long o_base = (unsigned long long)(size_t)(p.o + hd * D + (seq_row0 + g0 + 64 * wave) * p.ld_o);
+    const unsigned long long lse_base = (unsigned long long)(size_t)(p.lse + ((int64_t)s * p.H + hd) * p.T + g0 + 64 * wave);
+    unsigned loff[2];
+    int nT[2];
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+        const int gqs = g0 + 64 * wave + 32 * gi + r;
+        const bool in_T = gqs < p.T, valid = in_T && ql[gi] >= 0 && ql[gi] < len;
+        loff[gi] = 4u * (32 * gi + r) | (in_T ? 1u : 0u) | (valid ? 2u : 0u);
+        nT[gi] = min(32, max(0, p.T - (g0 + 64 * wave + 32 * gi)));      // rows of the group that exist in the tensor
+    }
+    // (the row stores: a store instruction writes rows 8 j + (lane >> 3), 16 bytes (lane & 7) of a 128-byte half row each)
+    const unsigned ooffc = (unsigned)((int64_t)(lane >> 3) * p.ld_o * 2) + 16u * (lane & 7);
+    const unsigned rows8o = dkv3_uni((unsigned)(8 * p.ld_o * 2)), nt01 = dkv3_uni((unsigned)nT[0] | ((unsigned)nT[1] << 8));
+    const unsigned ctl0 = dkv3_uni((unsigned)((ring_base & 3) | (pf ? 16 : 0) | (parity ? 1024 : 0) | (q_gather ? 2048 : 0)) | (npf << 5) | (first_state << 8));
 #ifdef HALVA_STAMP
-    unsigned st_[7];
+    unsigned st_[8];
     unsigned long long tc_[6];
     tc_[0] = stamp_t0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc_[1])::"memory");
@@ -208,31 +241,14 @@ __device__ __forceinline__ void sdpa_fwd3_item(const SdpaParams& p, char* smem, 
 #endif
     prefetched = npf != 0;
     ring_base = (ring_base + N) & 3;      // (a repeat pass starts from the same slot)
-    stores18 = g0 + 64 * wave + 32 < p.T;      // both row groups have a row to store: 2 x 8 row stores + 2 lse stores are issued below
-    // ---- the rows: O = O^T / l (the lane = row layout of store_rows_T), lse.  (Row numbers and pointers are formed HERE, from the lane number
-    // again: kept across the asm block they cost registers the block's operands need - spilled, and a scratch reload waits for every request in flight)
-    int lane2 = lane_in;
-    asm volatile("" : "+v"(lane2));
-#pragma unroll
-    for (int gi = 0; gi < 2; ++gi) {
-        const float l_tot = xhalf_sum(l[gi]);
-        const int gqs = g0 + 64 * wave + 32 * gi + (lane2 & 31), qls = gqs - start;
-        const bool in_T = gqs < p.T, valid = in_T && qls >= 0 && qls < len;
-        const float inv = (valid && l_tot > 0.f) ? 1.f / l_tot : 0.f;
-        if (in_T) {
-            const f32x16(&a4)[4] = *reinterpret_cast<const f32x16(*)[4]>(&acc[4 * gi]);
-            store_rows_T<D>(p.o + (seq_row0 + gqs) * p.ld_o + hd * D, a4, inv, true, lane2);
-            if ((lane2 >> 5) == 0 && p.lse) p.lse[((int64_t)s * p.H + hd) * p.T + gqs] = valid ? (mr[gi] + log2f(l_tot)) * kLn2 : 0.f;
-        }
-    }
 #ifdef HALVA_STAMP
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc_[5])::"memory");
     if (p.dbg && lane == 0 && blockIdx.x % 9 == 0 && blockIdx.x / 9 < 30 && cur.vb < (int)(2 * gridDim.x)) {      // slot: [block][item][wave][16]: the first four items
         unsigned long long* o_ = p.dbg + (((blockIdx.x / 9) * 4 + 2 * (cur.vb >= (int)gridDim.x) + cur.which) * 4 + wave) * 16;
         for (int i = 0; i < 6; ++i) o_[i] = tc_[i];
-        for (int i = 0; i < 7; ++i) o_[6 + i] = st_[i];
-        o_[13] = (unsigned long long)N | ((unsigned long long)qb << 16) | ((unsigned long long)blockIdx.x << 32);
-        o_[14] = (unsigned long long)g.n0 | ((unsigned long long)g.n1 << 16) | ((unsigned long long)g.n2 << 32) | ((unsigned long long)g.n3 << 48);
+        for (int i = 0; i < 8; ++i) o_[6 + i] = st_[i];
+        o_[14] = (unsigned long long)N | ((unsigned long long)qb << 16) | ((unsigned long long)blockIdx.x << 32);
+        o_[15] = (unsigned long long)g.n0 | ((unsigned long long)g.n1 << 16) | ((unsigned long long)g.n2 << 32) | ((unsigned long long)g.n3 << 48);
     }
 #endif
 }
@@ -250,7 +266,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     Fwd3Cursor cur;
     cur.vb = blockIdx.x;
     fwd3_cursor_load(p, cur, total);
-    bool prefetched = false, stores18 = false;
+    bool prefetched = false;
     int ring_base = 0, parity = 0;
     u32x4 qf[16];      // the Q fragments, in a[128:191] from here on: loaded here for the first item, by every block for its successor
     if (cur.vb < total) fwd3_load_q(qf, fwd3_q_row(p, cur, wave, lane, 0), fwd3_q_row(p, cur, wave, lane, 1));
@@ -258,7 +274,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     while (cur.vb < total) {
         Fwd3Cursor nxt = cur;
         fwd3_cursor_advance(p, nxt, total);
-        sdpa_fwd3_item(p, smem, cur, nxt, nxt.vb < total, prefetched, stores18, ring_base, qf, wave, lane, parity);
+        sdpa_fwd3_item(p, smem, cur, nxt, nxt.vb < total, prefetched, ring_base, qf, wave, lane, parity);
         cur = nxt;
         parity ^= 1;
     }

@@ -21,6 +21,10 @@ def run(S, T, lens, br_a=None, br_b=None, tag=""):
         e[0].record(); out = K.sdpa_causal(q, ss, sl, H, D, a, b); e[1].record(); out.backward(dout); e[2].record()
         torch.cuda.synchronize(); tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2])
     print("%-44s fwd %.3f ms  bwd %.3f ms" % (tag, tf / n, tb / n))
-run(16, 2048, [2048] * 16, tag="16 plain rows of 2048 (8 pairs, two rows each)")
-run(8, 3428, [3428] * 8, [668] * 8, [2048] * 8, tag="8 packed rows [668 | 1380 | 1380]")
-run(8, 3428, [3428] * 8, tag="8 plain causal rows of 3428 (for scale)")
+if os.environ.get("BENCH_STEP_SHAPES") == "1":      # the two launches of the 7B step's one-group default: 16 packed pairs, 16 reference rows
+    run(16, 3428, [3428] * 16, [668] * 16, [2048] * 16, tag="16 packed rows [668 | 1380 | 1380]")
+    run(16, 2048, [2048] * 16, tag="16 plain rows of 2048")
+else:
+    run(16, 2048, [2048] * 16, tag="16 plain rows of 2048 (8 pairs, two rows each)")
+    run(8, 3428, [3428] * 8, [668] * 8, [2048] * 8, tag="8 packed rows [668 | 1380 | 1380]")
+    run(8, 3428, [3428] * 8, tag="8 plain causal rows of 3428 (for scale)")

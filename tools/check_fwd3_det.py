@@ -46,9 +46,9 @@ def check(name, S, T, H, lens=None, br_a=None, br_b=None, reps=6, scale=1.0):
             print("   rep %d: %d output elements / %d lse differ, max |diff| %.3e, rows e.g. %s" % (r, nd, nl, float(d.max()), rows[:6].tolist()))
     oo, lo = run(qkv, lens, br_a, br_b, H, "0")
     d = (o0.float() - oo.float()).abs()
-    tol = 2.0 ** -7 * oo.float().abs() + 1e-3
+    tol = 2.0 ** -6 * oo.float().abs() + 2e-3      # two bf16 output ulps (rows with few keys: the two kernels round P against different references)
     nbig = int((d > tol).sum())
-    print("%-28s repeats %s | vs two-wave kernel: max |diff| %.3e, %d of %d elements beyond one bf16 rounding, lse max diff %.2e"
+    print("%-28s repeats %s | vs two-wave kernel: max |diff| %.3e, %d of %d elements beyond two bf16 roundings, lse max diff %.2e"
           % (name, "BIT-IDENTICAL" if not bad else "%d of %d DIFFER" % (bad, reps), float(d.max()), nbig, d.numel(), float((l0 - lo).abs().max())))
     if nbig:
         rows = torch.nonzero((d > tol).any(dim=2))

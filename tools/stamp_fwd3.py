@@ -42,27 +42,27 @@ for b in range(30):
             r = a[b, it, w]
             if r[5] == 0:
                 continue
-            N, qb, blk = int(r[13]) & 0xffff, (int(r[13]) >> 16) & 0xffff, int(r[13]) >> 32
-            n = [(int(r[14]) >> (16 * k)) & 0xffff for k in range(4)]
-            st = r[6:13]
+            N, qb, blk = int(r[14]) & 0xffff, (int(r[14]) >> 16) & 0xffff, int(r[14]) >> 32
+            n = [(int(r[15]) >> (16 * k)) & 0xffff for k in range(4)]
+            st = r[6:14]
             rows.append(dict(blk=blk, it=it, w=w, N=N, qb=qb, n=n, pre=int(r[1] - r[0]), asm=int(r[2] - r[1]), post=int(r[5] - r[2]), vote=int(r[3] - r[2]), qld=int(r[4] - r[3]), rows_=int(r[5] - r[4]),
                              req=d32(st[1], st[0]), zero=d32(st[2], st[1]), land=d32(st[3], st[2]), s0=d32(st[4], st[3]), loop=d32(st[5], st[4]),
-                             drain=d32(st[6], st[5]), t0=int(r[0]), t3=int(r[5])))
-print("%4s %2s %1s %3s %2s %-14s | %6s %7s %6s (%5s %5s %5s) | %5s %5s %6s %5s %8s %6s %5s" % ("blk", "it", "w", "N", "qb", "n0/n1/n2/n3", "pre", "asm", "post", "vote", "qload", "rows", "req", "zero", "land", "S0", "loop",
-                                                                           "/step", "drain"))
+                             drain=d32(st[6], st[5]), tail=d32(st[7], st[6]), t0=int(r[0]), t3=int(r[5])))
+print("%4s %2s %1s %3s %2s %-14s | %6s %7s %6s (%5s %5s %5s) | %5s %5s %6s %5s %8s %6s %5s %5s" % ("blk", "it", "w", "N", "qb", "n0/n1/n2/n3", "pre", "asm", "post", "vote", "qload", "rows", "req", "zero", "land", "S0", "loop",
+                                                                           "/step", "dr+vo", "tail"))
 for r in rows[:64]:
-    print("%4d %2d %1d %3d %2d %-14s | %6d %7d %6d (%5d %5d %5d) | %5d %5d %6d %5d %8d %6d %5d" % (r["blk"], r["it"], r["w"], r["N"], r["qb"], "/".join(map(str, r["n"])), r["pre"], r["asm"], r["post"], r["vote"], r["qld"], r["rows_"],
-                                                                                 r["req"], r["zero"], r["land"], r["s0"], r["loop"], r["loop"] // max(1, r["N"]), r["drain"]))
+    print("%4d %2d %1d %3d %2d %-14s | %6d %7d %6d (%5d %5d %5d) | %5d %5d %6d %5d %8d %6d %5d %5d" % (r["blk"], r["it"], r["w"], r["N"], r["qb"], "/".join(map(str, r["n"])), r["pre"], r["asm"], r["post"], r["vote"], r["qld"], r["rows_"],
+                                                                                 r["req"], r["zero"], r["land"], r["s0"], r["loop"], r["loop"] // max(1, r["N"]), r["drain"], r["tail"]))
 rows = [r for r in rows if 0 < r["N"] <= 64 and abs(r["asm"]) < 10 ** 7]
 tot = {}
 for r in rows:
-    for k in ("pre", "asm", "post", "req", "zero", "land", "s0", "loop", "drain"):
+    for k in ("pre", "asm", "post", "req", "zero", "land", "s0", "loop", "drain", "tail"):
         tot[k] = tot.get(k, 0) + r[k]
     tot["steps"] = tot.get("steps", 0) + r["N"]
     tot["items"] = tot.get("items", 0) + 1
-print("per item (mean over %d wave-items): pre %d asm %d post %d | req %d zero %d land %d S0 %d loop %d (%.0f per step) drain %d"
+print("per item (mean over %d wave-items): pre %d asm %d post %d | req %d zero %d land %d S0 %d loop %d (%.0f per step) drain+vote %d tail %d"
       % (tot["items"], tot["pre"] / tot["items"], tot["asm"] / tot["items"], tot["post"] / tot["items"], tot["req"] / tot["items"], tot["zero"] / tot["items"],
-         tot["land"] / tot["items"], tot["s0"] / tot["items"], tot["loop"] / tot["items"], tot["loop"] / tot["steps"], tot["drain"] / tot["items"]))
+         tot["land"] / tot["items"], tot["s0"] / tot["items"], tot["loop"] / tot["items"], tot["loop"] / tot["steps"], tot["drain"] / tot["items"], tot["tail"] / tot["items"]))
 # workgroup life: entry of item 0 to end of item 1 of wave 0, vs the sum of its parts
 life = {}
 for r in rows:
