@@ -22,23 +22,29 @@ n02 / n1 the steps of the three phases (masked | plain | masked: the diagonal st
 ndma the steps that request a tile (+ the next item's tiles << 8, see dma_groups), wave, q_piece / do_piece the bytes between a wave's pieces (16 rows) ("s");
 lo0 / range the masks' per-lane bounds ("v"): a score of key kl and row ql = qt0 + 4 h + c (c = the register's row inside the step) survives
 iff unsigned(c - lo) < range with lo = kl - qt0 - 4 h of the first step (the loop subtracts 64 per step) and range = len - kl (0 = lane off);
-alt_q0-3 / alt_do0-3 / alt_stat the lane offsets of the pieces / the statistics row of a PARTIAL last tile (rows clamped to the sequence) ("v");
-safe_q / safe_do / safe_l always-valid addresses that the requests of the steps without a tile left read into the dummy chunk ("s");
+alt_stat the lane offset of the statistics row of a PARTIAL last tile (rows clamped to the sequence) ("v");
+safe_l an always-valid address that the statistics requests of the steps without a tile left read into the dummy chunk ("s");
 ctl the control word (CTL_* below) ("s"); drawn ("=&v") what the home queue's counter at sched_ptr ("v", 64 bit) answered (first call, thread 0);  every other address arrives as the low / high word of a uniform value in VECTOR registers
-(x_lo, x_hi: scalar operands are scarce, and when they run out the compiler silently hands the asm a vector register): q / do the first row
-of the first tile to request, lse / nd its statistics rows, ds the dS pointer of the first step (this wave's strip).  The rows of the
-workgroup's NEXT item (nq / ndo / nlse / nnd: low / high words in vector registers too) are requested by the block's last three steps
-(ndma bits 8-15: how many of its tiles).
+(x_lo, x_hi: scalar operands are scarce, and when they run out the compiler silently hands the asm a vector register): q / do the sequence's
+first Q / dO row of this head (the base of a buffer descriptor; q_rec / do_rec its bytes, q_soff / do_soff the first tile to request in bytes
+from that row), lse / nd the statistics rows of the first tile to request, ds the dS pointer of the first step (this wave's strip).  The rows of
+the workgroup's NEXT item (nq / ndo + nqrec / ndorec / nqsoff / ndosoff, nlse / nnd: in vector registers too) are requested by the block's
+last three steps (ndma bits 8-15: how many of its tiles).
 The masked phases cost three more vector instructions per score."""
 import sys
 
 LOOKAHEAD, CAP, CAP_MASKED = 6, 5, 9
 X = [64, 96]; Y = [80, 112]; PB = [128, 144]; ZB = [136, 152]; SL = 160; RING = 176
 QRE, QRO, DRE, DRO, QC0, QC1, DC0, DC1, STAT, DSOFF, LANE4, LANE, V_LO, V_T, V_NINF = 208, 209, 210, 211, 212, 213, 214, 215, 216, 217, 218, 219, 220, 221, 222
-S_SLOT, S_CNT, S_DMALEFT, S_TOFF, S_TMP, S_TMP2 = "s72", "s73", "s74", "s75", "s76", "s77"
-QP, DP, LP, NP, DSP = (78, 79), (80, 81), (82, 83), (84, 85), (86, 87)
+S_SLOT, S_CNT, S_DMALEFT, S_TOFF, S_TMP, S_TMP2 = "s72", "s73", "s74", "s75", "s80", "s81"
+LP, NP, DSP = (82, 83), (84, 85), (86, 87)
 S_DSTQ, S_M0SAVE, S_DSTS, S_USEALT, S_ISSUED = "s88", "s89", "s90", "s91", "s96"
-QORG, DORG, SRC = (92, 93), (94, 95), (98, 99)
+SRC = (98, 99)
+# Q / dO tiles arrive through bounds-checked buffer descriptors over the sequence's rows of this head (round 4: as sdpa_fwd3's K / V tiles): a row past
+# the sequence arrives as ZEROS (experiments/fwd3/oob_probe.hip), so the partial last tile and the requests past the block's end need no case of
+# their own - three instructions per 1-KiB piece instead of ten.  The statistics rows (two dword requests per step) keep the pointer form.
+QDESC, DDESC = (92, 95), (76, 79)
+S_SOFFQ, S_SOFFD = "s70", "s71"
 DUMMY_LDS = 133120                  # 1 KiB behind the statistics: where the requests of the steps without a tile land
 MASKED = False
 PHASE = "a"
@@ -165,32 +171,34 @@ def addr_setup():
     return o
 
 
+def sq(quad):
+    return "s[%d:%d]" % quad
+
+
 def dma_groups():
     """[list of instruction texts] x 10: the requests of the tile three steps ahead - WITHOUT a taken branch on the common path (a taken
-    branch costs the wave tens of cycles, and eleven of them per step were a sixth of the step).  When no tile is left (the last steps of a
-    key block) the requests are still issued, redirected to a 1-KiB dummy chunk of LDS and to the first tile's rows: harmless, and the
-    step's vector-memory operations stay the same fourteen, so the wait for tile t+1 is ONE counted vmcnt in every step.  Only the partial
-    last tile of a sequence (rows clamped piece by piece: S_USEALT) leaves the line, to code behind the loop (`ool`)."""
+    branch costs the wave tens of cycles, and eleven of them per step were a sixth of the step).  Q / dO pieces: `buffer_load_dwordx4 ... offen lds`
+    through the sequence's descriptors - a piece past the sequence's last row brings zeros, a request past the block's last tile lands in a ring slot
+    nobody reads any more: no special case, and every step has the same vector-memory operations, so the wait for tile t+1 is ONE counted vmcnt.
+    The two statistics rows keep the pointer form: when no tile is left they are redirected to a 1-KiB dummy chunk of LDS, and the partial last
+    tile of a sequence (rows clamped: S_USEALT) leaves the line, to code behind the loop (`ool`)."""
     groups, ool = [], []
     # S_DMALEFT: bits 0-7 tiles of this block still to request; bits 8-15 tiles of the workgroup's NEXT item to request behind them (the steps
-    # of a block that have no tile of their own left to ask for - its last three - ask for the next item's first tiles instead of the dummy:
+    # of a block that have no tile of their own left to ask for - its last three - ask for the next item's first tiles:
     # same slot rotation, so the next block simply starts on a rotated ring; free of charge, where a prefetch block of its own behind the
-    # steps cost 3 700 cycles per item); bit 16: that switch has been made (it also keeps the partial-tile path off the next item's tiles)
+    # steps cost 3 700 cycles per item); bit 16: that switch has been made (it also keeps the partial-tile path off the next item's rows)
     pre = ["s_and_b32 s97, %s, 0xff" % S_DMALEFT, "s_cmp_eq_u32 s97, 0", "s_cbranch_scc1 .Ldkv3_sw%s_%%=" % PHASE, ".Ldkv3_swb%s_%%=:" % PHASE,
            "s_add_u32 %s, %s, 3" % (S_TMP, S_SLOT), "s_and_b32 %s, %s, 3" % (S_TMP, S_TMP), "s_lshl_b32 %s, %s, 14" % (S_DSTQ, S_TMP),
            "s_lshl_b32 %s, %%34, 10" % S_TMP2, "s_add_u32 %s, %s, %s" % (S_DSTQ, S_DSTQ, S_TMP2), "s_lshl_b32 %s, %s, 8" % (S_DSTS, S_TMP),
            "s_add_u32 %s, %s, %d" % (S_DSTS, S_DSTS, LSE_LDS),
            "s_and_b32 %s, %s, 0xff" % (S_ISSUED, S_DMALEFT), "s_min_u32 %s, %s, 1" % (S_ISSUED, S_ISSUED),
            "s_and_b32 %s, %s, 0x100ff" % (S_USEALT, S_DMALEFT), "s_bfe_u32 s97, %[ctl], 0x10008", "s_cmp_eq_u32 %s, 1" % S_USEALT, "s_cselect_b32 %s, s97, 0" % S_USEALT,
-           "s_mov_b64 %s, %s" % (sp(QORG), sp(QP)), "s_mov_b64 %s, %s" % (sp(DORG), sp(DP))]
+           "s_mov_b32 m0, %s" % S_DSTQ]
     k = 0
-    for which, ptr, org, voff, piece, base, alt0, safe in (("q", QP, QORG, "%27", "%37", 0, 43, "%55"), ("do", DP, DORG, "%28", "%38", DO_LDS, 47, "%56")):
+    for which, desc, soff, voff, piece, base in (("q", QDESC, S_SOFFQ, "%27", "%37", 0), ("do", DDESC, S_SOFFD, "%28", "%38", DO_LDS)):
         for i in range(4):
-            g = ["s_add_u32 %s, %s, %d" % (S_TMP, S_DSTQ, base + 4096 * i), "s_cmp_lg_u32 %s, 0" % S_ISSUED, "s_cselect_b32 m0, %s, %d" % (S_TMP, DUMMY_LDS),
-                 "s_cselect_b64 %s, %s, %s" % (sp(SRC), sp(ptr), safe), "s_cmp_lg_u32 %s, 0" % S_USEALT, "s_cbranch_scc1 .Ldkv3_a%d%s_%%=" % (k, PHASE),
-                 "global_load_lds_dwordx4 %s, %s" % (voff, sp(SRC)), ".Ldkv3_j%d%s_%%=:" % (k, PHASE),
-                 "s_add_u32 s%d, s%d, %s" % (ptr[0], ptr[0], piece), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])]
-            ool += [".Ldkv3_a%d%s_%%=:" % (k, PHASE), "global_load_lds_dwordx4 %%%d, %s" % (alt0 + i, sp(org)), "s_branch .Ldkv3_j%d%s_%%=" % (k, PHASE)]
+            g = (["s_add_u32 m0, %s, %d" % (S_DSTQ, base), "s_nop 0"] if (base and i == 0) else [])
+            g += ["buffer_load_dwordx4 %s, %s, %s offen lds" % (voff, sq(desc), soff), "s_add_u32 %s, %s, %s" % (soff, soff, piece), "s_add_u32 m0, m0, 4096"]
             groups.append((pre if k == 0 else []) + g)
             k += 1
     for ptr, extra, safe in ((LP, 0, "%57"), (NP, ND_DELTA, "%57")):
@@ -201,10 +209,13 @@ def dma_groups():
         ool += [".Ldkv3_a%d%s_%%=:" % (k, PHASE), "global_load_lds_dword %%51, %s" % sp(ptr), "s_branch .Ldkv3_j%d%s_%%=" % (k, PHASE)]
         groups.append(g)
         k += 1
-    ool += [".Ldkv3_sw%s_%%=:" % PHASE, "s_bitcmp1_b32 %s, 16" % S_DMALEFT, "s_cbranch_scc1 .Ldkv3_swb%s_%%=" % PHASE,      # already switched: dummies from here on
+    ool += [".Ldkv3_sw%s_%%=:" % PHASE, "s_bitcmp1_b32 %s, 16" % S_DMALEFT, "s_cbranch_scc1 .Ldkv3_swb%s_%%=" % PHASE,      # already switched: nothing left
             "s_lshr_b32 %s, %s, 8" % (S_DMALEFT, S_DMALEFT), "s_or_b32 %s, %s, 0x10000" % (S_DMALEFT, S_DMALEFT),
             "s_and_b32 s97, %s, 0xff" % S_DMALEFT, "s_cmp_eq_u32 s97, 0", "s_cbranch_scc1 .Ldkv3_swb%s_%%=" % PHASE]            # no next item to serve
-    for k, ptr in enumerate((QP, DP, LP, NP)):
+    ool += ["v_readfirstlane_b32 s%d, %%[nq_lo]" % QDESC[0], "v_readfirstlane_b32 s%d, %%[nq_hi]" % (QDESC[0] + 1), "v_readfirstlane_b32 s%d, %%[nqrec]" % (QDESC[0] + 2),
+            "v_readfirstlane_b32 s%d, %%[ndo_lo]" % DDESC[0], "v_readfirstlane_b32 s%d, %%[ndo_hi]" % (DDESC[0] + 1), "v_readfirstlane_b32 s%d, %%[ndorec]" % (DDESC[0] + 2),
+            "v_readfirstlane_b32 %s, %%[nqsoff]" % S_SOFFQ, "v_readfirstlane_b32 %s, %%[ndosoff]" % S_SOFFD]
+    for k, ptr in ((2, LP), (3, NP)):
         ool += ["v_readfirstlane_b32 s%d, %%[n%s_lo]" % (ptr[0], ("q", "do", "lse", "nd")[k]), "v_readfirstlane_b32 s%d, %%[n%s_hi]" % (ptr[1], ("q", "do", "lse", "nd")[k])]
     ool += ["s_nop 3", "s_branch .Ldkv3_swb%s_%%=" % PHASE]
     return groups, ool
@@ -356,7 +367,14 @@ def main():
            "v_mbcnt_lo_u32_b32 v%d, -1, 0" % LANE, "v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (LANE, LANE),
            "v_lshlrev_b32_e32 v%d, 4, v%d" % (DSOFF, LANE), "v_lshlrev_b32_e32 v%d, 2, v%d" % (LANE4, LANE),
            "s_bfe_u32 %s, %%[ctl], 0x20009" % S_SLOT, "s_mov_b32 %s, %%32" % S_DMALEFT] + \
-          ["v_readfirstlane_b32 s%d, %%[%s_%s]" % (ptr[w], nm, "lo" if w == 0 else "hi") for ptr, nm in ((QP, "q"), (DP, "do"), (LP, "lse"), (NP, "nd"), (DSP, "ds")) for w in (0, 1)] + [
+          ["v_readfirstlane_b32 s%d, %%[%s_%s]" % (ptr[w], nm, "lo" if w == 0 else "hi") for ptr, nm in ((LP, "lse"), (NP, "nd"), (DSP, "ds")) for w in (0, 1)] + [
+           # the sequence's Q / dO rows of this head as buffer descriptors (base, 0 stride, bytes up to the end of the last row, raw 32-bit format);
+           # q_soff / do_soff: the first tile to request, in bytes from the sequence's first row
+           "v_readfirstlane_b32 s%d, %%[q_lo]" % QDESC[0], "v_readfirstlane_b32 s%d, %%[q_hi]" % (QDESC[0] + 1), "v_readfirstlane_b32 s%d, %%[q_rec]" % (QDESC[0] + 2),
+           "s_mov_b32 s%d, 0x00020000" % (QDESC[0] + 3),
+           "v_readfirstlane_b32 s%d, %%[do_lo]" % DDESC[0], "v_readfirstlane_b32 s%d, %%[do_hi]" % (DDESC[0] + 1), "v_readfirstlane_b32 s%d, %%[do_rec]" % (DDESC[0] + 2),
+           "s_mov_b32 s%d, 0x00020000" % (DDESC[0] + 3),
+           "v_readfirstlane_b32 %s, %%[q_soff]" % S_SOFFQ, "v_readfirstlane_b32 %s, %%[do_soff]" % S_SOFFD,
 
            "s_lshl_b32 %s, %s, 14" % (S_TOFF, S_SLOT), "v_mov_b32_e32 v%d, %%41" % V_LO, "v_mov_b32_e32 v%d, 0xff800000" % V_NINF]
     global PHASE
@@ -378,14 +396,12 @@ def main():
         pro += [CTL_NPRO, "s_cmp_le_u32 s97, %d" % i, "s_cbranch_scc1 .Ldkv3_prodone_%="]
         pro += ["s_add_u32 %s, %s, %d" % (S_TMP, S_SLOT, i), "s_and_b32 %s, %s, 3" % (S_TMP, S_TMP), "s_lshl_b32 %s, %s, 14" % (S_DSTQ, S_TMP),
                 "s_lshl_b32 %s, %%34, 10" % S_TMP2, "s_add_u32 %s, %s, %s" % (S_DSTQ, S_DSTQ, S_TMP2), "s_lshl_b32 %s, %s, 8" % (S_DSTS, S_TMP),
-                "s_add_u32 %s, %s, %d" % (S_DSTS, S_DSTS, LSE_LDS), "s_mov_b64 %s, %s" % (sp(QORG), sp(QP)), "s_mov_b64 %s, %s" % (sp(DORG), sp(DP)),
+                "s_add_u32 %s, %s, %d" % (S_DSTS, S_DSTS, LSE_LDS),
                 CTL_PROALT, "s_cmp_eq_u32 s97, %d" % i, "s_cselect_b32 %s, 1, 0" % S_USEALT]
-        for which, ptr, org, voff, piece, base, alt0 in (("q", QP, QORG, "%27", "%37", 0, 43), ("do", DP, DORG, "%28", "%38", DO_LDS, 47)):
+        for which, desc, soff, voff, piece, base in (("q", QDESC, S_SOFFQ, "%27", "%37", 0), ("do", DDESC, S_SOFFD, "%28", "%38", DO_LDS)):
+            pro += ["s_add_u32 m0, %s, %d" % (S_DSTQ, base), "s_nop 0"]
             for k in range(4):
-                pro += ["s_add_u32 m0, %s, %d" % (S_DSTQ, base + 4096 * k), "s_cmp_lg_u32 %s, 0" % S_USEALT, "s_cbranch_scc1 .Ldkv3_pa%d%s%d_%%=" % (i, which, k),
-                        "global_load_lds_dwordx4 %s, %s" % (voff, sp(ptr)), "s_branch .Ldkv3_pj%d%s%d_%%=" % (i, which, k),
-                        ".Ldkv3_pa%d%s%d_%%=:" % (i, which, k), "global_load_lds_dwordx4 %%%d, %s" % (alt0 + k, sp(org)), ".Ldkv3_pj%d%s%d_%%=:" % (i, which, k),
-                        "s_add_u32 s%d, s%d, %s" % (ptr[0], ptr[0], piece), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])]
+                pro += ["buffer_load_dwordx4 %s, %s, %s offen lds" % (voff, sq(desc), soff), "s_add_u32 %s, %s, %s" % (soff, soff, piece), "s_add_u32 m0, m0, 4096", "s_nop 0"]
         for which, ptr, extra in (("l", LP, 0), ("n", NP, ND_DELTA)):
             pro += ["s_add_u32 m0, %s, %d" % (S_DSTS, extra), "s_cmp_lg_u32 %s, 0" % S_USEALT, "s_cbranch_scc1 .Ldkv3_pa%d%s_%%=" % (i, which),
                     "global_load_lds_dword v%d, %s" % (LANE4, sp(ptr)), "s_branch .Ldkv3_pj%d%s_%%=" % (i, which),
@@ -402,10 +418,9 @@ def main():
         lines += ["s_sub_u32 %s, %s, 1" % (S_CNT, S_CNT), "s_cmp_lg_u32 %s, 0" % S_CNT, "s_cbranch_scc1 .Ldkv3_loop%s_%%=" % phase, ".Ldkv3_skip%s_%%=:" % phase]
     lines += ["s_branch .Ldkv3_end_%="] + ool_a + ool_b + ool_c + [".Ldkv3_end_%=:", "s_waitcnt lgkmcnt(0)", "s_mov_b32 m0, %s" % S_M0SAVE]
     names = {24: "rowrel", 25: "colrel", 26: "statrel", 27: "voff_q", 28: "voff_do", 30: "sc", 32: "ndma", 34: "wave", 37: "q_piece", 38: "do_piece", 41: "lo0", 42: "range",
-             51: "alt_stat", 55: "safe_q", 56: "safe_do", 57: "safe_l"}
+             51: "alt_stat", 57: "safe_l"}
     names.update({i: "accV%d" % i for i in range(4)}); names.update({4 + i: "accK%d" % i for i in range(4)})
     names.update({8 + i: "kq%d" % i for i in range(8)}); names.update({16 + i: "vq%d" % i for i in range(8)})
-    names.update({43 + i: "alt_q%d" % i for i in range(4)}); names.update({47 + i: "alt_do%d" % i for i in range(4)})
     import re
     def named(l):      # the asm statement's operands are NAMED (sdpa_dkv3.h): the numbers above are this script's shorthand
         return re.sub(r"%(\d+)", lambda m: "%%[%s]" % names[int(m.group(1))], l)
@@ -430,7 +445,7 @@ def main():
             f.write('"%s\\n\\t"\n' % l)
     with open(os.environ.get("DKV3_OUT", "sdpa_dkv3_loop.inc").replace(".inc", "_clobbers.inc"), "w") as f:
         f.write("// generated by gen_dkv3_loop.py - do not edit\n")
-        f.write(", ".join('"v%d"' % i for i in range(64, 223)) + ",\n" + ", ".join('"s%d"' % i for i in range(72, 100)) + ', "vcc", "scc", "memory"\n')
+        f.write(", ".join('"v%d"' % i for i in range(64, 223)) + ",\n" + ", ".join('"s%d"' % i for i in range(70, 100)) + ', "vcc", "scc", "memory"\n')
     print("%s: %d asm lines" % (out, len(lines)))
 
 

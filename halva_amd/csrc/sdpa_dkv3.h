@@ -420,17 +420,18 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
             const float* lse2_g = p.lse2 + ((int64_t)s * p.H + hd) * p.T + cur.start;
             const float* nd_g = p.delta + ((int64_t)s * p.H + hd) * p.T + cur.start;
             char* ds_block = p.ds_ws + ((((int64_t)s * p.H + hd) * p.ds_nkb + kb) * p.ds_nt + q_begin / BQ) * 16384 + wave * 4096;
-            // a partial last tile: its rows are clamped to the sequence, piece by piece
-            unsigned alt_q[4], alt_do[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                alt_q[i] = dkv3_piece_voff(p.ld_qkv, wave, lane, i, cur.lr);
-                alt_do[i] = dkv3_piece_voff(p.ld_do, wave, lane, i, cur.lr);
-            }
+            // a partial last tile: its statistics rows are clamped to the sequence (its Q / dO rows past the end arrive as zeros: buffer descriptors)
             const unsigned alt_stat = 4 * min(lane, cur.lr - 1);
+            // the sequence's Q / dO rows of this head as buffer descriptors: base row, bytes up to the end of the last row
+            const unsigned long long q_base = (unsigned long long)(size_t)(qp + qrow0 * p.ld_qkv), do_base = (unsigned long long)(size_t)(dop + qrow0 * p.ld_do);
+            const unsigned q_rec = len > 0 ? (unsigned)((int64_t)(len - 1) * p.ld_qkv * 2 + D * 2) : 0u;
+            const unsigned do_rec = len > 0 ? (unsigned)((int64_t)(len - 1) * p.ld_do * 2 + D * 2) : 0u;
             // the next item's first tiles (requested by this item's last asm call)
-            const int64_t nrow0 = (int64_t)nxt.s * p.T + nxt.start + nxt.q_begin;
+            const int64_t nrow0 = (int64_t)nxt.s * p.T + nxt.start;
             const unsigned long long nq_ptr = (unsigned long long)(size_t)(qp0 + nxt.hd * D + nrow0 * p.ld_qkv), ndo_ptr = (unsigned long long)(size_t)(dop0 + nxt.hd * D + nrow0 * p.ld_do);
+            const unsigned nqrec = nxt.len > 0 ? (unsigned)((int64_t)(nxt.len - 1) * p.ld_qkv * 2 + D * 2) : 0u;
+            const unsigned ndorec = nxt.len > 0 ? (unsigned)((int64_t)(nxt.len - 1) * p.ld_do * 2 + D * 2) : 0u;
+            const unsigned nqsoff = (unsigned)((int64_t)nxt.q_begin * p.ld_qkv * 2), ndosoff = (unsigned)((int64_t)nxt.q_begin * p.ld_do * 2);
             const unsigned long long nl_ptr = (unsigned long long)(size_t)(p.lse2 + ((int64_t)nxt.s * p.H + nxt.hd) * p.T + nxt.start + nxt.q_begin);
             const unsigned long long nn_ptr = (unsigned long long)(size_t)(p.delta + ((int64_t)nxt.s * p.H + nxt.hd) * p.T + nxt.start + nxt.q_begin);
             // (fixed accumulator registers, the same in every asm statement that touches them: no copies; the block zeroes them on its first call)
