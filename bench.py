@@ -715,6 +715,15 @@ def main():
                 lin = 2 * ((27.06 + 1.31) + (27.06 + 2.62))
                 att = 2 * (1.10 + 2.75)
                 tf_exec = tf_pair - lin * (1 - row_ratio) - att * (1 - pair_ratio)
+            from halva_amd import llama as _llama
+            if _llama.TOP_ROWS and eng.last_top_rows:
+                # the top decoder layer's row-wise half (o, gate / up, down: (d^2 + 3 d F) of a layer's (4 d^2 + 3 d F) linear FLOPs) runs on
+                # the rows in front of a label only (halva_amd/llama.py:run_layers(rows=))
+                top = (4096.0 ** 2 + 3 * 4096.0 * 11008) / (4 * 4096.0 ** 2 + 3 * 4096.0 * 11008) / 32
+                skip = lambda k: 1.0 - eng.last_top_rows[k][0] / float(eng.last_top_rows[k][1]) if k in eng.last_top_rows else 0.0
+                rr = row_ratio if eng.last_packing is not None and eng.last_layout is not None else 1.0
+                tf_exec -= top * (2 * ((27.06 + 1.31) + (27.06 + 2.62)) * rr * skip("pairs")          # policy, pos / neg rows: fwd + bwd
+                                  + ((27.06 + 1.31) + (27.06 + 2.62)) * skip("ref") + 27.06 * skip("ref"))      # policy on the reference rows; reference model
         metric = {"7b": "paired-samples/sec (DPA step) LLaVA-1.5-7B @336px",
                   "13b": "paired-samples/sec (DPA step) LLaVA-1.5-13B @336px (extra workload, not the BASELINE metric)",
                   "vila13b": "paired-samples/sec (DPA step) VILA-13B @384px T=4096 (extra workload, not the BASELINE metric)"}[args.model]
@@ -742,6 +751,7 @@ def main():
                           "default's 16-pair group",
                           "oom_fallbacks_in_warmup": oom_fallbacks, "recompute": "none",
                           "parity_note": PARITY_NOTE,
+                          "top_layer_rows": {k: {"rows_run": v[0], "rows_of_the_pass": v[1]} for k, v in eng.last_top_rows.items()} or None,
                           "prefix_sharing": None if eng.last_packing is None else
                           {"rows_run": eng.last_packing[0], "rows_of_the_two_separate_sequences": eng.last_packing[1],
                            "note": "the correct and the hallucinated row of a pair share ONE pass over their common prefix "

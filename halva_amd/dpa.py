@@ -240,6 +240,19 @@ def _kept_rows(labels, row_of=None):
     return hid, dense, target
 
 
+def _distinct_rows(hid, dev):
+    """(uniq, inv) on the device: the distinct hidden rows `hid` names and, when a row is named twice (a packed pair's shared prefix
+    row predicts a token of BOTH responses), the map back (rows = h_uniq[inv]); (None, None) for an empty `hid`."""
+    if hid.numel() == 0:
+        return None, None
+    u, inv = np.unique(hid.numpy(), return_inverse=True)
+    if u.size == hid.numel():
+        u, order = hid.numpy(), None                # already distinct: keep the caller's order, no second gather
+    else:
+        order = torch.from_numpy(inv.astype(np.int64)).to(dev, non_blocking=True)
+    return torch.from_numpy(np.ascontiguousarray(u)).to(dev, non_blocking=True), order
+
+
 def model_spec(model):
     """What the step planner needs to know about a model wrapper: image tokens per image after the projector, the
     post-splice truncation length and padding side, and whether an image-less row advances the image index.
@@ -265,6 +278,7 @@ class DPAEngine:
         self.share_prefix = (os.environ.get("HALVA_SHARE_PREFIX", "1") != "0") if share_prefix is None else share_prefix
         self.last_packing = None
         self.last_layout = None
+        self.last_top_rows = {}          # {"pairs" | "ref": (rows the top layer's row-wise half ran on, rows of the pass)} (bench accounting)
         from .gemm_tuning import enable_tuned_gemms
         self.gemm_table = enable_tuned_gemms()      # measured hipBLASLt / rocBLAS kernel choices for the step's large matmuls
 
@@ -290,11 +304,11 @@ class DPAEngine:
             return torch.zeros(0, self.spec.n_patch, model.lm_head.weight.shape[1], dtype=torch.bfloat16, device=dev)
         return model.encode_images(self._images(batch, key, gp.images, dev))
 
-    def _hidden(self, model, plan, feats):
+    def _hidden(self, model, plan, feats, rows=None):
         m = model.get_model()
         dev = m.embed_tokens.weight.device
         embeds = K.splice_rows(m.embed_tokens.weight, feats, plan.src, plan.S, plan.T)
-        return model.hidden_states(embeds, None, plan.seq_start, plan.seq_len)
+        return model.hidden_states(embeds, None, plan.seq_start, plan.seq_len, rows=rows)
 
     def pair_group_loss(self, batch, plan, idx):
         """Contribution of the pairs `idx` to the alignment loss (already divided by B*P)."""
@@ -309,17 +323,21 @@ class DPAEngine:
             m = pol.get_model()
             embeds = K.splice_rows(m.embed_tokens.weight, feats, packed.src, g, packed.T)
             branch = tuple(t.to(dev, non_blocking=True) for t in (packed.br_a, packed.br_b, packed.pos))
-            h = pol.hidden_states(embeds, None, torch.zeros(g, dtype=torch.int32), packed.seq_len, branch=branch)
             hid, dense, target = _kept_rows(gp.labels, packed.row_of)
+            uniq, inv = _distinct_rows(hid, dev)
+            h = pol.hidden_states(embeds, None, torch.zeros(g, dtype=torch.int32), packed.seq_len, branch=branch, rows=uniq)
+            self.last_top_rows["pairs"] = (g * packed.T if uniq is None else int(uniq.numel()), g * packed.T)
             self.last_packing = (packed.rows_packed, packed.rows_unpacked)
             self.last_layout = (packed.T, packed.br_a.tolist(), packed.br_b.tolist(), packed.seq_len.tolist())      # host ints (bench accounting)
         else:
-            h = self._hidden(pol, gp, feats)
             hid, dense, target = _kept_rows(gp.labels)
+            uniq, inv = _distinct_rows(hid, dev)
+            h = self._hidden(pol, gp, feats, uniq)
+            self.last_top_rows["pairs"] = (2 * g * gp.T if uniq is None else int(uniq.numel()), 2 * g * gp.T)
         T1 = gp.T - 1
         logp_dense = torch.zeros(2 * g * T1, dtype=torch.float32, device=dev)
         if hid.numel():
-            rows = h.view(-1, h.shape[-1]).index_select(0, hid.to(dev, non_blocking=True))
+            rows = h if inv is None else h.index_select(0, inv)      # h: the rows `uniq` only (the top layer computed nothing else)
             lp = lm_head_logp(rows, pol.lm_head.weight, target.to(dev, non_blocking=True))
             logp_dense = logp_dense.index_copy(0, dense.to(dev, non_blocking=True), lp)
         logp_dense = logp_dense.view(2 * g, T1)
@@ -340,16 +358,15 @@ class DPAEngine:
         pol, ref = self.policy, self.ref_model
         dev = pol.device
         gp = plan.ref_group(idx)
-        h_pol = self._hidden(pol, gp, self._encode(pol, batch, "ref_images", gp, dev))
-        with torch.no_grad():
-            h_ref = self._hidden(ref, gp, self._encode(ref, batch, "ref_images", gp, dev))
-        hid, _, _ = _kept_rows(gp.labels)
-        if hid.numel() == 0:
+        hid, _, _ = _kept_rows(gp.labels)                      # (one layout, one label per row: distinct)
+        sel = hid.to(dev, non_blocking=True) if hid.numel() else None
+        h_pol = self._hidden(pol, gp, self._encode(pol, batch, "ref_images", gp, dev), sel)
+        self.last_top_rows["ref"] = (gp.S * gp.T if sel is None else int(sel.numel()), gp.S * gp.T)
+        if sel is None:
             return h_pol.sum() * 0.0, gp
-        sel = hid.to(dev, non_blocking=True)
-        d = h_pol.shape[-1]
-        kl = lm_head_kl(h_pol.view(-1, d).index_select(0, sel), h_ref.view(-1, d).index_select(0, sel), pol.lm_head.weight,
-                        ref.lm_head.weight)
+        with torch.no_grad():
+            h_ref = self._hidden(ref, gp, self._encode(ref, batch, "ref_images", gp, dev), sel)
+        kl = lm_head_kl(h_pol, h_ref, pol.lm_head.weight, ref.lm_head.weight)      # [n, d] each: the kept rows, in `hid` order
         return self.alpha * kl / plan.B, gp
 
     # -- whole micro-batch -------------------------------------------------------------------------

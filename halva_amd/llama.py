@@ -335,6 +335,32 @@ class SeqInfo:
         self.branch = branch       # (br_a, br_b, pos) of branch-packed rows, or None (halva_amd/kernels.py:_SdpaCausal)
 
 
+class _TakeRows(torch.autograd.Function):
+    """x[.., W] viewed as [rows, W] -> x[idx]; idx DISTINCT, so the backward is a copy into zeros (index_select's own backward is an
+    index_add: atomics on bf16)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.shape = x.shape
+        return x.view(-1, x.shape[-1]).index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        full = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        full.view(-1, full.shape[-1]).index_copy_(0, idx, g)
+        return full, None
+
+
+def _take_rows(x, idx):
+    return _TakeRows.apply(x, idx)
+
+
+# HALVA_TOP_ROWS=0: the top decoder layer runs on every row (A/B switch; results are identical row for row)
+TOP_ROWS = os.environ.get("HALVA_TOP_ROWS", "1") != "0"
+
+
 class DecoderLayer(nn.Module):
     """LlamaDecoderLayer (modelling_llama.py:352-420) with attention per llama_flash_attn_monkey_patch.py:16-93."""
 
@@ -355,15 +381,19 @@ class DecoderLayer(nn.Module):
     def groups(self):
         return (("self_attn", self.qkv), ("self_attn", self.o), ("mlp", self.gate_up), ("mlp", self.down))
 
-    def forward(self, x, info, use_lora=True, own_x=False):
+    def forward(self, x, info, use_lora=True, own_x=False, rows=None):
         """own_x: the caller will not look at `x` again (it is the previous layer's output): without autograd the residual adds then
-        run in place on it."""
+        run in place on it.
+        rows: int64 [n] distinct flat row indices into [S * T] (the TOP layer only, LlamaModel.run_layers): everything behind the
+        attention is row-wise, so the o projection, the post-attention norm and the MLP run on those rows alone and [n, d] is returned."""
         # every producer kernel writes straight into the (wider) operand buffer of the projection that follows it
         # (norm(x), x') come out of one autograd node so that the residual's gradient is added inside the norm's backward kernel, and
         # x' is a buffer of the block's own: the o / down projections accumulate onto it (no copy of the residual)
         h, x, mine = self.input_layernorm.fork(x, self.qkv.in_width, own_x)
         qkv = self.qkv(h, None, use_lora)
         a = K.attention(qkv, info.cos, info.sin, info.seq_start, info.seq_len, self.H, self.D, self.o.in_width, info.branch)
+        if rows is not None:
+            a, x, mine = _take_rows(a, rows), _take_rows(x, rows), RES_INPLACE      # (the gathered residual is a buffer of this block's own)
         x = self.o(a, x, use_lora, mine)
         h, x, mine = self.post_attention_layernorm.fork(x, self.gate_up.in_width, True)      # (x is this block's own by now)
         act = K.swiglu(self.gate_up(h, None, use_lora), self.down.in_width)
@@ -395,9 +425,13 @@ class LlamaModel(nn.Module):
             self._rope[(str(device), n)] = self._rope[key]
         return self._rope[key]
 
-    def run_layers(self, x, seq_start, seq_len, use_lora=True, branch=None):
+    def run_layers(self, x, seq_start, seq_len, use_lora=True, branch=None, rows=None):
         """x [S, T, d] bf16 -> last hidden state after the final RMSNorm (modelling_llama.py:580-705).
-        branch = (br_a, br_b, pos): rows are packed [prefix | A | B] sequences (see halva_sdpa_branch_fwd)."""
+        branch = (br_a, br_b, pos): rows are packed [prefix | A | B] sequences (see halva_sdpa_branch_fwd).
+        rows: int64 [n] DISTINCT flat indices into [S * T] of the only hidden rows the caller reads (the DPA loss reads the rows in
+        front of a label != -100, halva_trainer.py:522-537): the result is then [n, d] in that order, and the top layer does its
+        row-wise part (o projection, MLP, norms) for those rows only - the same arithmetic per row, no row of the reference's
+        [S, T, d] result that anything reads is dropped."""
         T = x.shape[1]
         cos, sin = self.rope(T, x.device)
         if cos.shape[0] < T:
@@ -412,9 +446,13 @@ class LlamaModel(nn.Module):
                 x.register_hook(lambda g, i=i, hook=hook: hook(i))
             if self.gradient_checkpointing and torch.is_grad_enabled() and x.requires_grad:
                 x = torch.utils.checkpoint.checkpoint(layer, x, info, use_lora, use_reentrant=False)
+            elif rows is not None and TOP_ROWS and i == len(self.layers) - 1:
+                x = layer(x, info, use_lora, i > 0, rows)
+                rows = None
             else:
                 x = layer(x, info, use_lora, i > 0)      # from layer 1 on `x` is the previous layer's own output
-        return self.norm(x)
+        x = self.norm(x)
+        return x if rows is None else x.view(-1, x.shape[-1]).index_select(0, rows)
 
 
 def add_lora(model, r, alpha, generator=None):

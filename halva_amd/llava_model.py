@@ -249,7 +249,7 @@ class LlavaLlamaForCausalLM(nn.Module, LlavaMetaForCausalLM):
         return sd
 
     # -- forward ---------------------------------------------------------------------------------
-    def hidden_states(self, inputs_embeds, attention_mask=None, seq_start=None, seq_len=None, branch=None):
+    def hidden_states(self, inputs_embeds, attention_mask=None, seq_start=None, seq_len=None, branch=None, rows=None):
         """Decoder stack + final norm on inputs_embeds [S, T, d].  The key-padding mask must be one contiguous run per
         row (what the splice produces); it is the raw [S, T] bool mask of the flash-attn seam
         (llama_flash_attn_monkey_patch.py:71,98-102)."""
@@ -263,7 +263,7 @@ class LlavaLlamaForCausalLM(nn.Module, LlavaMetaForCausalLM):
                 seq_start, seq_len = self._last_plan.seq_start, self._last_plan.seq_len     # no device sync
             else:
                 seq_start, seq_len = SP.spans_from_mask(_cpu(attention_mask))
-        return self.model.run_layers(inputs_embeds.to(torch.bfloat16), seq_start.to(dev), seq_len.to(dev), self._use_lora, branch)
+        return self.model.run_layers(inputs_embeds.to(torch.bfloat16), seq_start.to(dev), seq_len.to(dev), self._use_lora, branch, rows)
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                 labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None,
@@ -367,8 +367,8 @@ class _BaseOnlyLayer(nn.Module):
         super().__init__()
         self._l = [layer]            # not registered: the tensors belong to the policy model
 
-    def forward(self, x, info, use_lora=False, own_x=False):
-        return self._l[0](x, info, False, own_x)
+    def forward(self, x, info, use_lora=False, own_x=False, rows=None):
+        return self._l[0](x, info, False, own_x, rows)
 
 
 class _FrozenProjectorView(nn.Module):

@@ -341,7 +341,7 @@ class VilaLlavaLlamaModel(nn.Module):
                                max_len=getattr(lc, "tokenizer_model_max_length", None),
                                padding_side=getattr(lc, "tokenizer_padding_side", "right"), imageless_consumes=False)
 
-    def hidden_states(self, inputs_embeds, attention_mask=None, seq_start=None, seq_len=None, branch=None):
+    def hidden_states(self, inputs_embeds, attention_mask=None, seq_start=None, seq_len=None, branch=None, rows=None):
         S, T, _ = inputs_embeds.shape
         dev = inputs_embeds.device
         if seq_len is None:
@@ -352,7 +352,7 @@ class VilaLlavaLlamaModel(nn.Module):
                 seq_start, seq_len = self._last_plan.seq_start, self._last_plan.seq_len
             else:
                 seq_start, seq_len = SP.spans_from_mask(_cpu(attention_mask))
-        return self.llm.model.run_layers(inputs_embeds.to(torch.bfloat16), seq_start.to(dev), seq_len.to(dev), self._use_lora, branch)
+        return self.llm.model.run_layers(inputs_embeds.to(torch.bfloat16), seq_start.to(dev), seq_len.to(dev), self._use_lora, branch, rows)
 
     # -- the splice (llava_arch.py:264-871) -------------------------------------------------------
     def _splice(self, input_ids, attention_mask, labels, signs, images):
@@ -438,8 +438,8 @@ class _BaseOnlyLayer(nn.Module):
         super().__init__()
         self._l = [layer]
 
-    def forward(self, x, info, use_lora=False, own_x=False):
-        return self._l[0](x, info, False, own_x)
+    def forward(self, x, info, use_lora=False, own_x=False, rows=None):
+        return self._l[0](x, info, False, own_x, rows)
 
 
 class _FrozenProjectorView(nn.Module):

@@ -57,3 +57,48 @@ def test_inplace_residual_matches_the_out_of_place_path():
     for a, b in zip(g1, g0):
         # (the fork kernel adds the two gradients in one rounding where autograd rounds the norm's dx first: bf16 noise)
         assert float((a.float() - b.float()).abs().max()) <= 2e-2 * float(b.float().abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("grad", [True, False])
+def test_top_layer_on_the_kept_rows_only_matches_the_full_top_layer(grad):
+    """run_layers(rows=...): the top decoder layer does its row-wise part (o projection, post-attention norm, MLP, final norm) for the
+    rows the loss reads only.  Same rows as gathering from the full [S, T, d] result (the reference computes every row,
+    modelling_llama.py:580-705, and the loss reads logits[labels != -100], halva_trainer.py:522-537), same LoRA and input gradients
+    up to the bf16 noise of GEMMs that see another row count."""
+    from halva_amd import dpa
+    from halva_amd.llama import lora_named_parameters
+    z = load_npz("dpa_step_d128_init.npz")
+    pol, _, _ = build_product_models(z, device="cuda:0")
+    dpa.set_grad_sink(pol, False)
+    d = pol.config.hidden_size
+    S, T = 3, 96
+    g = torch.Generator().manual_seed(11)
+    x0 = (torch.randn(S, T, d, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    ss = torch.tensor([0, 5, 0], dtype=torch.int32, device="cuda")
+    sl = torch.tensor([96, 80, 33], dtype=torch.int32, device="cuda")
+    rows = torch.tensor([3, 17, 18, 95, 96 + 5, 96 + 60, 96 + 84, 2 * 96, 2 * 96 + 32], dtype=torch.int64, device="cuda")
+    w = torch.linspace(-1, 1, d, device="cuda")
+
+    def run(pruned):
+        for _, p in lora_named_parameters(pol):
+            p.grad = None
+        x = x0.clone().requires_grad_(grad)
+        with torch.set_grad_enabled(grad):
+            if pruned:
+                h = pol.model.run_layers(x, ss, sl, rows=rows)
+                assert h.shape == (rows.numel(), d)
+            else:
+                h = pol.model.run_layers(x, ss, sl).view(-1, d).index_select(0, rows)
+        gr = None
+        if grad:
+            (h.float() * w).sum().backward()
+            gr = [p.grad.clone() for _, p in lora_named_parameters(pol)] + [x.grad.clone()]
+        return h.detach().float(), gr
+
+    h1, g1 = run(True)
+    h0, g0 = run(False)
+    assert float((h1 - h0).abs().max()) <= 2e-2 * float(h0.abs().max())
+    if grad:
+        assert all(torch.isfinite(a).all() for a in g1)
+        for a, b in zip(g1, g0):
+            assert float((a.float() - b.float()).abs().max()) <= 2e-2 * float(b.float().abs().max()) + 1e-6

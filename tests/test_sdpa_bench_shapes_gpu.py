@@ -83,6 +83,37 @@ def test_packed_bench_row(ds_ws, monkeypatch):
     assert rel_err(o[0, 2048:], ref[0, 2048:]) < 1e-2
 
 
+def test_packed_vila_row_T4096_H40():
+    """configs[4] (VILA-13B: T = 4096 post-splice, 40 heads): the packed row [prefix 200 | A 3896 | B 3896] = 7992 rows, br_a = 200,
+    br_b = 4096 - the longest row the recipe can produce (32 key blocks of 256 per side, row-block walk of 32 virtual blocks per
+    head).  The dense fp32 reference runs head chunk by head chunk (a [40, 7992, 7992] score tensor would be 10 GB per copy)."""
+    S, T, H, D = 1, 7992, 40, 128
+    g = torch.Generator().manual_seed(33)
+    qkv = bf(torch.randn(S, T, 3, H, D, generator=g))
+    dout = bf(torch.randn(S, T, H, D, generator=g))
+    br = ([200], [4096])
+    qg = qkv.to(DEV).view(S, T, 3 * H * D).clone().requires_grad_(True)
+    mk = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    out = K().sdpa_causal(qg, mk([0]), mk([T]), H, D, mk(br[0]), mk(br[1]))
+    out.backward(dout.to(DEV).view(S, T, H * D))
+    torch.cuda.synchronize()
+    o = out.view(S, T, H, D).cpu().float()
+    dq = qg.grad.view(S, T, 3, H, D).cpu().float()
+    assert torch.isfinite(o).all() and torch.isfinite(dq).all()
+    step = 4
+    for h0 in range(0, H, step):
+        r = qkv[:, :, :, h0:h0 + step].float().requires_grad_(True)
+        ref = _branch_ref(r, [0], [T], br[0], br[1])
+        ref.backward(dout[:, :, h0:h0 + step].float())
+        for j in range(step):
+            h = h0 + j
+            assert rel_err(o[:, :, h], ref.detach()[:, :, j]) < 1.2e-2, ("fwd head", h)
+            assert float((o[:, :, h] - ref.detach()[:, :, j]).abs().max()) < 3e-2, ("fwd head", h)
+            for i, n in enumerate("dq dk dv".split()):
+                assert rel_err(dq[:, :, i, h], r.grad[:, :, i, j]) < 2.5e-2, (n, "head", h)
+        del r, ref
+
+
 def _bwd_bits(S, T, H, D, lens, starts, br, seed, env):
     import os
     old = {k: os.environ.get(k) for k in env}
