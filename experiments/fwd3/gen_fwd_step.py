@@ -19,9 +19,15 @@ Operands: %0-%3 / %4-%7 O^T accumulators of group 0 / 1 ("+a"), %8-%11 outputs: 
 %12-%19 / %20-%27 Q fragments ("a"), %28 row-read, %29 transposed-read lane offsets ("v"), %30 scale*log2(e), %31 iterations ("s");
 fwd_step_dma_asm.inc (tiles streamed through the ring by LDS-DMA) also: %32 / %33 lane offsets of a wave's K / V tile pieces ("v"), %34 wave,
 %35 bytes between a wave's pieces (16 rows) ("s"), %36-%39 first K / V tile rows of the wave's first piece (low / high words, "v")."""
+import os
 import sys
 
-LOOKAHEAD, CAP, CAP_MASKED = 6, 5, 8
+LOOKAHEAD, CAP, CAP_MASKED = 6, int(os.environ.get("FWD_CAP", "5")), 8
+# round-4 variants of the row-sum / running-maximum work (timing experiments; results of l / max then differ from MODE 0's)
+LSUM = os.environ.get("FWD_LSUM", "pk")          # pk: v_pk_add_f32 (shipped) | add: two v_add_f32 | none
+NO_M3 = os.environ.get("FWD_NO_M3", "0") == "1"   # drop the running maximum
+EXP_COST = int(os.environ.get("FWD_EXP_COST", "2"))
+VARIANT = any(k in os.environ for k in ("FWD_CAP", "FWD_LSUM", "FWD_NO_M3", "FWD_EXP_COST"))
 XS = {(0, 0): 64, (0, 1): 80, (1, 0): 96, (1, 1): 112}      # score tiles [group][key half]: 16 registers each
 PB = {(0, 0): 128, (0, 1): 136, (1, 0): 144, (1, 1): 152}   # packed P: 8 registers each
 L2, MX, MREF = {0: 160, 1: 164}, {0: 168, 1: 169}, {0: 170, 1: 171}      # l: two pairs per group (alternating), running max, reference
@@ -87,7 +93,9 @@ def valu_ops(g, kh):
     x, pb, l2, mx, mref = XS[(g, kh)], PB[(g, kh)], L2[g], MX[g], MREF[g]
     M3 = lambda i: Ins("v_max3_f32 v%d, v%d, v%d, v%d" % (mx, x + 2 * i, x + 2 * i + 1, mx), "valu", reads=["v%d" % (x + 2 * i), "v%d" % (x + 2 * i + 1), "v%d" % mx], writes=["v%d" % mx], cost=1)
     A = lambda r: Ins("v_fma_f32 v%d, v%d, %%30, -v%d" % (x + r, x + r, mref), "valu", reads=["v%d" % (x + r), "v%d" % mref], writes=["v%d" % (x + r)], cost=1)
-    B = lambda r: Ins("v_exp_f32_e32 v%d, v%d" % (x + r, x + r), "trans", reads=["v%d" % (x + r)], writes=["v%d" % (x + r)], cost=2)
+    B = lambda r: Ins("v_exp_f32_e32 v%d, v%d" % (x + r, x + r), "trans", reads=["v%d" % (x + r)], writes=["v%d" % (x + r)], cost=EXP_COST)
+    La = lambda i, j: Ins("v_add_f32_e32 v%d, v%d, v%d" % (l2 + 2 * (i & 1) + j, l2 + 2 * (i & 1) + j, x + 2 * i + j), "valu",
+                          reads=["v%d" % (l2 + 2 * (i & 1) + j), "v%d" % (x + 2 * i + j)], writes=["v%d" % (l2 + 2 * (i & 1) + j)], cost=1)
     Ls = lambda i: Ins("v_pk_add_f32 %s, %s, %s" % (vr(l2 + 2 * (i & 1), 2), vr(l2 + 2 * (i & 1), 2), vr(x + 2 * i, 2)), "valu",
                        reads=regs(l2 + 2 * (i & 1), 2) + regs(x + 2 * i, 2), writes=regs(l2 + 2 * (i & 1), 2), cost=1)
     Dp = lambda i: Ins("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (pb + i, x + 2 * i, x + 2 * i + 1), "valu", reads=regs(x + 2 * i, 2), writes=["v%d" % (pb + i)], cost=1)
@@ -98,15 +106,17 @@ def valu_ops(g, kh):
             # (ONE unit: the pair shares VCC, and the two groups' vector work is interleaved gap by gap)
             o += [Ins("v_cmp_lt_i32_e32 vcc, %d, v%d\\n\\tv_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (key, RANGE[g], x + r, V_NINF, x + r), "valu",
                       reads=["v%d" % RANGE[g], "v%d" % (x + r), "v%d" % V_NINF], writes=["v%d" % (x + r)], cost=2)]
-    o += [M3(i) for i in range(8)]
+    lsum = lambda i: {"pk": [Ls(i)], "add": [La(i, 0), La(i, 1)], "none": []}[LSUM]
+    if not NO_M3:
+        o += [M3(i) for i in range(8)]
     o += [A(0), A(1), A(2), A(3)]
     for r in range(12):
         o += [B(r), A(r + 4)]
         if r % 2 == 1 and r >= 3:
             i = (r - 3) // 2
-            o += [Ls(i), Dp(i)]
+            o += lsum(i) + [Dp(i)]
     o += [B(12), B(13), B(14), B(15)]
-    o += [Ls(5), Dp(5), Ls(6), Dp(6), Ls(7), Dp(7)]
+    o += lsum(5) + [Dp(5)] + lsum(6) + [Dp(6)] + lsum(7) + [Dp(7)]
     return o
 
 
@@ -234,7 +244,12 @@ def check(seq):
 def main():
     global DMA, MASKED
     for DMA, MASKED in ((False, False), (True, False), (False, True)):
-        emit()
+        try:
+            emit()
+        except AssertionError as e:      # (a timing variant of the plain step need not fit the other two streams)
+            if not (DMA or MASKED) or not VARIANT:
+                raise
+            print("skipped (DMA %s, MASKED %s): %s" % (DMA, MASKED, e))
 
 
 def emit():

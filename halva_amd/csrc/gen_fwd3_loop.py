@@ -40,7 +40,11 @@ import os
 import re
 import sys
 
-LOOKAHEAD, CAP, CAP_MASKED = 6, 5, 8
+# Issue units per MFMA gap (one unit ~ 4 cycles; a v_exp_f32 is two).  MI355X_MICROARCH.md prices a gap at 32 cycles = the MFMA's own 8 + 24 of
+# other issue, i.e. 6 units - and packed f32 VALU beside MFMAs far above its slot: the row sums as v_pk_add_f32 at CAP 5 ran 2 804 cycles per
+# step in experiments/fwd3, as two v_add_f32 at CAP 6 2 339 (round 4; build_variants.sh there).  FWD3_CAP / FWD3_CAP_MASKED / FWD3_LSUM: experiments.
+LOOKAHEAD, CAP, CAP_MASKED = 6, int(os.environ.get("FWD3_CAP", "6")), int(os.environ.get("FWD3_CAP_MASKED", "8"))
+LSUM = os.environ.get("FWD3_LSUM", "add")
 XS = {(0, 0): 64, (0, 1): 80, (1, 0): 96, (1, 1): 112}      # score tiles [group][key half]: 16 registers each
 PB = {(0, 0): 128, (0, 1): 136, (1, 0): 144, (1, 1): 152}   # packed P: 8 registers each
 L2, MX, MREF, RANGE = {0: 160, 1: 164}, {0: 168, 1: 169}, {0: 170, 1: 171}, {0: 172, 1: 173}
@@ -142,8 +146,11 @@ def valu_ops(g, kh):
     M3 = lambda i: Ins("v_max3_f32 v%d, v%d, v%d, v%d" % (mx, x + 2 * i, x + 2 * i + 1, mx), "valu", reads=["v%d" % (x + 2 * i), "v%d" % (x + 2 * i + 1), "v%d" % mx], writes=["v%d" % mx], cost=1)
     A = lambda r: Ins("v_fma_f32 v%d, v%d, %%[sc], -v%d" % (x + r, x + r, mref), "valu", reads=["v%d" % (x + r), "v%d" % mref], writes=["v%d" % (x + r)], cost=1)
     B = lambda r: Ins("v_exp_f32_e32 v%d, v%d" % (x + r, x + r), "trans", reads=["v%d" % (x + r)], writes=["v%d" % (x + r)], cost=2)
-    Ls = lambda i: Ins("v_pk_add_f32 %s, %s, %s" % (vr(l2 + 2 * (i & 1), 2), vr(l2 + 2 * (i & 1), 2), vr(x + 2 * i, 2)), "valu",
+    Lp = lambda i: Ins("v_pk_add_f32 %s, %s, %s" % (vr(l2 + 2 * (i & 1), 2), vr(l2 + 2 * (i & 1), 2), vr(x + 2 * i, 2)), "valu",
                        reads=regs(l2 + 2 * (i & 1), 2) + regs(x + 2 * i, 2), writes=regs(l2 + 2 * (i & 1), 2), cost=1)
+    La = lambda i, j: Ins("v_add_f32_e32 v%d, v%d, v%d" % (l2 + 2 * (i & 1) + j, l2 + 2 * (i & 1) + j, x + 2 * i + j), "valu",
+                          reads=["v%d" % (l2 + 2 * (i & 1) + j), "v%d" % (x + 2 * i + j)], writes=["v%d" % (l2 + 2 * (i & 1) + j)], cost=1)
+    Ls = lambda i: [Lp(i)] if LSUM == "pk" else [La(i, 0), La(i, 1)]
     Dp = lambda i: Ins("v_cvt_pk_bf16_f32 v%d, v%d, v%d" % (pb + i, x + 2 * i, x + 2 * i + 1), "valu", reads=regs(x + 2 * i, 2), writes=["v%d" % (pb + i)], cost=1)
     o = []
     if MASKED:
@@ -154,9 +161,9 @@ def valu_ops(g, kh):
         o += [B(r), A(r + 4)]
         if r % 2 == 1 and r >= 3:
             i = (r - 3) // 2
-            o += [Ls(i), Dp(i)]
+            o += Ls(i) + [Dp(i)]
     o += [B(12), B(13), B(14), B(15)]
-    o += [Ls(5), Dp(5), Ls(6), Dp(6), Ls(7), Dp(7)]
+    o += Ls(5) + [Dp(5)] + Ls(6) + [Dp(6)] + Ls(7) + [Dp(7)]
     return o
 
 
