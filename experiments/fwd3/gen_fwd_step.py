@@ -27,7 +27,12 @@ LOOKAHEAD, CAP, CAP_MASKED = 6, int(os.environ.get("FWD_CAP", "5")), 8
 LSUM = os.environ.get("FWD_LSUM", "pk")          # pk: v_pk_add_f32 (shipped) | add: two v_add_f32 | none
 NO_M3 = os.environ.get("FWD_NO_M3", "0") == "1"   # drop the running maximum
 EXP_COST = int(os.environ.get("FWD_EXP_COST", "2"))
-VARIANT = any(k in os.environ for k in ("FWD_CAP", "FWD_LSUM", "FWD_NO_M3", "FWD_EXP_COST"))
+DMA_M0 = os.environ.get("FWD_DMA_M0", "each")
+DMA_REQ = os.environ.get("FWD_DMA_REQ", "1") == "1"
+DMA_BAR = os.environ.get("FWD_DMA_BAR", "1") == "1"
+DMA_COST = int(os.environ.get("FWD_DMA_COST", "0"))
+DMA_GAPS = [int(x) for x in os.environ.get("FWD_DMA_GAPS", "0,1,2,3,4,5,6,7").split(",")]
+VARIANT = any(k.startswith("FWD_") for k in os.environ) or any(k in os.environ for k in ("FWD_CAP", "FWD_LSUM", "FWD_NO_M3", "FWD_EXP_COST"))
 XS = {(0, 0): 64, (0, 1): 80, (1, 0): 96, (1, 1): 112}      # score tiles [group][key half]: 16 registers each
 PB = {(0, 0): 128, (0, 1): 136, (1, 0): 144, (1, 1): 152}   # packed P: 8 registers each
 L2, MX, MREF = {0: 160, 1: 164}, {0: 168, 1: 169}, {0: 170, 1: 171}      # l: two pairs per group (alternating), running max, reference
@@ -147,8 +152,9 @@ def dma_groups():
     groups = []
     for ptr, base, voff in ((KP, K_LDS, "%32"), (VP, V_LDS, "%33")):
         for i in range(4):
-            groups.append((pre if not groups else []) + ["s_add_u32 m0, %s, %d" % (S_DST, base + 4096 * i), "s_nop 0", "global_load_lds_dwordx4 %s, s[%d:%d]" % (voff, ptr[0], ptr[1]),
-                                                         "s_add_u32 s%d, s%d, %%35" % (ptr[0], ptr[0]), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])])
+            m0 = ["s_add_u32 m0, %s, %d" % (S_DST, base + 4096 * i), "s_nop 0"] if (i == 0 or DMA_M0 != "once") else []      # (once: a timing probe, the pieces overwrite each other)
+            ld = ["global_load_lds_dwordx4 %s, s[%d:%d]" % (voff, ptr[0], ptr[1])] if DMA_REQ else []
+            groups.append((pre if not groups else []) + m0 + ld + ["s_add_u32 s%d, s%d, %%35" % (ptr[0], ptr[0]), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])])
     return groups
 
 
@@ -158,9 +164,10 @@ def build_body():
     used = [0] * 64
     if DMA:
         for k, grp in enumerate(dma_groups()):
-            gaps[k] += [Ins(t, "raw") for t in grp]
+            gaps[DMA_GAPS[k]] += [Ins(t, "raw") for t in grp]
+            used[DMA_GAPS[k]] += DMA_COST
         # tile t+1 (its K half is read from gap 10 of the next iteration on) has landed for every wave: only tile t+2's 8 requests may stay in flight
-        gaps[57] += [Ins(t, "raw") for t in ("s_waitcnt vmcnt(8)", "s_barrier", "s_add_u32 %s, %s, 1" % (S_SLOT, S_SLOT), "s_and_b32 %s, %s, 3" % (S_SLOT, S_SLOT))]
+        gaps[57] += [Ins(t, "raw") for t in ((("s_waitcnt vmcnt(8)",) if DMA_REQ else ()) + (("s_barrier",) if DMA_BAR else ()) + ("s_add_u32 %s, %s, 1" % (S_SLOT, S_SLOT), "s_and_b32 %s, %s, 3" % (S_SLOT, S_SLOT)))]
     # A operands: pair m = MFMAs 2m, 2m+1; its read(s) go out in gap 2m - LOOKAHEAD (of the previous iteration for the first pairs)
     for m in range(32):
         g = (2 * m - LOOKAHEAD) % 64

@@ -45,6 +45,14 @@ import sys
 # step in experiments/fwd3, as two v_add_f32 at CAP 6 2 339 (round 4; build_variants.sh there).  FWD3_CAP / FWD3_CAP_MASKED / FWD3_LSUM: experiments.
 LOOKAHEAD, CAP, CAP_MASKED = 6, int(os.environ.get("FWD3_CAP", "6")), int(os.environ.get("FWD3_CAP_MASKED", "8"))
 LSUM = os.environ.get("FWD3_LSUM", "add")
+# The running row maximum (one v_max3_f32 per two scores) is NOT tracked: every instruction of the single wave costs an issue slot of ~4 cycles
+# whatever its unit, and the check it fed - "has a score outgrown the row's exponent reference" - is made on the row SUMS at the end of the pass
+# instead: a partial sum that is not < 2^100 (P overflowed, or is about to) repeats the row block with that row's reference raised by 120
+# (log2 units), as often as it takes.  Any reference within ~100 of the row's true maximum gives the same result: P, l and O^T are floating
+# point numbers, only their common exponent moves.  FWD3_TRACK_MAX=1 puts the v_max3 back (timing experiments; the value is unused).
+TRACK_MAX = os.environ.get("FWD3_TRACK_MAX", "0") == "1"
+WAIT_AGE = int(os.environ.get("FWD3_WAIT_AGE", "4"))      # 0: one wait per first use
+REDO_LIMIT, REDO_STEP = 0x71800000, 0x42f00000      # 2^100, 120.0
 XS = {(0, 0): 64, (0, 1): 80, (1, 0): 96, (1, 1): 112}      # score tiles [group][key half]: 16 registers each
 PB = {(0, 0): 128, (0, 1): 136, (1, 0): 144, (1, 1): 152}   # packed P: 8 registers each
 L2, MX, MREF, RANGE = {0: 160, 1: 164}, {0: 168, 1: 169}, {0: 170, 1: 171}, {0: 172, 1: 173}
@@ -155,7 +163,8 @@ def valu_ops(g, kh):
     o = []
     if MASKED:
         o += mask_ops(g, kh, RANGE[g])
-    o += [M3(i) for i in range(8)]
+    if TRACK_MAX:
+        o += [M3(i) for i in range(8)]
     o += [A(0), A(1), A(2), A(3)]
     for r in range(12):
         o += [B(r), A(r + 4)]
@@ -258,14 +267,22 @@ def linearize(M, gaps):
 
 
 def insert_waits(seq, carried):
-    fifo, pending, lines, prev = list(carried), {}, [], None
+    """s_waitcnt lgkmcnt(N) in front of the first user of an LDS read, N from the in-order queue.  A wait that is due anyway also covers every
+    younger read issued at least WAIT_AGE MFMAs ago (long landed: the wait costs the same issue slot and saves the next one - one wait per two
+    MFMA pairs instead of one per pair)."""
+    # (ages in MFMAs, relative to this stretch's first: what an iteration leaves in flight was issued 64 MFMAs before the same point of the next)
+    fifo, pending, lines, prev, now = [dict(e, age=e["age"] - 64 if e.get("age", -99) > 0 else e.get("age", -99)) for e in carried], {}, [], None, 0
     for e in fifo:
         for r in e["defs"]:
             pending[r] = e
     for ins in seq:
+        if ins.kind == "mfma":
+            now += 1
         need = [pending[r] for r in (ins.reads | ins.writes) if r in pending]
         if need:
             last = max(fifo.index(e) for e in need)
+            while WAIT_AGE and last + 1 < len(fifo) and now - fifo[last + 1]["age"] >= WAIT_AGE:
+                last += 1
             cnt = len(fifo) - 1 - last
             assert cnt <= 15
             lines.append("s_waitcnt lgkmcnt(%d)" % cnt)
@@ -278,7 +295,7 @@ def insert_waits(seq, carried):
             lines.append("s_nop 0")
         lines.append(ins.text)
         if ins.kind == "lds":
-            e = {"defs": set(ins.lds_defs)}
+            e = {"defs": set(ins.lds_defs), "age": now}
             fifo.append(e)
             for r in e["defs"]:
                 pending[r] = e
@@ -309,7 +326,7 @@ def carried_reads(M):
     for m in range(32):
         if 2 * m - LOOKAHEAD < 0:
             for l in a_loads(M[2 * m]["a"], m % 8):
-                c.append({"defs": set(l.lds_defs)})
+                c.append({"defs": set(l.lds_defs), "age": 2 * m - LOOKAHEAD})      # (issued in gap 64 + 2 m - LOOKAHEAD of the iteration before)
     return c
 
 
@@ -512,7 +529,7 @@ def emit(out):
         L += ["v_mfma_f32_32x32x16_bf16 a[%d:%d], v[%d:%d], v[%d:%d], 0" % (16 * o, 16 * o + 15, RING, RING + 3, RING, RING + 3)]
     for g in (0, 1):
         L += ["v_mov_b32_e32 v%d, 0" % (PB[(g, 1)] + i) for i in range(8)]
-        L += ["v_mov_b32_e32 v%d, 0" % (L2[g] + i) for i in range(4)] + ["v_mov_b32_e32 v%d, 0xff800000" % MX[g]]
+        L += ["v_mov_b32_e32 v%d, 0" % (L2[g] + i) for i in range(4)] + (["v_mov_b32_e32 v%d, 0xff800000" % MX[g]] if TRACK_MAX else [])
     L += ["v_mov_b32_e32 v%d, 0xff800000" % V_NINF]
     L += ["s_and_b32 %s, %s, 3" % (S_TMP, S_T), "s_lshl_b32 %s, %s, 14" % (S_TOFFK, S_TMP), "s_mov_b32 %s, %s" % (S_TOFFV, S_TOFFK)]      # V "tile -1" := tile 0's slot (finite data; its P is zero)
     L += [i.text for i in k_addr_from_toff()] + [i.text for i in v_addr_from_toff()]
@@ -562,28 +579,30 @@ def emit(out):
     lines, fifo = chain_block(M, range(0, 16), LOOKAHEAD // 2, carried_reads(M))
     L += lines
     L += ["s_branch .Lf3_end_%="] + ool_pro + ool_p + ool_m + [".Lf3_end_%=:", "s_waitcnt lgkmcnt(0)"]
-    # ---------------- did any query's maximum outgrow its reference by more than 2^64?  Workgroup-wide (the waves share the tile ring): every wave leaves
-    # its answer in the item's vote words (LDS, double buffered by ctl bit 10), barrier, everybody reads all four.  The barrier is also the one
-    # behind which the ring may be requested into again.  (A repeat pass does not vote: its reference IS the maximum.)
+    # ---------------- has any row's exponent reference been outgrown?  (TRACK_MAX above: judged by the row sums.)  Workgroup-wide - the waves share the
+    # tile ring -: every wave leaves its answer in the item's vote words (LDS, double buffered by ctl bit 10), barrier, everybody reads all four.
+    # The barrier is also the one behind which the ring may be requested into again.  The two lanes of a row (keys 4h.. of every 8) must move
+    # their reference together: the larger of their partial sums decides for both.
     T = (V_T0, V_T1)
     R0, R1, R2 = RING, RING + 1, RING + 2
-    L += ["s_cmp_eq_u32 %s, 1" % S_REDO, "s_cbranch_scc1 .Lf3_exit_%="]
+    FLAG = (SRC, (82, 83))      # which lanes repeat, per group (s[82:83] = S_SEG / S_FLD: loop-only)
     for g in (0, 1):
-        L += ["v_mov_b32_e32 v%d, v%d" % (T[g], MX[g]), "v_mov_b32_e32 v%d, v%d" % (R0, MX[g]), "s_nop 1", "v_permlane32_swap_b32_e32 v%d, v%d" % (T[g], R0), "s_nop 1",
-              "v_max_f32_e32 v%d, v%d, v%d" % (T[g], T[g], R0), "v_mul_f32_e32 v%d, %%[sc], v%d" % (T[g], T[g]),
-              "v_add_f32_e32 v%d, 0x42800000, v%d" % (R0, MREF[g]), "v_cmp_gt_f32_e32 vcc, v%d, v%d" % (T[g], R0),
-              ("s_mov_b64 %s, vcc" % sp(SRC)) if g == 0 else ("s_or_b64 %s, %s, vcc" % (sp(SRC), sp(SRC)))]
-    L += ["s_cmp_lg_u64 %s, 0" % sp(SRC), "s_cselect_b32 %s, 1, 0" % S_TMP, "v_mov_b32_e32 v%d, %s" % (R1, S_TMP),
+        L += ["v_max3_f32 v%d, v%d, v%d, v%d" % (T[g], L2[g], L2[g] + 1, L2[g] + 2), "v_max_f32_e32 v%d, v%d, v%d" % (T[g], T[g], L2[g] + 3),
+              "v_mov_b32_e32 v%d, v%d" % (R0, T[g]), "s_nop 1", "v_permlane32_swap_b32_e32 v%d, v%d" % (T[g], R0), "s_nop 1",
+              "v_max_f32_e32 v%d, v%d, v%d" % (T[g], T[g], R0), "v_mov_b32_e32 v%d, 0x%08x" % (R0, REDO_LIMIT), "v_cmp_nlt_f32_e32 vcc, v%d, v%d" % (T[g], R0),
+              "s_mov_b64 %s, vcc" % sp(FLAG[g])]
+    L += ["s_or_b64 vcc, %s, %s" % (sp(FLAG[0]), sp(FLAG[1])),
+          "s_cmp_lg_u64 vcc, 0", "s_cselect_b32 %s, 1, 0" % S_TMP, "v_mov_b32_e32 v%d, %s" % (R1, S_TMP),
           "s_bfe_u32 %s, %%[ctl], 0x1000a" % S_TMP, "s_lshl_b32 %s, %s, 4" % (S_TMP, S_TMP), "s_add_u32 %s, %s, %d" % (S_TMP, S_TMP, MAIL_LDS),
           "s_lshl_b32 %s, %%[wave], 2" % S_TMP2, "s_add_u32 %s, %s, %s" % (S_TMP2, S_TMP2, S_TMP), "v_mov_b32_e32 v%d, %s" % (R2, S_TMP2),
           "ds_write_b32 v%d, v%d" % (R2, R1), "s_waitcnt lgkmcnt(0)", "s_barrier",
           "v_mov_b32_e32 v%d, %s" % (R2, S_TMP), "ds_read_b128 v[%d:%d], v%d" % (RING + 4, RING + 7, R2), "s_waitcnt lgkmcnt(0)",
           "v_or3_b32 v%d, v%d, v%d, v%d" % (R1, RING + 4, RING + 5, RING + 6), "v_or_b32_e32 v%d, v%d, v%d" % (R1, R1, RING + 7), "s_nop 1",
           "v_readfirstlane_b32 %s, v%d" % (S_TMP, R1), "s_nop 3", "s_cmp_eq_u32 %s, 0" % S_TMP, "s_cbranch_scc1 .Lf3_exit_%="]
-    # rare: the whole row block again, cold, against the true row maxima; what the first pass requested for the next item must have landed
-    # before this pass requests into the same slots
+    # rare: the whole row block again, cold, the references of the rows that overflowed raised; what this pass requested for the next item must
+    # have landed before the next pass requests into the same slots
     for g in (0, 1):
-        L += ["v_cmp_lt_f32_e32 vcc, v%d, v%d" % (V_NINF, T[g]), "v_cndmask_b32_e32 v%d, 0, v%d, vcc" % (MREF[g], T[g])]
+        L += ["s_mov_b64 vcc, %s" % sp(FLAG[g]), "v_add_f32_e32 v%d, 0x%08x, v%d" % (T[g], REDO_STEP, MREF[g]), "v_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (MREF[g], MREF[g], T[g])]
     L += ["s_mov_b32 %s, 1" % S_REDO, "s_mov_b32 %s, 0" % S_PF, "s_waitcnt vmcnt(0)", "s_branch .Lf3_pass_%="]
     # ---------------- way out.  Every wave has passed the vote's barrier: the ring slot of the item's last tile is free (the other three hold the next
     # item's first tiles).  Per row group g: [the NEXT item's Q rows of the group requested by LDS-DMA into this wave's 8 KiB of that slot - whole

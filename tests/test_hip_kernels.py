@@ -221,10 +221,12 @@ def test_sdpa_causal_fwd_bwd(T, lens, starts, H, D, slow_tr):
 @pytest.mark.gpu
 @pytest.mark.parametrize("D", [128, 64])
 def test_sdpa_exponent_reference_moves_when_later_keys_dominate(D):
-    """The forward keeps ONE exponent reference per row (its first tile's maximum) and only moves it when a later score exceeds it
-    by 64 in log2 units - a path ordinary activations never take.  Keys whose scores grow by ~90 then ~135 nats from one 64-key
-    tile to the next force it twice per row; the result must still match the fp32 softmax (and the backward, which recomputes P
-    from the saved log-sum-exp, must agree as well)."""
+    """The forward keeps ONE exponent reference per row (the maximum over its first 32 visible keys) and only moves it when the row's
+    sums show that P = exp2(score - reference) overflowed or is about to (a partial row sum not below 2^100) - a path ordinary
+    activations never take: the row block is then repeated with the reference of those rows raised by 120 log2 units, as often
+    as it takes.  Keys whose scores grow by ~56 then ~136 nats from one 64-key tile to the next force one repeat for the rows of the
+    third tile and two for the rows of the fourth; the result must still match the fp32 softmax (and the backward, which recomputes
+    P from the saved log-sum-exp, must agree as well)."""
     T, H, S = 256, 2, 1
     g = torch.Generator().manual_seed(11)
     u = torch.randn(H, D, generator=g)
@@ -252,7 +254,8 @@ def test_sdpa_exponent_reference_moves_when_later_keys_dominate(D):
     o = out.view(S, T, H, D).cpu().float()
     assert torch.isfinite(o).all()
     scores = (r[0, :, 0].detach().permute(1, 0, 2) @ r[0, :, 1].detach().permute(1, 2, 0)) / math.sqrt(D)
-    assert float(scores[:, 200, 128:192].max() - scores[:, 200, :64].max()) > 64 * math.log(2)      # the jump really exceeds the threshold
+    assert float(scores[:, 200, 128:201].max() - scores[:, 200, :32].max()) > 220 * math.log(2)     # row 200 needs two repeats (2 x 120 log2 units)
+    assert float(scores[:, 150, 128:151].max() - scores[:, 150, :32].max()) > 100 * math.log(2)     # row 150 one
     assert rel_err(o, ref) < 1e-2, "fwd"
     assert float((o - ref.detach()).abs().max()) < 3e-2
     dq = qg.grad.view(S, T, 3, H, D).cpu().float()
