@@ -14,9 +14,14 @@ Operands of the asm block: %0-%3 dV^T accumulators, %4-%7 dK^T accumulators ("+a
 %28 scale*log2(e) ("s"), %29 number of steps ("s")."""
 import sys
 
-LOOKAHEAD, CAP = 6, 5
+import os
+# round 4 timing variants: DKV_LA = how many MFMAs ahead an operand is read, DKV_NRING = slots of the operand ring (8: v176-v207; 16: up to v239,
+# the address registers then sit behind it), DKV_CAP
+LOOKAHEAD, CAP = int(os.environ.get("DKV_LA", "6")), int(os.environ.get("DKV_CAP", "5"))
+NRING = int(os.environ.get("DKV_NRING", "8"))
 X = [64, 96]; Y = [80, 112]; PB = [128, 144]; ZB = [136, 152]; SL = 160; RING = 176
-QRE, QRO, DRE, DRO, QC0, QC1, DC0, DC1, STAT, DSOFF, TMP = 208, 209, 210, 211, 212, 213, 214, 215, 216, 217, 218
+QRE, QRO, DRE, DRO, QC0, QC1, DC0, DC1, STAT, DSOFF, TMP = [RING + 4 * NRING + i for i in range(11)]
+assert LOOKAHEAD < NRING
 S_T, S_CNT, S_TMP, S_TOFF = "s90", "s91", "s92", "s93"
 Q_LDS, DO_LDS, LSE_LDS, ND_DELTA, NTILE = 0, 65536, 131072, 1024, 4
 
@@ -68,7 +73,7 @@ def a_loads(desc, slot):
 
 
 def mfma_ins(n, m):
-    slot = RING + 4 * (n % 8)
+    slot = RING + 4 * (n % NRING)
     a = vr(slot, 4)
     if m["prod"] == "S":
         d = vr(X[m["sub"]], 16)
@@ -116,7 +121,7 @@ def build_body():
     for n in range(64):
         g = n - LOOKAHEAD
         if g >= 0:
-            gaps[g] += a_loads(M[n]["a"], n % 8)
+            gaps[g] += a_loads(M[n]["a"], n % NRING)
     addr_update_gap = 64 - LOOKAHEAD - 1            # after the reads for MFMA 63
     # --- LDS: statistics.  -delta goes straight into the dP accumulator, lse into SL
     def stat(sub, j, which):
@@ -160,7 +165,7 @@ def build_body():
     upd += addr_setup(loop=True)
     gaps[addr_update_gap] += upd
     for n in range(LOOKAHEAD):
-        gaps[64 - LOOKAHEAD + n] += a_loads(M[n]["a"], n % 8)
+        gaps[64 - LOOKAHEAD + n] += a_loads(M[n]["a"], n % NRING)
     return M, gaps
 
 
@@ -253,7 +258,7 @@ def main():
     check(seq + seq)
     carried = []
     for n in range(LOOKAHEAD):
-        for l in a_loads(M[n]["a"], n % 8):
+        for l in a_loads(M[n]["a"], n % NRING):
             carried.append({"defs": set(l.lds_defs)})
     lines1, fifo1 = insert_waits(seq, carried)
     lines2, fifo2 = insert_waits(seq, fifo1)
@@ -262,7 +267,7 @@ def main():
            "s_mov_b32 %s, 0" % S_T, "s_mov_b32 %s, 0" % S_TMP, "s_mov_b32 %s, 0" % S_TOFF, "s_mov_b32 %s, %%29" % S_CNT]
     pro += [i.text for i in addr_setup(loop=False)]
     for n in range(LOOKAHEAD):
-        pro += [l.text for l in a_loads(M[n]["a"], n % 8)]
+        pro += [l.text for l in a_loads(M[n]["a"], n % NRING)]
     body = ["1:"] + lines1 + ["s_sub_u32 %s, %s, 1" % (S_CNT, S_CNT), "s_cmp_lg_u32 %s, 0" % S_CNT, "s_cbranch_scc1 1b", "s_waitcnt lgkmcnt(0)"]
     out = sys.argv[1] if len(sys.argv) > 1 else "step_asm.inc"
     with open(out, "w") as f:
@@ -272,7 +277,7 @@ def main():
     nv = sum(1 for s in seq if s.kind in ("valu", "trans"))
     nl = sum(1 for s in seq if s.kind == "lds")
     print("step: 64 MFMAs, %d vector, %d LDS reads, %d lines; busiest gap %d issue units" % (nv, nl, len(lines1), max(sum(i.cost for i in g) for g in gaps)))
-    clob = ", ".join('"v%d"' % i for i in range(64, 220)) + ', "s90", "s91", "s92", "s93", "scc", "memory"'
+    clob = ", ".join('"v%d"' % i for i in range(64, RING + 4 * NRING + 12)) + ', "s90", "s91", "s92", "s93", "scc", "memory"'
     with open(out.replace(".inc", "_clobbers.inc"), "w") as f:
         f.write(clob + "\n")
 

@@ -31,9 +31,12 @@ from that row), lse / nd the statistics rows of the first tile to request, ds th
 the workgroup's NEXT item (nq / ndo + nqrec / ndorec / nqsoff / ndosoff, nlse / nnd: in vector registers too) are requested by the block's
 last three steps (ndma bits 8-15: how many of its tiles).
 The masked phases cost three more vector instructions per score."""
+import os
 import sys
 
 LOOKAHEAD, CAP, CAP_MASKED = 6, 5, 9
+WAIT_AGE = int(os.environ.get("DKV3_WAIT_AGE", "4"))      # 0: one wait per first use (rounds 2-3)
+CARRY_K = 4
 X = [64, 96]; Y = [80, 112]; PB = [128, 144]; ZB = [136, 152]; SL = 160; RING = 176
 QRE, QRO, DRE, DRO, QC0, QC1, DC0, DC1, STAT, DSOFF, LANE4, LANE, V_LO, V_T, V_NINF = 208, 209, 210, 211, 212, 213, 214, 215, 216, 217, 218, 219, 220, 221, 222
 S_SLOT, S_CNT, S_DMALEFT, S_TOFF, S_TMP, S_TMP2 = "s72", "s73", "s74", "s75", "s80", "s81"
@@ -288,18 +291,26 @@ def linearize(M, gaps):
     return seq
 
 
-def insert_waits(seq, carried):
-    fifo = list(carried)
+def insert_waits(seq, carried, final_keep=None):
+    """s_waitcnt lgkmcnt(N) in front of the first user of an LDS read, N from the in-order queue.  A wait that is due anyway also covers every
+    younger read issued at least WAIT_AGE MFMAs ago (long landed): every instruction of the single wave, a wait included, is an issue slot of
+    ~4 cycles, and the stream had one wait per MFMA (round 4; ages in MFMAs relative to the iteration's first)."""
+    fifo = [dict(e, age=e["age"] - 64 if e.get("age", -99) > 0 else e.get("age", -99)) for e in carried]
     pending = {}
     for e in fifo:
         for r in e["defs"]:
             pending[r] = e
     lines = []
     prev = None
+    now = 0
     for ins in seq:
+        if ins.kind == "mfma":
+            now += 1
         need = [pending[r] for r in (ins.reads | ins.writes) if r in pending]
         if need:
             last = max(fifo.index(e) for e in need)
+            while WAIT_AGE and last + 1 < len(fifo) and now - fifo[last + 1]["age"] >= WAIT_AGE:
+                last += 1
             cnt = len(fifo) - 1 - last
             assert cnt <= 15, "lgkmcnt field overflow"
             lines.append("s_waitcnt lgkmcnt(%d)" % cnt)
@@ -312,13 +323,16 @@ def insert_waits(seq, carried):
             lines.append("s_nop 0")
         lines.append(ins.text)
         if ins.kind == "lds":
-            e = {"defs": set(ins.lds_defs)}
+            e = {"defs": set(ins.lds_defs), "age": now}
             fifo.append(e)
             for r in e["defs"]:
                 pending[r] = e
         assert len(fifo) <= 15, "more than 15 LDS reads in flight"
         if ins.kind not in ("salu", "raw"):
             prev = ins
+    if final_keep is not None and len(fifo) > final_keep:      # a canonical queue at the iteration's end: only the youngest reads stay in flight
+        lines.append("s_waitcnt lgkmcnt(%d)" % final_keep)
+        fifo = fifo[-final_keep:]
     return lines, fifo
 
 
@@ -344,12 +358,16 @@ def variant(masked, phase):
     M, gaps, ool = build_body()
     seq = linearize(M, gaps)
     check(seq + seq)
+    # every phase's iteration starts and ends with the SAME reads in flight - the youngest CARRY_K of the next iteration's first operands - so that
+    # the phases can follow each other in any order; whoever enters a loop (the prologue, main()) has waited down to that state
     carried = []
     for n in range(LOOKAHEAD):
         for l in a_loads(M[n]["a"], n % 8):
-            carried.append({"defs": set(l.lds_defs)})
-    lines1, fifo1 = insert_waits(seq, carried)
-    lines2, fifo2 = insert_waits(seq, fifo1)
+            carried.append({"defs": set(l.lds_defs), "age": n - LOOKAHEAD + 1})
+    carried = carried[-CARRY_K:]
+    lines1, fifo1 = insert_waits(seq, carried, CARRY_K)
+    lines2, fifo2 = insert_waits(seq, fifo1, CARRY_K)
+    assert [sorted(e["defs"]) for e in fifo1] == [sorted(e["defs"]) for e in carried], "the iteration's last reads are not the next one's first operands"
     assert lines1 == lines2 and [sorted(e["defs"]) for e in fifo1] == [sorted(e["defs"]) for e in fifo2], "loop is not in steady state"
     nv = sum(1 for s in seq if s.kind in ("valu", "trans"))
     nl = sum(1 for s in seq if s.kind == "lds")
@@ -411,6 +429,7 @@ def main():
     pro += [i.text for i in addr_setup()]
     for n in range(LOOKAHEAD):
         pro += [l.text for l in a_loads(M[n]["a"], n % 8)]
+    pro += ["s_waitcnt lgkmcnt(%d)" % CARRY_K]      # (the state every iteration starts in: variant())
     lines = list(pro)
     for phase, body, count in (("a", body_a, "s_and_b32 %s, %%[n02], 0xffff" % S_CNT), ("b", body_b, "s_mov_b32 %s, %%[n1]" % S_CNT), ("c", body_c, "s_lshr_b32 %s, %%[n02], 16" % S_CNT)):
         lines += [count, "s_cmp_eq_u32 %s, 0" % S_CNT, "s_cbranch_scc1 .Ldkv3_skip%s_%%=" % phase, ".Ldkv3_loop%s_%%=:" % phase]

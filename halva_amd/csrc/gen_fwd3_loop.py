@@ -339,6 +339,8 @@ def variant(masked, phase):
     lines1, fifo1 = insert_waits(seq, carried_reads(M))
     lines2, fifo2 = insert_waits(seq, fifo1)
     assert lines1 == lines2 and [sorted(e["defs"]) for e in fifo1] == [sorted(e["defs"]) for e in fifo2], "loop is not in steady state"
+    # (the plain and the masked body follow each other: both must end with exactly the next iteration's first operands in flight)
+    assert [sorted(e["defs"]) for e in fifo1] == [sorted(e["defs"]) for e in carried_reads(M)], "the iteration's last reads are not the next one's first operands"
     assert [sorted(e["defs"]) for e in fifo1] == [sorted(e["defs"]) for e in carried_reads(M)], "the bodies must leave the same LDS queue"
     nv = sum(1 for s in seq if s.kind in ("valu", "trans"))
     nl = sum(1 for s in seq if s.kind == "lds")
