@@ -4,6 +4,9 @@
 //   phrase_sum   masked segmented sum of token log-probs by phrase id              (halva_trainer.py:411-419,556-557)
 // Rows are read with 16-byte accesses per lane, reduced with wave shuffles + one LDS exchange per workgroup.
 #include "common.h"
+#include <atomic>
+#include <cstdint>
+#include <cstdlib>
 
 namespace {
 
@@ -16,14 +19,15 @@ struct RowIO;
 template <>
 struct RowIO<bf16_t> {
     static constexpr int W = 8;
-    __device__ static void load(const bf16_t* p, float (&f)[8]) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+    typedef u32x4 Raw;      // one 16-byte chunk as it lies in memory (kl_rows keeps the rows' chunks in LDS between its two passes)
+    __device__ static void cvt(const u32x4& v, float (&f)[8]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f[2 * i] = bf16_lo(v[i]);
             f[2 * i + 1] = bf16_hi(v[i]);
         }
     }
+    __device__ static void load(const bf16_t* p, float (&f)[8]) { cvt(*reinterpret_cast<const u32x4*>(p), f); }
     __device__ static void store(bf16_t* p, const float (&f)[8]) {
         u32x4 v;
 #pragma unroll
@@ -36,11 +40,12 @@ struct RowIO<bf16_t> {
 template <>
 struct RowIO<float> {
     static constexpr int W = 4;
-    __device__ static void load(const float* p, float (&f)[4]) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    typedef f32x4 Raw;
+    __device__ static void cvt(const f32x4& v, float (&f)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) f[i] = v[i];
     }
+    __device__ static void load(const float* p, float (&f)[4]) { cvt(*reinterpret_cast<const f32x4*>(p), f); }
     __device__ static void store(float* p, const float (&f)[4]) {
         f32x4 v;
 #pragma unroll
@@ -151,11 +156,19 @@ __global__ __launch_bounds__(256) void token_logp_bwd_kernel(const T* logits, in
 // ---------------------------------------------------------------------------------------------------
 // KL(ref || pol) of one row.  Running state per thread: (m_r, s_r, a_r) for the reference with
 // a_r = sum exp2(t_r - m_r) * (z_r - z_p), and (m_p, s_p) for the policy.
-template <typename T>
-__global__ __launch_bounds__(256) void kl_rows_kernel(const T* pol, const T* __restrict__ ref, int64_t ld,
-                                                      const float* __restrict__ w, float* __restrict__ kl, T* dpol,
-                                                      float gscale, int V) {
-    constexpr int W = RowIO<T>::W;
+// KEEP (round 4): every thread holds its 16-byte chunks of the two rows IN REGISTERS between the statistics pass and the gradient pass (NT = 512
+// threads x KCH = 8 chunks x 2 rows = 64 registers, 122 in all: two workgroups per CU; all sixteen loads are issued before the first use), so
+// that every logit is fetched from HBM ONCE: the second pass of the 256-thread form is not served by L2 / MALL (5 row passes reach HBM for 3
+// algorithmic, profiles/r03_rowops_pmc.json).  tools/bench_kl_rows.py, 8192 rows of 32 000: 362-391 us against 453-457 (4.0-4.3 instead of
+// 3.45 TB/s of the three algorithmic passes).  Forms that leave ONE workgroup on a CU were slower than reading twice - nothing is in flight
+// while it reduces and stores: the rows in 128 000 B of LDS 561 us, in the registers of 1024 threads (92 each) 481-545; 256 x 16 chunks 385-401.
+template <typename T, int NT, bool KEEP, int KCH = 4>
+__global__ __launch_bounds__(NT) void kl_rows_kernel(const T* pol, const T* __restrict__ ref, int64_t ld,
+                                                     const float* __restrict__ w, float* __restrict__ kl, T* dpol,
+                                                     float gscale, int V) {
+    constexpr int W = RowIO<T>::W, kNW = NT / 64;
+    typedef typename RowIO<T>::Raw Raw;
+    Raw keep_r[KEEP ? KCH : 1], keep_p[KEEP ? KCH : 1];      // (the launcher guarantees V / W <= KCH * NT)
     __shared__ float red[5][kNW];
     __shared__ float bc[2];
     const int64_t r = blockIdx.x;
@@ -171,8 +184,8 @@ __global__ __launch_bounds__(256) void kl_rows_kernel(const T* pol, const T* __r
             float z[W];
 #pragma unroll
             for (int j = 0; j < W; ++j) z[j] = 0.f;
-            for (int c = threadIdx.x; c < nvec; c += 256) RowIO<T>::store(drow + (int64_t)c * W, z);
-            for (int v = nvec * W + threadIdx.x; v < V; v += 256) RowIO<T>::put(drow + v, 0.f);
+            for (int c = threadIdx.x; c < nvec; c += NT) RowIO<T>::store(drow + (int64_t)c * W, z);
+            for (int v = nvec * W + threadIdx.x; v < V; v += NT) RowIO<T>::put(drow + v, 0.f);
         }
         return;
     }
@@ -194,10 +207,25 @@ __global__ __launch_bounds__(256) void kl_rows_kernel(const T* pol, const T* __r
         }
         sp += exp2f(tp - mp);
     };
-    for (int c = threadIdx.x; c < nvec; c += 256) {
+    if (KEEP) {
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int c = threadIdx.x + i * NT;
+            if (c < nvec) keep_r[i] = *reinterpret_cast<const Raw*>(rrow + (int64_t)c * W), keep_p[i] = *reinterpret_cast<const Raw*>(prow + (int64_t)c * W);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < (KEEP ? KCH : 1 << 30); ++i) {
+        const int c = threadIdx.x + i * NT;
+        if (c >= nvec) break;
         float fr[W], fp[W];
-        RowIO<T>::load(rrow + (int64_t)c * W, fr);
-        RowIO<T>::load(prow + (int64_t)c * W, fp);
+        if (KEEP) {
+            RowIO<T>::cvt(keep_r[i], fr);
+            RowIO<T>::cvt(keep_p[i], fp);
+        } else {
+            RowIO<T>::load(rrow + (int64_t)c * W, fr);
+            RowIO<T>::load(prow + (int64_t)c * W, fp);
+        }
         // chunk-wise rescale: one max per chunk keeps the exp count at W + 2 per input
         float cr = fr[0], cp = fp[0];
 #pragma unroll
@@ -225,7 +253,7 @@ __global__ __launch_bounds__(256) void kl_rows_kernel(const T* pol, const T* __r
             sp += exp2f(fp[j] * kLog2e - mp);
         }
     }
-    for (int v = nvec * W + threadIdx.x; v < V; v += 256) step(RowIO<T>::get(rrow + v), RowIO<T>::get(prow + v));
+    for (int v = nvec * W + threadIdx.x; v < V; v += NT) step(RowIO<T>::get(rrow + v), RowIO<T>::get(prow + v));
     // wave then workgroup merge
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -273,15 +301,23 @@ __global__ __launch_bounds__(256) void kl_rows_kernel(const T* pol, const T* __r
     const float lr2 = bc[0], lp2 = bc[1];
     const float gs = wr * gscale;
     T* drow = dpol + r * ld;
-    for (int c = threadIdx.x; c < nvec; c += 256) {
+#pragma unroll
+    for (int i = 0; i < (KEEP ? KCH : 1 << 30); ++i) {
+        const int c = threadIdx.x + i * NT;
+        if (c >= nvec) break;
         float fr[W], fp[W];
-        RowIO<T>::load(rrow + (int64_t)c * W, fr);
-        RowIO<T>::load(prow + (int64_t)c * W, fp);
+        if (KEEP) {
+            RowIO<T>::cvt(keep_r[i], fr);
+            RowIO<T>::cvt(keep_p[i], fp);
+        } else {
+            RowIO<T>::load(rrow + (int64_t)c * W, fr);
+            RowIO<T>::load(prow + (int64_t)c * W, fp);
+        }
 #pragma unroll
         for (int j = 0; j < W; ++j) fp[j] = gs * (exp2f(fp[j] * kLog2e - lp2) - exp2f(fr[j] * kLog2e - lr2));
         RowIO<T>::store(drow + (int64_t)c * W, fp);
     }
-    for (int v = nvec * W + threadIdx.x; v < V; v += 256) {
+    for (int v = nvec * W + threadIdx.x; v < V; v += NT) {
         const float zr = RowIO<T>::get(rrow + v), zp = RowIO<T>::get(prow + v);
         RowIO<T>::put(drow + v, gs * (exp2f(zp * kLog2e - lp2) - exp2f(zr * kLog2e - lr2)));
     }
@@ -369,11 +405,19 @@ extern "C" int halva_kl_rows(const void* pol, const void* ref, halva_dtype dt, i
     HALVA_CHECK_ARG(V > 0 && ld >= V, "kl_rows: bad V=%d / ld=%lld", V, (long long)ld);
     HALVA_CHECK_ARG(R < (1ll << 31), "kl_rows: too many rows");
     if (R <= 0) return HALVA_OK;
-    if (dt == HALVA_BF16)
-        hipLaunchKernelGGL(kl_rows_kernel<bf16_t>, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pol,
+    // the rows held in registers between the two passes (bf16 with a gradient, whole 16-byte chunks, at most 8 chunks per thread of 512);
+    // HALVA_KL_KEEP=0 = the 256-thread form that reads them twice
+    const char* kl_env = getenv("HALVA_KL_KEEP");      // (read on every call: a test flips it inside one process)
+    const bool keep_on = !(kl_env && kl_env[0] == '0');
+    const bool vec16 = ((((uintptr_t)pol | (uintptr_t)ref | (uintptr_t)dpol) & 15) == 0) && ld % 8 == 0 && V % 8 == 0;
+    if (dt == HALVA_BF16 && dpol && keep_on && vec16 && V / 8 <= 8 * 512) {
+        hipLaunchKernelGGL((kl_rows_kernel<bf16_t, 512, true, 8>), dim3((unsigned)R), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)pol,
+                           (const bf16_t*)ref, ld, w, kl, (bf16_t*)dpol, gscale, V);
+    } else if (dt == HALVA_BF16)
+        hipLaunchKernelGGL((kl_rows_kernel<bf16_t, 256, false>), dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pol,
                            (const bf16_t*)ref, ld, w, kl, (bf16_t*)dpol, gscale, V);
     else if (dt == HALVA_F32)
-        hipLaunchKernelGGL(kl_rows_kernel<float>, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, (const float*)pol,
+        hipLaunchKernelGGL((kl_rows_kernel<float, 256, false>), dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, (const float*)pol,
                            (const float*)ref, ld, w, kl, (float*)dpol, gscale, V);
     else
         HALVA_CHECK_ARG(false, "kl_rows: unsupported dtype %d", (int)dt);

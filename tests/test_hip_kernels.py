@@ -481,6 +481,30 @@ def test_kl_rows(dtype):
     assert float(same.abs().max()) < 1e-5                    # identical models -> exactly ~0
 
 
+def test_kl_rows_register_resident_rows_match_the_two_read_form(monkeypatch):
+    """halva_kl_rows keeps both bf16 rows in registers between its statistics pass and its gradient pass (one HBM read per logit);
+    HALVA_KL_KEEP=0 is the form that reads them twice.  Same values up to the summation order of 512 instead of 256 partial sums per row."""
+    g = torch.Generator().manual_seed(10)
+    R, V = 37, 32000
+    pol = (torch.randn(R, V, generator=g) * 3).to(torch.bfloat16)
+    ref = (pol.float() + 0.3 * torch.randn(R, V, generator=g)).to(torch.bfloat16)
+    w = torch.ones(R)
+    w[5] = 0
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HALVA_KL_KEEP", mode)
+        pg = pol.to(DEV).requires_grad_(True)
+        kl = K().kl_rows(pg, ref.to(DEV), w.to(DEV))
+        kl.sum().backward()
+        torch.cuda.synchronize()
+        out[mode] = (kl.detach().cpu(), pg.grad.cpu().float())
+    assert float((out["1"][0] - out["0"][0]).abs().max()) < 1e-5 * max(1.0, float(out["0"][0].abs().max()))
+    assert float(out["1"][0][5]) == 0.0 and float(out["1"][1][5].abs().sum()) == 0.0
+    d = (out["1"][1] - out["0"][1]).abs()
+    assert float(d.max()) <= 2.0 ** -7 * float(out["0"][1].abs().max())          # at most one bf16 rounding apart, and almost nowhere
+    assert float((d > 0).float().mean()) < 1e-3
+
+
 def test_phrase_sum_golden_and_grad():
     z = load_npz("loss_small.npz")
     logps = torch.from_numpy(z["logps"])
