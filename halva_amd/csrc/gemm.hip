@@ -4,6 +4,7 @@
 // Workgroup = 4 waves as 2x2, tile 128x128x64, each wave 64x64 (2x2 MFMA tiles); operands are register-staged
 // into double-buffered swizzled LDS tiles; transposed operands are read with ds_read_b64_tr_b16.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -176,6 +177,98 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Round 4: the TN form for the LoRA weight gradients (halva_wgrad_accumulate: C[M, N] f32 += A^T B over `rows`, A [rows, M] and B [rows, N] column
+// windows of row-major activations, M and N multiples of 128) with the operand tiles brought in by LDS-DMA instead of through registers:
+//   * a k-tile = 64 rows of 128 columns (256 bytes each) per operand = sixteen 1-KiB pieces of four rows; wave w requests pieces w, w + 4, w + 8,
+//     w + 12 of both operands with `buffer_load_dwordx4 ... offen lds` through a bounds-checked descriptor over the k-slab (a row past the slab
+//     arrives as ZEROS: no tail case; experiments/fwd3/oob_probe.hip) - no staging registers, no ds_write (8 x 13 cycles per thread and tile before);
+//   * the LDS image keeps the XOR swizzle of Operand<true> (its ds_read_b64_tr_b16 fragments are conflict-free on it): LDS-DMA writes lane l
+//     to byte 16 l of the piece, so the swizzle is applied to WHICH chunk of its row a lane fetches - constant per wave (piece & 3 == wave);
+//   * two stages (64 KiB: two workgroups per CU): iteration t waits for its own requests of tile t, barrier (tile t complete for everyone; everyone
+//     has finished tile t - 1), requests tile t + 1 into the other stage, multiplies tile t.
+// Same arithmetic and summation order inside a slab as gemm_kernel<true, true>: bitwise the same partials.
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const GemmParams p) {
+    constexpr int TILE = 128 * 64 * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* a_lds = smem;               // [2][TILE]
+    char* b_lds = smem + 2 * TILE;    // [2][TILE]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int64_t kb = (int64_t)blockIdx.z * p.ksplit;
+    const int K = (int)min((int64_t)p.ksplit, p.K - kb);
+    const int nk = (K + 63) / 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // descriptors over the slab's rows of this tile's 128 columns: base, stride 0, bytes up to the end of the last row's 128 columns, raw dwords
+    auto desc = [&](const bf16_t* base, int64_t ld) {
+        const uint64_t a = (uint64_t)(size_t)base;
+        u32x4 d;
+        d[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+        d[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        d[2] = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)(K - 1) * ld + 128) * 2));
+        d[3] = 0x00020000u;
+        return d;
+    };
+    const u32x4 da = desc(p.A + kb * p.lda + m0, p.lda), db = desc(p.B + kb * p.ldb + n0, p.ldb);
+    // lane (row l >> 4 of the piece, position l & 15) fetches chunk (position ^ swizzle(row)) of its row: off128's image
+    const int prow = lane >> 4, chunk = (lane & 15) ^ ((prow << 2) | wave);
+    const unsigned voa = (unsigned)(prow * p.lda * 2 + chunk * 16), vob = (unsigned)(prow * p.ldb * 2 + chunk * 16);
+    const unsigned lds_a = (unsigned)(size_t)(__attribute__((address_space(3))) char*)a_lds, lds_b = (unsigned)(size_t)(__attribute__((address_space(3))) char*)b_lds;
+    auto request = [&](int it, int stage) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave + 4 * i;
+            const unsigned sa = (unsigned)(((int64_t)it * 64 + 4 * piece) * p.lda * 2), sb = (unsigned)(((int64_t)it * 64 + 4 * piece) * p.ldb * 2);
+            const unsigned dst_a = lds_a + stage * TILE + piece * 1024, dst_b = lds_b + stage * TILE + piece * 1024;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %7 offen lds\n\t"
+                         "s_mov_b32 m0, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %8 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voa), "v"(vob), "s"(da), "s"(db), "s"(dst_a), "s"(dst_b), "s"(sa), "s"(sb) : "memory");
+        }
+    };
+    request(0, 0);
+#pragma unroll 1
+    for (int it = 0; it < nk; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // tile `it` is complete for every wave; every wave is through with tile it - 1
+        if (it + 1 < nk) request(it + 1, (it + 1) & 1);
+        const char* at = a_lds + (it & 1) * TILE;
+        const char* bt = b_lds + (it & 1) * TILE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s16x8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = Operand<true>::frag(at, 64 * wm + 32 * i, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = Operand<true>::frag(bt, 64 * wn + 32 * j, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                                       __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+        }
+    }
+    float* cz = (float*)p.C + (int64_t)blockIdx.z * p.M * p.ldc;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + 64 * wn + 32 * j + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                cz[(int64_t)m * p.ldc + n] = acc[i][j][r];
+            }
+    }
+}
+
 // images [n, 3, hw, hw] bf16 -> col [n * (hw/p)^2, Kp] bf16, k = (c, ky, kx), zero padded to Kp
 __global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ img, bf16_t* __restrict__ col, int n, int hw,
                                                      int p, int Kp, int64_t total) {
@@ -295,8 +388,19 @@ extern "C" int halva_wgrad_accumulate(const void* A, int64_t lda, const void* B,
     p.K = (int)rows;
     p.out_f32 = 1;
     p.ksplit = ksplit;
-    const int rc = launch_gemm<true, true>(p, (hipStream_t)stream);
-    if (rc != HALVA_OK) return rc;
+    // HALVA_WGRAD_DMA=0: the register-staged gemm_kernel<true, true> of rounds 2-3 (also what odd shapes take)
+    const char* e_dma = getenv("HALVA_WGRAD_DMA");
+    const int64_t slab_bytes = (int64_t)ksplit * (lda > ldb ? lda : ldb) * 2;
+    if (!(e_dma && e_dma[0] == '0') && M % 128 == 0 && N % 128 == 0 && slab_bytes < (1ll << 31)) {
+        const dim3 grid(N / 128, M / 128, splits);
+        const size_t lds = 4 * 128 * 64 * 2;
+        (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(wgrad_dma_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
+        HALVA_CHECK_LAUNCH("wgrad_dma");
+    } else {
+        const int rc = launch_gemm<true, true>(p, (hipStream_t)stream);
+        if (rc != HALVA_OK) return rc;
+    }
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, C, mn, splits,
                        alpha);
     HALVA_CHECK_LAUNCH("splitk_reduce");
