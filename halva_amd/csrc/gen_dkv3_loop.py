@@ -209,8 +209,9 @@ def dma_groups():
              "s_cselect_b64 %s, %s, %s" % (sp(SRC), sp(ptr), safe), "s_cmp_lg_u32 %s, 0" % S_USEALT, "s_cbranch_scc1 .Ldkv3_a%d%s_%%=" % (k, PHASE),
              "global_load_lds_dword v%d, %s" % (LANE4, sp(SRC)), ".Ldkv3_j%d%s_%%=:" % (k, PHASE),
              "s_add_u32 s%d, s%d, 256" % (ptr[0], ptr[0]), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])]
-        ool += [".Ldkv3_a%d%s_%%=:" % (k, PHASE), "global_load_lds_dword %%51, %s" % sp(ptr), "s_branch .Ldkv3_j%d%s_%%=" % (k, PHASE)]
-        groups.append(g)
+        if "nostat" not in os.environ.get("DKV3_DIAG", ""):
+            ool += [".Ldkv3_a%d%s_%%=:" % (k, PHASE), "global_load_lds_dword %%51, %s" % sp(ptr), "s_branch .Ldkv3_j%d%s_%%=" % (k, PHASE)]
+        groups.append([] if "nostat" in os.environ.get("DKV3_DIAG", "") else g)      # (timing experiment: the statistics requests and their scalar code gone)
         k += 1
     ool += [".Ldkv3_sw%s_%%=:" % PHASE, "s_bitcmp1_b32 %s, 16" % S_DMALEFT, "s_cbranch_scc1 .Ldkv3_swb%s_%%=" % PHASE,      # already switched: nothing left
             "s_lshr_b32 %s, %s, 8" % (S_DMALEFT, S_DMALEFT), "s_or_b32 %s, %s, 0x10000" % (S_DMALEFT, S_DMALEFT),
@@ -453,7 +454,7 @@ def main():
     lines = expanded
     diag = os.environ.get("DKV3_DIAG", "")      # timing experiments only (results are wrong): nodma / nobar / nostore, comma separated
     if "nodma" in diag:
-        lines = [l for l in lines if not l.startswith("global_load_lds")]
+        lines = [l for l in lines if not l.startswith("global_load_lds") and not (l.startswith("buffer_load") and l.endswith(" lds"))]
     if "nobar" in diag:
         lines = [l for l in lines if l != "s_barrier" and not l.startswith("s_waitcnt vmcnt")]
     if "nostore" in diag:

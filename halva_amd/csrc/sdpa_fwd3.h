@@ -76,7 +76,7 @@ __device__ __forceinline__ Fwd3Geom fwd3_geom(const SdpaParams& p, int qb, int s
 // A workgroup's position in its static sequence of row blocks: virtual block vb = blockIdx.x + k * gridDim.x (the blocks the static launch of
 // sdpa_fwd_kernel would have started: map_block / paired_blocks - heavy block first, then the light one), all wave-uniform.
 struct Fwd3Cursor {
-    int vb, which, first, second, cur_qb, s, hd, start, len;
+    int vb, which, first, second, cur_qb, s, hd, start, len, seen_s;      // seen_s: the sequence start / len / br were loaded for (-1: none yet)
     Branch br;
     __device__ __forceinline__ int qb() const { return cur_qb; }      // (a stored scalar: `which ? second : first` was compiled into a scratch array)
 };
@@ -87,13 +87,20 @@ __device__ __forceinline__ void fwd3_cursor_load(const SdpaParams& p, Fwd3Cursor
     // the sequence's geometry by SCALAR loads (they return through lgkmcnt): as vector loads the compiler waits for each of them with vmcnt(0) - it
     // knows nothing of what the asm blocks have in flight -, i.e. for the rows just stored and the tiles requested for the next item
     const int sq = (int)dkv3_uni((unsigned)c.s);
-    auto sload = [&](const int32_t* base, int dflt) {
-        if (base == nullptr) return dflt;
-        int v;
-        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(dkv3_uni64(base + sq)) : "memory");
-        return v;
-    };
-    c.start = sload(p.seq_start, 0), c.len = sload(p.seq_len, p.T), c.br.a = sload(p.br_a, 0x7fffffff), c.br.b = sload(p.br_b, 0x7fffffff);
+    if (sq != c.seen_s) {      // (a workgroup's consecutive virtual blocks mostly belong to one sequence)
+        // four loads, ONE wait (an array the launch does not have reads a word of q instead and takes its default afterwards)
+        const int32_t* dummy = reinterpret_cast<const int32_t*>(p.q);
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\ts_load_dword %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(c.start), "=&s"(c.len), "=&s"(c.br.a), "=&s"(c.br.b)
+                     : "s"(dkv3_uni64(p.seq_start ? p.seq_start + sq : dummy)), "s"(dkv3_uni64(p.seq_len ? p.seq_len + sq : dummy)),
+                       "s"(dkv3_uni64(p.br_a ? p.br_a + sq : dummy)), "s"(dkv3_uni64(p.br_b ? p.br_b + sq : dummy))
+                     : "memory");
+        if (!p.seq_start) c.start = 0;
+        if (!p.seq_len) c.len = p.T;
+        if (!p.br_a) c.br.a = 0x7fffffff;
+        if (!p.br_b) c.br.b = 0x7fffffff;
+        c.seen_s = sq;
+    }
     paired_blocks(p.nblk, c.start, c.br, b, c.first, c.second);
     c.which = 0, c.cur_qb = c.first;
 }
@@ -264,6 +271,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int total = ((p.nblk + 1) / 2) * p.npairs;
     WG_CLOCK_BEGIN();
     Fwd3Cursor cur;
+    cur.seen_s = -1;
     cur.vb = blockIdx.x;
     fwd3_cursor_load(p, cur, total);
     bool prefetched = false;

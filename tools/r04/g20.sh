@@ -1,10 +1,10 @@
 #!/bin/bash
 # sdpa_bwd_dkv3 with merged LDS waits: tests, then a time-based A/B against DKV3_WAIT_AGE=0 (libhalva_hip_w0.so) at the step's shapes
 cd $GRAFT_REPO_ROOT; O=gpurun_out; R=$PWD
-timeout 900 python3 -m pytest tests/test_hip_kernels.py tests/test_sdpa_bench_shapes_gpu.py -x -q -m gpu > $O/r04_pytest_sdpa_f.log 2>&1; tail -3 $O/r04_pytest_sdpa_f.log
+[ -n "$SKIPTESTS" ] || timeout 900 python3 -m pytest tests/test_hip_kernels.py tests/test_sdpa_bench_shapes_gpu.py -x -q -m gpu > $O/r04_pytest_sdpa_f.log 2>&1; tail -3 $O/r04_pytest_sdpa_f.log
 export BENCH_STEP_SHAPES=1
 cd /tmp && export TMPDIR=/tmp
-for v in w0 cur w0 cur; do
+for v in ${VARIANTS:-w0 cur w0 cur}; do
   if [ $v = cur ]; then unset HALVA_HIP_LIB; else export HALVA_HIP_LIB=$R/halva_amd/libhalva_hip_$v.so; fi
   rm -rf $R/gpurun_out/prof_ab_$v
   rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_ab_$v -o p --output-format csv -- python3 $R/tools/bench_sdpa_branch.py > /dev/null 2>&1
