@@ -422,6 +422,8 @@ def tail_code():
             if c & 1:
                 o += ["s_add_u32 %s, %s, %%[rows8]" % (S_SOFFQ, S_SOFFQ)]
         o += [".Lf3_noqdma%d_%%=:" % g]
+        if g == 0:
+            o += stamp(1, "tail")      # the group's Q requests are out
         # ---- this item's rows of the group
         l, lt, lse, fl, loff, inv = T0, T0 + 1, T0 + 4, T0 + 5, T0 + 6, T0 + 30      # (inv: a pair, v_pk_mul's factor)
         W, A, R = T0 + 8, T0 + 12, T0 + 40                                           # 4 packed words; 8 accumulator values; 4 x 4 registers read back
@@ -465,21 +467,30 @@ def tail_code():
         # ---- the group's fragments, straight into the Q registers (lane (r, h): row r, chunk 2 ks + h of the half-tile image): the requests were
         # issued in front of 8 row stores and the lse store
         # (a group with rows beyond the tensor may have issued fewer: then everything has to land)
+        if g == 0:
+            o += stamp(2, "tail")      # the group's rows and lse are stored (issued): what follows is the wait for its Q rows
         o += ["s_bitcmp1_b32 %[ctl], 11", "s_cbranch_scc1 .Lf3_qgather%d_%%=" % g, "s_cmp_lt_u32 %s, 32" % S_TMP2, "s_cbranch_scc1 .Lf3_qw0%d_%%=" % g,
               "s_waitcnt vmcnt(9)", "s_branch .Lf3_qw%d_%%=" % g, ".Lf3_qw0%d_%%=:" % g, "s_waitcnt vmcnt(0)", ".Lf3_qw%d_%%=:" % g]
         o += ["ds_read_b128 %%[q%d], v%d offset:%d" % (8 * g + ks, (KRE, KRO)[ks & 1], 512 * (ks >> 1)) for ks in range(8)]
         o += ["s_waitcnt lgkmcnt(0)", "s_branch .Lf3_qdone%d_%%=" % g, ".Lf3_qgather%d_%%=:" % g]
         o += ["global_load_dwordx4 %%[q%d], %%[nqg%d], off%s" % (8 * g + ks, g, (" offset:%d" % (32 * ks)) if ks else "") for ks in range(8)]
         o += ["s_waitcnt vmcnt(0)", ".Lf3_qdone%d_%%=:" % g]
+        if g == 0:
+            o += stamp(3, "tail")      # group 0's fragments are in their registers
     return o
 
 
 STAMP = False
 
 
-def stamp(k):
+STAMP_TAIL = os.environ.get("FWD3_STAMP_TAIL", "0") == "1"      # stamps 1..3 inside the tail (row group 0) instead of the prologue: tools/stamp_fwd3.py STAMP_TAIL=1
+
+
+def stamp(k, where="main"):
     """diagnostic builds (sdpa_fwd3_loop_stamp.inc, -DHALVA_STAMP): the low word of s_memtime into output operand st<k> (k = 0..7)"""
-    return ["s_memtime s[68:69]", "s_waitcnt lgkmcnt(0)", "v_mov_b32_e32 %%[st%d], s68" % k] if STAMP else []
+    if not STAMP or (k in (1, 2, 3) and (where == "tail") != STAMP_TAIL):
+        return []
+    return ["s_memtime s[68:69]", "s_waitcnt lgkmcnt(0)", "v_mov_b32_e32 %%[st%d], s68" % k]
 
 
 def main():

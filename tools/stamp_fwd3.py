@@ -47,7 +47,7 @@ for b in range(30):
             st = r[6:14]
             rows.append(dict(blk=blk, it=it, w=w, N=N, qb=qb, n=n, pre=int(r[1] - r[0]), asm=int(r[2] - r[1]), post=int(r[5] - r[2]), vote=int(r[3] - r[2]), qld=int(r[4] - r[3]), rows_=int(r[5] - r[4]),
                              req=d32(st[1], st[0]), zero=d32(st[2], st[1]), land=d32(st[3], st[2]), s0=d32(st[4], st[3]), loop=d32(st[5], st[4]),
-                             drain=d32(st[6], st[5]), tail=d32(st[7], st[6]), t0=int(r[0]), t3=int(r[5])))
+                             drain=d32(st[6], st[5]), tail=d32(st[7], st[6]), t0=int(r[0]), t3=int(r[5]), raw=[int(x) for x in st]))
 print("%4s %2s %1s %3s %2s %-14s | %6s %7s %6s (%5s %5s %5s) | %5s %5s %6s %5s %8s %6s %5s %5s" % ("blk", "it", "w", "N", "qb", "n0/n1/n2/n3", "pre", "asm", "post", "vote", "qload", "rows", "req", "zero", "land", "S0", "loop",
                                                                            "/step", "dr+vo", "tail"))
 for r in rows[:64]:
@@ -60,6 +60,10 @@ for r in rows:
         tot[k] = tot.get(k, 0) + r[k]
     tot["steps"] = tot.get("steps", 0) + r["N"]
     tot["items"] = tot.get("items", 0) + 1
+if os.environ.get("STAMP_TAIL") == "1":      # a FWD3_STAMP_TAIL=1 build: stamps 1..3 sit in the tail (row group 0)
+    n = len(rows)
+    parts = [sum(d32(x, y) for x, y in ((r["raw"][a_], r["raw"][b_]) for r in rows)) / n for a_, b_ in ((1, 6), (2, 1), (3, 2), (7, 3))]
+    print("tail (mean over %d wave-items): group 0 Q requests %.0f | group 0 rows + lse %.0f | wait + read-back of group 0's Q %.0f | all of group 1 %.0f" % (n, *parts))
 print("per item (mean over %d wave-items): pre %d asm %d post %d | req %d zero %d land %d S0 %d loop %d (%.0f per step) drain+vote %d tail %d"
       % (tot["items"], tot["pre"] / tot["items"], tot["asm"] / tot["items"], tot["post"] / tot["items"], tot["req"] / tot["items"], tot["zero"] / tot["items"],
          tot["land"] / tot["items"], tot["s0"] / tot["items"], tot["loop"] / tot["items"], tot["loop"] / tot["steps"], tot["drain"] / tot["items"], tot["tail"] / tot["items"]))

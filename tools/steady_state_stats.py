@@ -28,7 +28,7 @@ def cat(n):
         if key in n: return lab
     if "anonymous namespace" in n:
         for k in ("swiglu_bwd", "swiglu_fwd", "rmsnorm_bwd", "rmsnorm_fwd", "rope_qk", "splice_rows", "token_logp_fwd", "token_logp_bwd", "kl_rows",
-                  "phrase_sum_fwd", "phrase_sum_bwd", "gemm_kernel", "im2col", "gelu_bwd", "colsum", "splitk_reduce", "clock_probe"):
+                  "phrase_sum_fwd", "phrase_sum_bwd", "wgrad_dma", "gemm_kernel", "im2col", "gelu_bwd", "colsum", "splitk_reduce", "clock_probe"):
             if k in n: return k + " (HIP)"
     if n.startswith("Cijk") or n.startswith("Custom_Cijk"): return "hipBLASLt / rocBLAS GEMMs (PyTorch-ROCm)"
     for key, lab in (("multi_tensor_apply", "AdamW (torch foreach kernels)"), ("elementwise_kernel", "torch elementwise (adds, casts, copies, fills)"),

@@ -10,7 +10,7 @@ def cat(n):
         if key in n: return lab
     if "anonymous namespace" in n:
         for k in ("swiglu_bwd", "swiglu_fwd", "rmsnorm_bwd", "rmsnorm_fwd", "rope_qk", "splice_rows", "token_logp_fwd", "token_logp_bwd", "kl_rows",
-                  "phrase_sum_fwd", "phrase_sum_bwd", "gemm_kernel", "im2col", "gelu_bwd", "colsum", "layernorm_fwd", "layernorm_bwd_params",
+                  "phrase_sum_fwd", "phrase_sum_bwd", "wgrad_dma", "gemm_kernel", "im2col", "gelu_bwd", "colsum", "layernorm_fwd", "layernorm_bwd_params",
                   "downsample2x2", "image_resample_h", "image_resample_v", "splitk_reduce"):
             if k in n: return k + " (HIP)"
     if n.startswith("Cijk") or n.startswith("Custom_Cijk"): return "hipBLASLt GEMMs (PyTorch-ROCm)"
