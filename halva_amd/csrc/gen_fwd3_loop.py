@@ -412,6 +412,8 @@ def tail_code():
         # ---- request the group's 32 rows of the NEXT item: piece c = rows 8 (c / 2) .. + 7, chunks 8 (c % 2) .. + 7 of the half-tile image
         # (ctl bit 11: the next row block begins in front of its sequence - left padding: its Q fragments are gathered row by row with clamped
         # pointers behind the stores instead, as the workgroup's first item's are)
+        # (Tried in round 4 and NOT kept: the eight requests handed out one at a time between the eight conversion stretches below - the tail grew
+        # from 6 330 to 7 870 cycles: a request costs the lone wave its ~85 cycles wherever it is issued, and the last ones then land late.)
         o += ["s_bitcmp1_b32 %[ctl], 11", "s_cbranch_scc1 .Lf3_noqdma%d_%%=" % g]
         o += ["v_readfirstlane_b32 %s, %%[nqsoff%d]" % (S_SOFFQ, g), "s_mov_b32 m0, %s" % S_QST, "s_nop 2"]
         for c in range(8):      # (no immediate offset: an LDS-DMA load adds it to the LDS address as well)
@@ -423,7 +425,7 @@ def tail_code():
                 o += ["s_add_u32 %s, %s, %%[rows8]" % (S_SOFFQ, S_SOFFQ)]
         o += [".Lf3_noqdma%d_%%=:" % g]
         if g == 0:
-            o += stamp(1, "tail")      # the group's Q requests are out
+            o += stamp(1, "tail")
         # ---- this item's rows of the group
         l, lt, lse, fl, loff, inv = T0, T0 + 1, T0 + 4, T0 + 5, T0 + 6, T0 + 30      # (inv: a pair, v_pk_mul's factor)
         W, A, R = T0 + 8, T0 + 12, T0 + 40                                           # 4 packed words; 8 accumulator values; 4 x 4 registers read back
