@@ -1456,12 +1456,23 @@ __global__ __launch_bounds__(256) void sdpa_bwd_delta_kernel(const SdpaParams p,
 __device__ __forceinline__ int ds_piece_off(int key, int qgroup) {      // byte offset of (key 0..31, queries 4 G .. 4 G + 3) in a strip's 2 KiB
     return 1024 * (qgroup >> 2) + 16 * (key + 32 * (qgroup & 1)) + 8 * ((qgroup >> 1) & 1);
 }
+// The LDS copy (round 4): the same image with its 1-KiB pieces 1152 bytes apart (strips 2304, ring slots 4608).  One transposed read has, in
+// each half of the wave, its lanes on byte pairs that differ in G >> 2 (the piece) and G & 1 (512 bytes apart inside the piece) only: 1 KiB and
+// 512 bytes are multiples of the 256-byte bank row - the same banks FOUR times (SQ_LDS_BANK_CONFLICT = 37 % of this kernel's LDS cycles,
+// profiles/r04_sdpa_all_pmc.json).  The 128 bytes of padding move the odd pieces half a bank row: two-way.  Measured and NOT kept: the last
+// factor of two by an XOR of the chunk position, applied by the LDS-DMA lanes (lane l fetches chunk l ^ swizzle; LDS-DMA writes lane l to
+// byte 16 l) - zero conflicts, but the requests no longer ask for their 1 KiB in lane order and the kernel, which is HBM-bound, ran 1.6 % SLOWER
+// (950-959 -> 971-973 us at the step's shapes, same box).
+constexpr int DS_LDS_PIECE = 1024 + 128, DS_LDS_STRIP = 2 * DS_LDS_PIECE, DS_LDS_SLOT = 2 * DS_LDS_STRIP;
+__device__ __forceinline__ int ds_lds_off(int key, int qgroup) {      // (inside a strip)
+    return DS_LDS_PIECE * (qgroup >> 2) + 16 * (key + 32 * (qgroup & 1)) + 8 * ((qgroup >> 1) & 1);
+}
 template <int D, bool SLOW_TR>
 __device__ __forceinline__ void sdpa_bwd_dq2_block(const SdpaParams& p, char* smem, int s, int hd, int qb, int wave, int lane) {
     constexpr int NW = 8, BN = 64, DT = D / 32, BM = 32 * NW, RING = 3;
     constexpr int TILE_BYTES = BN * D * 2;
     char* k_lds = smem;                                            // [RING][BN][D]
-    char* ds_lds = smem + RING * TILE_BYTES + wave * (RING * 4096);  // per wave: [RING][2 strips][2 KiB]
+    char* ds_lds = smem + RING * TILE_BYTES + wave * (RING * DS_LDS_SLOT);  // per wave: [RING][2 strips][2 pieces of 1 KiB + 128 B]
     const int h = lane >> 5;
     const int start = p.seq_start ? p.seq_start[s] : 0;
     const int len = p.seq_len ? p.seq_len[s] : p.T;
@@ -1502,7 +1513,7 @@ __device__ __forceinline__ void sdpa_bwd_dq2_block(const SdpaParams& p, char* sm
             const char* src = ds_pair + ((int64_t)(kt >> 1) * p.ds_nt + step) * 16384 + 2 * (kt & 1) * 4096 + sub * 2048;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {                 // strip c >> 1, register half c & 1
-                const unsigned dst = ds_dst + slot * 4096 + c * 1024;
+                const unsigned dst = ds_dst + slot * DS_LDS_SLOT + (c >> 1) * DS_LDS_STRIP + (c & 1) * DS_LDS_PIECE;
                 const unsigned voff = lane * 16;
                 const char* rows = src + (c >> 1) * 4096 + (c & 1) * 1024;
                 unsigned keep;
@@ -1514,7 +1525,7 @@ __device__ __forceinline__ void sdpa_bwd_dq2_block(const SdpaParams& p, char* sm
     };
     // per-lane byte offsets of the transposed reads of dS^T (see frag_cols for the lane roles): key 8 jj + 4 hb + q4, query group 4 (g & 1) + pp
     const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3, hb = g >> 1;
-    const int ds_rd0 = ds_piece_off(4 * hb + q4, 4 * (g & 1) + pp);           // jj = 0; jj = 1 adds 8 keys = 128 bytes
+    const int ds_rd0 = ds_lds_off(4 * hb + q4, 4 * (g & 1) + pp);           // jj = 0; jj = 1 adds 8 keys = 128 bytes
     // A row block wholly in branch B never needs the key tiles that lie wholly inside [a, b) (the producer wrote no dS for them either):
     // the walk jumps from tile skip_lo - 1 to tile skip_hi, as the forward's does.  In the bench's packed rows [668 | 1380 | 1380] that
     // is 21 of the 33..54 tiles of each of the six B blocks - 30 % of this kernel's tile steps, each a 16-KiB K tile and up to 32 KiB
@@ -1550,7 +1561,7 @@ __device__ __forceinline__ void sdpa_bwd_dq2_block(const SdpaParams& p, char* sm
         if (i + 2 < n_walk) stage(tile_at(i + 2), (slot + 2) % RING);         // into the slot of tile i - 1
         if (tile_live(kt)) {
             const char* ktile = k_lds + slot * TILE_BYTES;
-            const char* dst_t = ds_lds + slot * 4096;
+            const char* dst_t = ds_lds + slot * DS_LDS_SLOT;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {               // 16 keys each: strip ks >> 1, half ks & 1
                 if (strip_hidden(kt, ks >> 1)) continue;
@@ -1559,12 +1570,12 @@ __device__ __forceinline__ void sdpa_bwd_dq2_block(const SdpaParams& p, char* sm
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int key = 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3), qq = lane & 31;
-                        zb[j] = *reinterpret_cast<const short*>(dst_t + (ks >> 1) * 2048 + ds_piece_off(key, qq >> 2) + (qq & 3) * 2);
+                        zb[j] = *reinterpret_cast<const short*>(dst_t + (ks >> 1) * DS_LDS_STRIP + ds_lds_off(key, qq >> 2) + (qq & 3) * 2);
                     }
                 } else {
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
-                        const char* a = dst_t + (ks >> 1) * 2048 + ds_rd0 + 16 * (16 * (ks & 1) + 8 * jj);
+                        const char* a = dst_t + (ks >> 1) * DS_LDS_STRIP + ds_rd0 + 16 * (16 * (ks & 1) + 8 * jj);
                         const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)a);
                         zb[4 * jj + 0] = t[0];
                         zb[4 * jj + 1] = t[1];
@@ -1756,7 +1767,7 @@ int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st) {
             rc2 = slow ? launch_one(sdpa_bwd_dkv2_kernel<D, CAUSAL, true>, p, CAUSAL, 128, 512, lds_dkv, S, st, "sdpa_bwd_dkv2")
                        : launch_one(sdpa_bwd_dkv2_kernel<D, CAUSAL, false>, p, CAUSAL, 128, 512, lds_dkv, S, st, "sdpa_bwd_dkv2");
         if (rc2 != HALVA_OK) return rc2;
-        const size_t lds_dq2 = 3 * 64 * D * 2 + 8 * 3 * 4096;
+        const size_t lds_dq2 = 3 * 64 * D * 2 + 8 * 3 * DS_LDS_SLOT;
         return slow ? launch_one(sdpa_bwd_dq2_kernel<D, true>, p, true, 256, 512, lds_dq2, S, st, "sdpa_bwd_dq2")
                     : launch_one(sdpa_bwd_dq2_kernel<D, false>, p, true, 256, 512, lds_dq2, S, st, "sdpa_bwd_dq2");
     }
