@@ -40,19 +40,23 @@ CARRY_K = 4
 X = [64, 96]; Y = [80, 112]; PB = [128, 144]; ZB = [136, 152]; SL = 160; RING = 176
 QRE, QRO, DRE, DRO, QC0, QC1, DC0, DC1, STAT, DSOFF, LANE4, LANE, V_LO, V_T, V_NINF = 208, 209, 210, 211, 212, 213, 214, 215, 216, 217, 218, 219, 220, 221, 222
 S_SLOT, S_CNT, S_DMALEFT, S_TOFF, S_TMP, S_TMP2 = "s72", "s73", "s74", "s75", "s80", "s81"
-LP, NP, DSP = (82, 83), (84, 85), (86, 87)
-S_DSTQ, S_M0SAVE, S_DSTS, S_USEALT, S_ISSUED = "s88", "s89", "s90", "s91", "s96"
+DSP, SDESC = (82, 83), (84, 87)      # the step's dS chunk (pointer); the statistics of this (sequence, head) as a buffer descriptor
+S_DSTQ, S_M0SAVE, S_DSTS, S_SOFFS = "s88", "s89", "s90", "s91"      # (s96 free)
 SRC = (98, 99)
 # Q / dO tiles arrive through bounds-checked buffer descriptors over the sequence's rows of this head (round 4: as sdpa_fwd3's K / V tiles): a row past
 # the sequence arrives as ZEROS (experiments/fwd3/oob_probe.hip), so the partial last tile and the requests past the block's end need no case of
-# their own - three instructions per 1-KiB piece instead of ten.  The statistics rows (two dword requests per step) keep the pointer form.
+# their own - three instructions per 1-KiB piece instead of ten.  The statistics (round 4, second pass): the delta kernel writes lse2 and -delta of a
+# 64-row step side by side - [lse2 x 64][-delta x 64] = 512 bytes per step, steps in sequence coordinates (sdpa.hip:sdpa_bwd_delta_kernel) - so ONE
+# `buffer_load_dwordx4 ... lds` per step brings both (lanes 0..31; the upper lanes' offsets lie outside the descriptor and write zeros into the unused
+# half of the 1-KiB statistics slot), a step past the sequence brings zeros, and the selects, the dummy target and the clamped-lane path of the two
+# pointer-form requests are gone: 4 instructions instead of 18 + 6, one vector-memory operation instead of two (a request costs the lone wave ~25-60
+# cycles, experiments/issue_cost).
 QDESC, DDESC = (92, 95), (76, 79)
 S_SOFFQ, S_SOFFD = "s70", "s71"
-DUMMY_LDS = 133120                  # 1 KiB behind the statistics: where the requests of the steps without a tile land
 MASKED = False
 PHASE = "a"
-DO_LDS, LSE_LDS, ND_DELTA, NSLOT = 65536, 131072, 1024, 4
-VM_STEADY = 32                      # vector-memory operations issued behind the requests of tile t+1 when step t waits for it: 3 x 4 stores + 2 x 10 requests
+DO_LDS, LSE_LDS, ND_DELTA, NSLOT = 65536, 131072, 256, 4      # statistics slot t & 3: [lse2 x 64][-delta x 64][512 bytes unused] at LSE_LDS + 1024 slot
+VM_STEADY = 30                      # vector-memory operations issued behind the requests of tile t+1 when step t waits for it: 3 x 4 stores + 2 x 9 requests
 WAIT_GAP = 64 - LOOKAHEAD - 1
 # ctl, the call's control word: bit 0 first call of the key block, bits 1-2 tiles to request up front, bits 3-5 which of them is the partial
 # last tile (7: none), bit 8 the run's last request is the partial
@@ -168,7 +172,7 @@ def addr_setup():
     o.append(Ins("v_xor_b32_e32 v%d, 32, v%d" % (QC1, QC0), "valu", reads=["v%d" % QC0], writes=["v%d" % QC1], cost=1))
     o.append(Ins("v_add_u32_e32 v%d, %d, v%d" % (DC0, DO_LDS, QC0), "valu", reads=["v%d" % QC0], writes=["v%d" % DC0], cost=1))
     o.append(Ins("v_add_u32_e32 v%d, %d, v%d" % (DC1, DO_LDS, QC1), "valu", reads=["v%d" % QC1], writes=["v%d" % DC1], cost=1))
-    o.append(Ins("s_lshl_b32 %s, %s, 8" % (S_TMP, S_SLOT), "salu"))
+    o.append(Ins("s_lshl_b32 %s, %s, 10" % (S_TMP, S_SLOT), "salu"))
     o.append(Ins("s_add_u32 %s, %s, %d" % (S_TMP, S_TMP, LSE_LDS), "salu"))
     o.append(Ins("v_add_u32_e32 v%d, %s, %%26" % (STAT, S_TMP), "valu", writes=["v%d" % STAT], cost=1))
     return o
@@ -179,23 +183,19 @@ def sq(quad):
 
 
 def dma_groups():
-    """[list of instruction texts] x 10: the requests of the tile three steps ahead - WITHOUT a taken branch on the common path (a taken
-    branch costs the wave tens of cycles, and eleven of them per step were a sixth of the step).  Q / dO pieces: `buffer_load_dwordx4 ... offen lds`
-    through the sequence's descriptors - a piece past the sequence's last row brings zeros, a request past the block's last tile lands in a ring slot
-    nobody reads any more: no special case, and every step has the same vector-memory operations, so the wait for tile t+1 is ONE counted vmcnt.
-    The two statistics rows keep the pointer form: when no tile is left they are redirected to a 1-KiB dummy chunk of LDS, and the partial last
-    tile of a sequence (rows clamped: S_USEALT) leaves the line, to code behind the loop (`ool`)."""
+    """[list of instruction texts] x 9: the requests of the tile three steps ahead - WITHOUT a taken branch on the common path (a taken
+    branch costs the wave tens of cycles).  Q / dO pieces and the statistics: `buffer_load_dwordx4 ... offen lds` through the sequence's
+    descriptors - a row / step past the sequence brings zeros, a request past the block's last tile lands in a ring slot nobody reads any more:
+    no special case, and every step has the same vector-memory operations, so the wait for tile t+1 is ONE counted vmcnt."""
     groups, ool = [], []
     # S_DMALEFT: bits 0-7 tiles of this block still to request; bits 8-15 tiles of the workgroup's NEXT item to request behind them (the steps
     # of a block that have no tile of their own left to ask for - its last three - ask for the next item's first tiles:
     # same slot rotation, so the next block simply starts on a rotated ring; free of charge, where a prefetch block of its own behind the
-    # steps cost 3 700 cycles per item); bit 16: that switch has been made (it also keeps the partial-tile path off the next item's rows)
+    # steps cost 3 700 cycles per item); bit 16: that switch has been made
     pre = ["s_and_b32 s97, %s, 0xff" % S_DMALEFT, "s_cmp_eq_u32 s97, 0", "s_cbranch_scc1 .Ldkv3_sw%s_%%=" % PHASE, ".Ldkv3_swb%s_%%=:" % PHASE,
            "s_add_u32 %s, %s, 3" % (S_TMP, S_SLOT), "s_and_b32 %s, %s, 3" % (S_TMP, S_TMP), "s_lshl_b32 %s, %s, 14" % (S_DSTQ, S_TMP),
-           "s_lshl_b32 %s, %%34, 10" % S_TMP2, "s_add_u32 %s, %s, %s" % (S_DSTQ, S_DSTQ, S_TMP2), "s_lshl_b32 %s, %s, 8" % (S_DSTS, S_TMP),
+           "s_lshl_b32 %s, %%34, 10" % S_TMP2, "s_add_u32 %s, %s, %s" % (S_DSTQ, S_DSTQ, S_TMP2), "s_lshl_b32 %s, %s, 10" % (S_DSTS, S_TMP),
            "s_add_u32 %s, %s, %d" % (S_DSTS, S_DSTS, LSE_LDS),
-           "s_and_b32 %s, %s, 0xff" % (S_ISSUED, S_DMALEFT), "s_min_u32 %s, %s, 1" % (S_ISSUED, S_ISSUED),
-           "s_and_b32 %s, %s, 0x100ff" % (S_USEALT, S_DMALEFT), "s_bfe_u32 s97, %[ctl], 0x10008", "s_cmp_eq_u32 %s, 1" % S_USEALT, "s_cselect_b32 %s, s97, 0" % S_USEALT,
            "s_mov_b32 m0, %s" % S_DSTQ]
     k = 0
     for which, desc, soff, voff, piece, base in (("q", QDESC, S_SOFFQ, "%27", "%37", 0), ("do", DDESC, S_SOFFD, "%28", "%38", DO_LDS)):
@@ -204,23 +204,16 @@ def dma_groups():
             g += ["buffer_load_dwordx4 %s, %s, %s offen lds" % (voff, sq(desc), soff), "s_add_u32 %s, %s, %s" % (soff, soff, piece), "s_add_u32 m0, m0, 4096"]
             groups.append((pre if k == 0 else []) + g)
             k += 1
-    for ptr, extra, safe in ((LP, 0, "%57"), (NP, ND_DELTA, "%57")):
-        g = ["s_add_u32 %s, %s, %d" % (S_TMP, S_DSTS, extra), "s_cmp_lg_u32 %s, 0" % S_ISSUED, "s_cselect_b32 m0, %s, %d" % (S_TMP, DUMMY_LDS),
-             "s_cselect_b64 %s, %s, %s" % (sp(SRC), sp(ptr), safe), "s_cmp_lg_u32 %s, 0" % S_USEALT, "s_cbranch_scc1 .Ldkv3_a%d%s_%%=" % (k, PHASE),
-             "global_load_lds_dword v%d, %s" % (LANE4, sp(SRC)), ".Ldkv3_j%d%s_%%=:" % (k, PHASE),
-             "s_add_u32 s%d, s%d, 256" % (ptr[0], ptr[0]), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])]
-        if "nostat" not in os.environ.get("DKV3_DIAG", ""):
-            ool += [".Ldkv3_a%d%s_%%=:" % (k, PHASE), "global_load_lds_dword %%51, %s" % sp(ptr), "s_branch .Ldkv3_j%d%s_%%=" % (k, PHASE)]
-        groups.append([] if "nostat" in os.environ.get("DKV3_DIAG", "") else g)      # (timing experiment: the statistics requests and their scalar code gone)
-        k += 1
+    stat = ["s_mov_b32 m0, %s" % S_DSTS, "s_nop 0", "buffer_load_dwordx4 %%[stat_voff], %s, %s offen lds" % (sq(SDESC), S_SOFFS), "s_add_u32 %s, %s, 512" % (S_SOFFS, S_SOFFS)]
+    groups.append([] if "nostat" in os.environ.get("DKV3_DIAG", "") else stat)      # (timing experiment: the statistics request and its scalar code gone)
     ool += [".Ldkv3_sw%s_%%=:" % PHASE, "s_bitcmp1_b32 %s, 16" % S_DMALEFT, "s_cbranch_scc1 .Ldkv3_swb%s_%%=" % PHASE,      # already switched: nothing left
             "s_lshr_b32 %s, %s, 8" % (S_DMALEFT, S_DMALEFT), "s_or_b32 %s, %s, 0x10000" % (S_DMALEFT, S_DMALEFT),
             "s_and_b32 s97, %s, 0xff" % S_DMALEFT, "s_cmp_eq_u32 s97, 0", "s_cbranch_scc1 .Ldkv3_swb%s_%%=" % PHASE]            # no next item to serve
     ool += ["v_readfirstlane_b32 s%d, %%[nq_lo]" % QDESC[0], "v_readfirstlane_b32 s%d, %%[nq_hi]" % (QDESC[0] + 1), "v_readfirstlane_b32 s%d, %%[nqrec]" % (QDESC[0] + 2),
             "v_readfirstlane_b32 s%d, %%[ndo_lo]" % DDESC[0], "v_readfirstlane_b32 s%d, %%[ndo_hi]" % (DDESC[0] + 1), "v_readfirstlane_b32 s%d, %%[ndorec]" % (DDESC[0] + 2),
-            "v_readfirstlane_b32 %s, %%[nqsoff]" % S_SOFFQ, "v_readfirstlane_b32 %s, %%[ndosoff]" % S_SOFFD]
-    for k, ptr in ((2, LP), (3, NP)):
-        ool += ["v_readfirstlane_b32 s%d, %%[n%s_lo]" % (ptr[0], ("q", "do", "lse", "nd")[k]), "v_readfirstlane_b32 s%d, %%[n%s_hi]" % (ptr[1], ("q", "do", "lse", "nd")[k])]
+            "v_readfirstlane_b32 %s, %%[nqsoff]" % S_SOFFQ, "v_readfirstlane_b32 %s, %%[ndosoff]" % S_SOFFD,
+            "v_readfirstlane_b32 s%d, %%[nst_lo]" % SDESC[0], "v_readfirstlane_b32 s%d, %%[nst_hi]" % (SDESC[0] + 1), "v_readfirstlane_b32 s%d, %%[nst_rec]" % (SDESC[0] + 2),
+            "v_readfirstlane_b32 %s, %%[nst_soff]" % S_SOFFS]
     ool += ["s_nop 3", "s_branch .Ldkv3_swb%s_%%=" % PHASE]
     return groups, ool
 
@@ -386,7 +379,10 @@ def main():
            "v_mbcnt_lo_u32_b32 v%d, -1, 0" % LANE, "v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (LANE, LANE),
            "v_lshlrev_b32_e32 v%d, 4, v%d" % (DSOFF, LANE), "v_lshlrev_b32_e32 v%d, 2, v%d" % (LANE4, LANE),
            "s_bfe_u32 %s, %%[ctl], 0x20009" % S_SLOT, "s_mov_b32 %s, %%32" % S_DMALEFT] + \
-          ["v_readfirstlane_b32 s%d, %%[%s_%s]" % (ptr[w], nm, "lo" if w == 0 else "hi") for ptr, nm in ((LP, "lse"), (NP, "nd"), (DSP, "ds")) for w in (0, 1)] + [
+          ["v_readfirstlane_b32 s%d, %%[ds_%s]" % (DSP[w], "lo" if w == 0 else "hi") for w in (0, 1)] + [
+           # the statistics of this (sequence, head): 512 bytes per 64-row step from the sequence's first row on; st_soff: the first step to request
+           "v_readfirstlane_b32 s%d, %%[st_lo]" % SDESC[0], "v_readfirstlane_b32 s%d, %%[st_hi]" % (SDESC[0] + 1), "v_readfirstlane_b32 s%d, %%[st_rec]" % (SDESC[0] + 2),
+           "s_mov_b32 s%d, 0x00020000" % (SDESC[0] + 3), "v_readfirstlane_b32 %s, %%[st_soff]" % S_SOFFS,
            # the sequence's Q / dO rows of this head as buffer descriptors (base, 0 stride, bytes up to the end of the last row, raw 32-bit format);
            # q_soff / do_soff: the first tile to request, in bytes from the sequence's first row
            "v_readfirstlane_b32 s%d, %%[q_lo]" % QDESC[0], "v_readfirstlane_b32 s%d, %%[q_hi]" % (QDESC[0] + 1), "v_readfirstlane_b32 s%d, %%[q_rec]" % (QDESC[0] + 2),
@@ -414,18 +410,13 @@ def main():
     for i in range(3):
         pro += [CTL_NPRO, "s_cmp_le_u32 s97, %d" % i, "s_cbranch_scc1 .Ldkv3_prodone_%="]
         pro += ["s_add_u32 %s, %s, %d" % (S_TMP, S_SLOT, i), "s_and_b32 %s, %s, 3" % (S_TMP, S_TMP), "s_lshl_b32 %s, %s, 14" % (S_DSTQ, S_TMP),
-                "s_lshl_b32 %s, %%34, 10" % S_TMP2, "s_add_u32 %s, %s, %s" % (S_DSTQ, S_DSTQ, S_TMP2), "s_lshl_b32 %s, %s, 8" % (S_DSTS, S_TMP),
-                "s_add_u32 %s, %s, %d" % (S_DSTS, S_DSTS, LSE_LDS),
-                CTL_PROALT, "s_cmp_eq_u32 s97, %d" % i, "s_cselect_b32 %s, 1, 0" % S_USEALT]
+                "s_lshl_b32 %s, %%34, 10" % S_TMP2, "s_add_u32 %s, %s, %s" % (S_DSTQ, S_DSTQ, S_TMP2), "s_lshl_b32 %s, %s, 10" % (S_DSTS, S_TMP),
+                "s_add_u32 %s, %s, %d" % (S_DSTS, S_DSTS, LSE_LDS)]
         for which, desc, soff, voff, piece, base in (("q", QDESC, S_SOFFQ, "%27", "%37", 0), ("do", DDESC, S_SOFFD, "%28", "%38", DO_LDS)):
             pro += ["s_add_u32 m0, %s, %d" % (S_DSTQ, base), "s_nop 0"]
             for k in range(4):
                 pro += ["buffer_load_dwordx4 %s, %s, %s offen lds" % (voff, sq(desc), soff), "s_add_u32 %s, %s, %s" % (soff, soff, piece), "s_add_u32 m0, m0, 4096", "s_nop 0"]
-        for which, ptr, extra in (("l", LP, 0), ("n", NP, ND_DELTA)):
-            pro += ["s_add_u32 m0, %s, %d" % (S_DSTS, extra), "s_cmp_lg_u32 %s, 0" % S_USEALT, "s_cbranch_scc1 .Ldkv3_pa%d%s_%%=" % (i, which),
-                    "global_load_lds_dword v%d, %s" % (LANE4, sp(ptr)), "s_branch .Ldkv3_pj%d%s_%%=" % (i, which),
-                    ".Ldkv3_pa%d%s_%%=:" % (i, which), "global_load_lds_dword %%51, %s" % sp(ptr), ".Ldkv3_pj%d%s_%%=:" % (i, which),
-                    "s_add_u32 s%d, s%d, 256" % (ptr[0], ptr[0]), "s_addc_u32 s%d, s%d, 0" % (ptr[1], ptr[1])]
+        pro += ["s_mov_b32 m0, %s" % S_DSTS, "s_nop 0", "buffer_load_dwordx4 %%[stat_voff], %s, %s offen lds" % (sq(SDESC), S_SOFFS), "s_add_u32 %s, %s, 512" % (S_SOFFS, S_SOFFS)]
     pro += [".Ldkv3_prodone_%=:", "s_waitcnt vmcnt(0)", "s_barrier", ".Ldkv3_nofirst_%=:"]
     pro += [i.text for i in addr_setup()]
     for n in range(LOOKAHEAD):
@@ -437,8 +428,7 @@ def main():
         lines += body
         lines += ["s_sub_u32 %s, %s, 1" % (S_CNT, S_CNT), "s_cmp_lg_u32 %s, 0" % S_CNT, "s_cbranch_scc1 .Ldkv3_loop%s_%%=" % phase, ".Ldkv3_skip%s_%%=:" % phase]
     lines += ["s_branch .Ldkv3_end_%="] + ool_a + ool_b + ool_c + [".Ldkv3_end_%=:", "s_waitcnt lgkmcnt(0)", "s_mov_b32 m0, %s" % S_M0SAVE]
-    names = {24: "rowrel", 25: "colrel", 26: "statrel", 27: "voff_q", 28: "voff_do", 30: "sc", 32: "ndma", 34: "wave", 37: "q_piece", 38: "do_piece", 41: "lo0", 42: "range",
-             51: "alt_stat", 57: "safe_l"}
+    names = {24: "rowrel", 25: "colrel", 26: "statrel", 27: "voff_q", 28: "voff_do", 30: "sc", 32: "ndma", 34: "wave", 37: "q_piece", 38: "do_piece", 41: "lo0", 42: "range"}
     names.update({i: "accV%d" % i for i in range(4)}); names.update({4 + i: "accK%d" % i for i in range(4)})
     names.update({8 + i: "kq%d" % i for i in range(8)}); names.update({16 + i: "vq%d" % i for i in range(8)})
     import re

@@ -82,7 +82,9 @@ struct SdpaParams {
     bf16_t* dv;
     float* lse;           // [S, H, T]
     float* delta;         // [S, H, T]
-    float* lse2;          // [S, H, T] lse * log2(e), written by the delta pass for sdpa_bwd_dkv3 (tail of the dS workspace), or nullptr
+    float* lse2;          // sdpa_bwd_dkv3's row statistics, written by the delta pass (tail of the dS workspace; nullptr without one): per (sequence,
+                          // head) stat_nt records of 512 bytes, one per 64-row step in SEQUENCE coordinates: [lse * log2(e) x 64][-delta x 64]
+    int stat_nt;          // records per (sequence, head) = ceil(T / 64)
     int sched_order;      // order of the items inside a queue (sdpa_dkv3.h)
     int* sched;           // sdpa_bwd_dkv3's eight work-queue counters, 128 B apart (behind lse2 in the workspace), zeroed by the delta pass
     const int32_t* seq_start;
@@ -1434,9 +1436,13 @@ __global__ __launch_bounds__(256) void sdpa_bwd_delta_kernel(const SdpaParams p,
         for (int o = D / 16; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
         if (lane % (D / 8) == 0) {
             const int64_t at = ((int64_t)s * p.H + hd) * p.T + t;
-            if (for_dkv3) {      // sdpa_bwd_dkv3 starts its dP chain from -delta and fetches lse * log2(e) as a plain row (sdpa_dkv3.h)
-                p.delta[at] = -acc;
-                p.lse2[at] = p.lse[at] * kLog2e;
+            if (for_dkv3) {      // sdpa_bwd_dkv3 starts its dP chain from -delta and fetches both statistics of a 64-row step with ONE request (sdpa_dkv3.h)
+                const int loc = t - start;
+                float* rec = p.lse2 + (((int64_t)s * p.H + hd) * p.stat_nt + (loc >> 6)) * 128;
+                rec[loc & 63] = p.lse[at] * kLog2e;
+                rec[64 + (loc & 63)] = -acc;
+                if (loc == len - 1)      // the rest of the sequence's last record: zeros (a padded query row then yields P = 1, dS = 0 - finite)
+                    for (int j = (loc & 63) + 1; j < 64; ++j) rec[j] = 0.f, rec[64 + j] = 0.f;
             } else {
                 p.delta[at] = acc;
             }
@@ -1843,7 +1849,7 @@ extern "C" int halva_sdpa_causal_bwd_ld(const void* qkv, const void* out, int64_
                                  scale, stream);
 }
 
-static int64_t lse2_region_bytes(int S, int T, int H) { return (((int64_t)S * H * T * 4 + 256) + 127) / 128 * 128; }
+static int64_t lse2_region_bytes(int S, int T, int H) { return (((int64_t)S * H * ((T + 63) / 64) * 512 + 256) + 127) / 128 * 128; }
 static int64_t ds_region_bytes(int S, int T, int H) { return (int64_t)S * H * ((T + 127) / 128) * ((T + 63) / 64) * 16384; }
 
 extern "C" int64_t halva_sdpa_bwd_ws_bytes(int S, int T, int H, int D) {
@@ -1899,6 +1905,7 @@ extern "C" int halva_sdpa_branch_bwd_ws(const void* qkv, const void* out, int64_
     p.sched = p.ds_ws ? reinterpret_cast<int*>(p.ds_ws + ds_region_bytes(S, T, H) + lse2_region_bytes(S, T, H)) : nullptr;
     p.ds_nkb = (T + 127) / 128;
     p.ds_nt = (T + 63) / 64;
+    p.stat_nt = (T + 63) / 64;
     p.scale = scale > 0.f ? scale : 1.f / sqrtf((float)D);
     return D == 128 ? launch_bwd<128, true>(p, S, (hipStream_t)stream) : launch_bwd<64, true>(p, S, (hipStream_t)stream);
 }

@@ -24,9 +24,8 @@
 constexpr int DKV3_TILE = 64 * 128 * 2;                      // one Q or dO tile
 constexpr int DKV3_DO = 4 * DKV3_TILE;                       // dO ring behind the Q ring
 constexpr int DKV3_LSE = 8 * DKV3_TILE;                      // [4][64] lse2, then [4][64] -delta
-constexpr int DKV3_ND = DKV3_LSE + 4 * 64 * 4;
-constexpr int DKV3_DUMMY = DKV3_ND + 4 * 64 * 4;              // 1 KiB: where the requests of the last steps of a block (no tile left) land
-constexpr int DKV3_SCHED = DKV3_DUMMY + 1024;                // [2][8] ints: the persistent workgroup's item mail box
+constexpr int DKV3_ND = DKV3_LSE + 4 * 64 * 4;              // (the plain-HIP twin's own layout; the generated loop: four 1-KiB slots [lse2 x 64][-delta x 64][unused])
+constexpr int DKV3_SCHED = DKV3_LSE + 4096;                  // [2][8] ints: the persistent workgroup's item mail box
 constexpr int DKV3_LDS = DKV3_SCHED + 64;
 
 __device__ __forceinline__ unsigned dkv3_uni(unsigned x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -144,8 +143,7 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_block_hip(const SdpaParams& p, cha
     const bf16_t* qp = p.q + hd * D;
     const bf16_t* dop = p.d_o + hd * D;
     const int64_t qrow0 = seq_row0 + start;
-    const float* lse2_g = p.lse2 + ((int64_t)s * p.H + hd) * p.T + start;
-    const float* nd_g = p.delta + ((int64_t)s * p.H + hd) * p.T + start;
+    const float* stat_g = p.lse2 + ((int64_t)s * p.H + hd) * p.stat_nt * 128;      // [step][lse2 x 64 | -delta x 64], sequence coordinates
     char* q_lds = smem;
     char* do_lds = smem + DKV3_DO;
     float* lse_lds = reinterpret_cast<float*>(smem + DKV3_LSE);
@@ -160,8 +158,8 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_block_hip(const SdpaParams& p, cha
     };
     auto load_stats = [&](int i, float& a, float& b) {
         const int ql = min(q_begin + i * BQ + lane, len - 1);
-        a = lse2_g[ql];
-        b = nd_g[ql];
+        a = stat_g[(ql >> 6) * 128 + (ql & 63)];
+        b = stat_g[(ql >> 6) * 128 + 64 + (ql & 63)];
     };
     auto store_stats = [&](int i, float a, float b) {
         lse_lds[(i & 3) * 64 + lane] = a;
@@ -417,11 +415,12 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
             const bf16_t* qp = qp0 + hd * D;
             const bf16_t* dop = dop0 + hd * D;
             const int64_t qrow0 = seq_row0 + cur.start;
-            const float* lse2_g = p.lse2 + ((int64_t)s * p.H + hd) * p.T + cur.start;
-            const float* nd_g = p.delta + ((int64_t)s * p.H + hd) * p.T + cur.start;
+            // the statistics of this (sequence, head), 512 bytes per 64-row step in sequence coordinates (sdpa.hip:sdpa_bwd_delta_kernel), as a buffer
+            // descriptor: a step past the sequence brings zeros; lanes 32..63 of a request lie outside it on purpose (they fill the unused half of the slot)
+            const unsigned long long st_base = (unsigned long long)(size_t)(p.lse2 + ((int64_t)s * p.H + hd) * p.stat_nt * 128);
+            const unsigned st_rec = (unsigned)(((len + BQ - 1) / BQ) * 512);
+            const unsigned stat_voff = lane < 32 ? 16u * lane : 0x7ffffff0u;
             char* ds_block = p.ds_ws + ((((int64_t)s * p.H + hd) * p.ds_nkb + kb) * p.ds_nt + q_begin / BQ) * 16384 + wave * 4096;
-            // a partial last tile: its statistics rows are clamped to the sequence (its Q / dO rows past the end arrive as zeros: buffer descriptors)
-            const unsigned alt_stat = 4 * min(lane, cur.lr - 1);
             // the sequence's Q / dO rows of this head as buffer descriptors: base row, bytes up to the end of the last row
             const unsigned long long q_base = (unsigned long long)(size_t)(qp + qrow0 * p.ld_qkv), do_base = (unsigned long long)(size_t)(dop + qrow0 * p.ld_do);
             const unsigned q_rec = len > 0 ? (unsigned)((int64_t)(len - 1) * p.ld_qkv * 2 + D * 2) : 0u;
@@ -432,8 +431,8 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
             const unsigned nqrec = nxt.len > 0 ? (unsigned)((int64_t)(nxt.len - 1) * p.ld_qkv * 2 + D * 2) : 0u;
             const unsigned ndorec = nxt.len > 0 ? (unsigned)((int64_t)(nxt.len - 1) * p.ld_do * 2 + D * 2) : 0u;
             const unsigned nqsoff = (unsigned)((int64_t)nxt.q_begin * p.ld_qkv * 2), ndosoff = (unsigned)((int64_t)nxt.q_begin * p.ld_do * 2);
-            const unsigned long long nl_ptr = (unsigned long long)(size_t)(p.lse2 + ((int64_t)nxt.s * p.H + nxt.hd) * p.T + nxt.start + nxt.q_begin);
-            const unsigned long long nn_ptr = (unsigned long long)(size_t)(p.delta + ((int64_t)nxt.s * p.H + nxt.hd) * p.T + nxt.start + nxt.q_begin);
+            const unsigned long long nst_base = (unsigned long long)(size_t)(p.lse2 + ((int64_t)nxt.s * p.H + nxt.hd) * p.stat_nt * 128);
+            const unsigned nst_rec = (unsigned)(((nxt.len + BQ - 1) / BQ) * 512), nst_soff = (unsigned)(nxt.q_begin / BQ * 512);
             // (fixed accumulator registers, the same in every asm statement that touches them: no copies; the block zeroes them on its first call)
             f32x16 accV[4], accK[4];      // dV^T, dK^T (local to the item: carried from round to round they travelled through vector registers)
 #ifdef HALVA_STAMP

@@ -32,8 +32,7 @@
             const bool cold = t == 0 && !prefetched;
             const int tq = cold ? 0 : t + 3;
             const unsigned q_soff = (unsigned)((q_begin + (int64_t)tq * BQ) * p.ld_qkv * 2), do_soff = (unsigned)((q_begin + (int64_t)tq * BQ) * p.ld_do * 2);
-            const unsigned long long lse_ptr = (unsigned long long)(size_t)(lse2_g + q_begin + tq * BQ);
-            const unsigned long long nd_ptr = (unsigned long long)(size_t)(nd_g + q_begin + tq * BQ);
+            const unsigned st_soff = (unsigned)((q_begin / BQ + tq) * 512);      // the first step whose statistics this call requests (512 bytes per step)
             // the call's control word: first call of the block | tiles it requests itself | which of those is the partial last tile
             // | the run's last request is the partial last tile | ring slot of the first step's tile   (gen_dkv3_loop.py: CTL_*)
             const unsigned ctl_u = dkv3_uni((t == 0 ? 1u : 0u) | ((cold ? (unsigned)min(3, ntiles) : 0u) << 1) |
@@ -44,9 +43,6 @@
             const unsigned pf = (t_side == ntiles && n - ndma == 3) ? (unsigned)npro_next : 0u;
             requested_next = requested_next || pf != 0;
             const unsigned ndma_u = dkv3_uni((unsigned)ndma | (pf << 8));
-            // an always-valid source for the statistics requests of the steps with no tile left (they land in the dummy chunk): this pair's first
-            // statistics row (the lse2 region is padded by a row)
-            const unsigned long long safe_l = dkv3_uni64(p.lse2 + ((int64_t)s * p.H + hd) * p.T);
 #ifdef HALVA_STAMP
             if (t == 0) DKV3_NOW(t1_);
 #endif
@@ -60,15 +56,15 @@
                   [vq2] "{a[168:171]}"(vq[2]), [vq3] "{a[172:175]}"(vq[3]), [vq4] "{a[176:179]}"(vq[4]), [vq5] "{a[180:183]}"(vq[5]), [vq6] "{a[184:187]}"(vq[6]),
                   [vq7] "{a[188:191]}"(vq[7]), [rowrel] "v"(rowrel), [colrel] "v"(colrel), [statrel] "v"(statrel), [voff_q] "v"(voff_q), [voff_do] "v"(voff_do),
                   [sc] "s"(sc), [n02] "s"(n02_u), [n1] "s"(n1_u), [ndma] "s"(ndma_u), [wave] "s"(wave_u), [q_piece] "s"(q_piece), [do_piece] "s"(do_piece),
-                  [lo0] "v"(lo0), [range] "v"(range), [alt_stat] "v"(alt_stat),
-                  [safe_l] "s"(safe_l), [ctl] "s"(ctl_u),
+                  [lo0] "v"(lo0), [range] "v"(range), [stat_voff] "v"(stat_voff),
+                  [ctl] "s"(ctl_u),
                   // uniform 64-bit addresses as two vector registers each (the block reads them with v_readfirstlane: scalar operands are scarce)
                   [q_lo] "v"((unsigned)q_base), [q_hi] "v"((unsigned)(q_base >> 32)), [do_lo] "v"((unsigned)do_base), [do_hi] "v"((unsigned)(do_base >> 32)),
                   [q_rec] "v"(q_rec), [do_rec] "v"(do_rec), [q_soff] "v"(q_soff), [do_soff] "v"(do_soff), [nqrec] "v"(nqrec), [ndorec] "v"(ndorec), [nqsoff] "v"(nqsoff), [ndosoff] "v"(ndosoff),
-                  [lse_lo] "v"((unsigned)lse_ptr), [lse_hi] "v"((unsigned)(lse_ptr >> 32)), [nd_lo] "v"((unsigned)nd_ptr), [nd_hi] "v"((unsigned)(nd_ptr >> 32)),
+                  [st_lo] "v"((unsigned)st_base), [st_hi] "v"((unsigned)(st_base >> 32)), [st_rec] "v"(st_rec), [st_soff] "v"(st_soff),
                   [ds_lo] "v"((unsigned)ds_ptr), [ds_hi] "v"((unsigned)(ds_ptr >> 32)), [nq_lo] "v"((unsigned)nq_ptr), [nq_hi] "v"((unsigned)(nq_ptr >> 32)),
-                  [ndo_lo] "v"((unsigned)ndo_ptr), [ndo_hi] "v"((unsigned)(ndo_ptr >> 32)), [nlse_lo] "v"((unsigned)nl_ptr), [nlse_hi] "v"((unsigned)(nl_ptr >> 32)),
-                  [nnd_lo] "v"((unsigned)nn_ptr), [nnd_hi] "v"((unsigned)(nn_ptr >> 32))
+                  [ndo_lo] "v"((unsigned)ndo_ptr), [ndo_hi] "v"((unsigned)(ndo_ptr >> 32)),
+                  [nst_lo] "v"((unsigned)nst_base), [nst_hi] "v"((unsigned)(nst_base >> 32)), [nst_rec] "v"(nst_rec), [nst_soff] "v"(nst_soff)
                 :
 #include "sdpa_dkv3_loop_clobbers.inc"
             );
