@@ -26,7 +26,11 @@ constexpr int DKV3_DO = 4 * DKV3_TILE;                       // dO ring behind t
 constexpr int DKV3_LSE = 8 * DKV3_TILE;                      // [4][64] lse2, then [4][64] -delta
 constexpr int DKV3_ND = DKV3_LSE + 4 * 64 * 4;              // (the plain-HIP twin's own layout; the generated loop: four 1-KiB slots [lse2 x 64][-delta x 64][unused])
 constexpr int DKV3_SCHED = DKV3_LSE + 4096;                  // [2][8] ints: the persistent workgroup's item mail box
-constexpr int DKV3_LDS = DKV3_SCHED + 64;
+constexpr int DKV3_STAGE = DKV3_SCHED + 128;                 // [4 waves][4 KiB]: a wave's staging area for its dK / dV rows (dkv3_store_rows_lds)
+constexpr int DKV3_LDS = DKV3_STAGE + 4 * 4096;
+#ifndef DKV3_ROWS_VIA_LDS
+#define DKV3_ROWS_VIA_LDS 1      // 0: the dK / dV rows stored straight from the accumulator layout (store_rows_T), rounds 2-3
+#endif
 
 __device__ __forceinline__ unsigned dkv3_uni(unsigned x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ unsigned long long dkv3_uni64(const void* ptr) {
@@ -96,6 +100,41 @@ __device__ __forceinline__ unsigned dkv3_piece_voff(int64_t ld, int wave, int la
     const int row = 8 * band + ((rem % 512) >> 6);
     const int ch = 4 * (rem / 512) + (((rem >> 4) & 3) ^ ((row >> 2) & 3));
     return (unsigned)((min(row, nrows - 1) * ld + ch * 8) * 2);
+}
+
+// A wave's [128 x 32] transposed accumulator (lane = key row, registers = columns d: store_rows_T's layout) as bf16 rows, TRANSPOSED through 4 KiB of
+// LDS of the wave's own (round 4; the forward's tail does the same, gen_fwd3_loop.py:tail_code): two passes of 64 columns; a lane writes its eight
+// 8-byte pieces of the pass to [row][128 bytes] with the 16-byte chunk index XORed by (row >> 1) & 7, reads back 16 bytes of row 8 j + (lane >> 3),
+// chunk lane & 7, and every store instruction writes eight whole 128-byte row pieces - instead of 16 bytes into each of 32 rows, which the CU's address
+// unit takes a lane at a time (rows converted and stored: 5 180 cycles per item, profiles/r04_dkv3_anatomy.log).  row0: the wave's first row; rows_ok:
+// how many of its 32 rows exist in the tensor.  mul: per KEY lane (0 for a key outside the sequence).
+__device__ __forceinline__ void dkv3_store_rows_lds(char* smem, int wave, bf16_t* row0, int64_t ld, const f32x16 (&acc)[4], float mul, int rows_ok, int lane) {
+    typedef __attribute__((address_space(3))) char lchar;
+    lchar* stage = (lchar*)(smem + DKV3_STAGE + wave * 4096);
+    const int r = lane & 31, h = lane >> 5;
+    lchar* wr = stage + r * 128 + 8 * h;
+    const int wmask = ((r >> 1) & 7) << 4;
+    const int rr = lane >> 3, rc = lane & 7;      // read side: row 8 j + rr, chunk rc
+    // (row 8 j + rr: (row >> 1) & 7 = ((rr >> 1) + 4 j) & 7 = (rr >> 1) ^ 4 for odd j)
+    lchar* rd[2] = {stage + rr * 128 + ((rc ^ ((rr >> 1) & 7)) << 4), stage + rr * 128 + ((rc ^ ((rr >> 1) & 7) ^ 4) << 4)};
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int dtl = 0; dtl < 2; ++dtl)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dt = 2 * pass + dtl;
+                u32x2 w;
+                w[0] = pack_bf16x2(acc[dt][4 * g + 0] * mul, acc[dt][4 * g + 1] * mul);
+                w[1] = pack_bf16x2(acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
+                *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(wr + (((4 * dtl + g) << 4) ^ wmask)) = w;
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32x4 v = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(rd[j & 1] + 1024 * j);
+            if (8 * j + rr < rows_ok) *reinterpret_cast<u32x4*>(row0 + (int64_t)(8 * j + rr) * ld + 64 * pass + 8 * rc) = v;
+        }
+    }
 }
 
 // One key block in plain HIP (HALVA_DKV3_ASM=0: the readable twin of the generated loop, with the same ring protocol; every item starts cold)
@@ -463,7 +502,13 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
             asm volatile("" : "+v"(gk_st));
             bf16_t* dk_row = p.dk + (seq_row0 + gk_st) * p.ld_qkv + hd * D;
             bf16_t* dv_row = p.dv + (seq_row0 + gk_st) * p.ld_qkv + hd * D;
-            if (k_in_T) {
+            if (DKV3_ROWS_VIA_LDS) {      // (rows of the wave in the tensor: uniform)
+                const int wrow0 = kb * 128 + 32 * wave;
+                const int rows_ok = min(32, max(0, p.T - wrow0));
+                bf16_t* w0 = p.dk + (seq_row0 + wrow0) * p.ld_qkv + hd * D;
+                dkv3_store_rows_lds(smem, wave, w0 + (p.dv - p.dk), p.ld_qkv, accV, k_valid ? 1.f : 0.f, rows_ok, lane);
+                dkv3_store_rows_lds(smem, wave, w0, p.ld_qkv, accK, k_valid ? p.scale : 0.f, rows_ok, lane);
+            } else if (k_in_T) {
                 store_rows_T<D>(dv_row, accV, k_valid ? 1.f : 0.f, true, lane);
                 store_rows_T<D>(dk_row, accK, k_valid ? p.scale : 0.f, true, lane);
             }
