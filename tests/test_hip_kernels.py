@@ -569,6 +569,25 @@ def test_wgrad_accumulate_matches_fp32_reference(rows, M, N, lda, ldb):
     assert float((out[0].double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())) * max(1, rows // 2000)
 
 
+@pytest.mark.parametrize("rows,M,N,lda,ldb", [(27424, 384, 4096, 4480, 4480), (3001, 128, 11008, 11136, 11136), (2000, 4096, 128, 12288, 4480)])
+def test_wgrad_lds_dma_kernel_gives_the_register_staged_kernels_bits(rows, M, N, lda, ldb, monkeypatch):
+    """halva_wgrad_accumulate's operand tiles arrive by LDS-DMA (wgrad_dma_kernel, M and N multiples of 128); HALVA_WGRAD_DMA=0 is the
+    register-staged gemm_kernel<true, true> of rounds 2-3.  Same slabs, same MFMA order inside a slab: the same bits - including a k-slab
+    that ends inside a 64-row tile (rows past it arrive as zeros through the bounds-checked descriptor)."""
+    g = torch.Generator().manual_seed(6)
+    abuf = bf(torch.randn(rows, lda, generator=g)).to(DEV)
+    bbuf = bf(torch.randn(rows, ldb, generator=g)).to(DEV)
+    A, B = abuf[:, lda - M:], bbuf[:, :N]
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HALVA_WGRAD_DMA", mode)
+        C = torch.zeros(M, N, device=DEV)
+        K().wgrad_accumulate(C, A, B, 1.0)
+        torch.cuda.synchronize()
+        out[mode] = C
+    assert torch.equal(out["1"], out["0"])
+
+
 def test_clip_tower_features_match_reference():
     """CLIPVisionTower.forward of the reference (clip_encoder.py:37-56 around HF CLIPVisionModel: patch conv, class token +
     position embeddings, pre-LN, pre-norm blocks with quick_gelu, hidden_states[-2], CLS row dropped) and encode_images
