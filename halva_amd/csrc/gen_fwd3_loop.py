@@ -52,7 +52,7 @@ LSUM = os.environ.get("FWD3_LSUM", "add")
 # point numbers, only their common exponent moves.  FWD3_TRACK_MAX=1 puts the v_max3 back (timing experiments; the value is unused).
 TRACK_MAX = os.environ.get("FWD3_TRACK_MAX", "0") == "1"
 WAIT_AGE = int(os.environ.get("FWD3_WAIT_AGE", "4"))      # 0: one wait per first use
-REDO_LIMIT, REDO_STEP = 0x71800000, 0x42f00000      # 2^100, 120.0
+REDO_LIMIT, REDO_STEP, MAX_REDO = 0x71800000, 0x42f00000, 8      # 2^100, 120.0, repeats at most (8 x 120 log2 units = scores 660 nats above the row's first keys)
 XS = {(0, 0): 64, (0, 1): 80, (1, 0): 96, (1, 1): 112}      # score tiles [group][key half]: 16 registers each
 PB = {(0, 0): 128, (0, 1): 136, (1, 0): 144, (1, 1): 152}   # packed P: 8 registers each
 L2, MX, MREF, RANGE = {0: 160, 1: 164}, {0: 168, 1: 169}, {0: 170, 1: 171}, {0: 172, 1: 173}
@@ -514,7 +514,8 @@ def emit(out):
           "v_readfirstlane_b32 s%d, %%[k_lo]" % DESC0[0], "v_readfirstlane_b32 s%d, %%[k_hi]" % (DESC0[0] + 1), "v_readfirstlane_b32 s%d, %%[nrec]" % (DESC0[0] + 2),
           "s_mov_b32 s%d, 0x00020000" % (DESC0[0] + 3), "v_readfirstlane_b32 %s, %%[soff0]" % S_SOFF0,
           "s_bfe_u32 %s, %%[ctl], 0x10004" % S_PF, "s_mov_b32 %s, 0" % S_REDO]
-    # ---------------- one pass over the item (re-entered once, with S_REDO = 1, when a row maximum outgrew its reference)
+    # ---------------- one pass over the item (re-entered, S_REDO counting the repeats, when a row sum shows that P overflowed: at most MAX_REDO times -
+    # inputs with NaN / inf scores would repeat for ever; they end with the NaN / inf they ask for instead)
     L += [".Lf3_pass_%=:", "s_mov_b64 s[%d:%d], s[%d:%d]" % (DESC[0], DESC[0] + 1, DESC0[0], DESC0[0] + 1), "s_mov_b64 s[%d:%d], s[%d:%d]" % (DESC[0] + 2, DESC[0] + 3, DESC0[0] + 2, DESC0[0] + 3),
           "s_mov_b32 %s, %s" % (S_SOFFK, S_SOFF0),
           "s_and_b32 %s, %%[ctl], 3" % S_T,                                   # ring slot of tile 0
@@ -565,7 +566,7 @@ def emit(out):
           "s_cmp_eq_u32 %s, 2" % S_TMP, "s_cbranch_scc0 .Lf3_rsp2_%=", "v_mov_b32_e32 v%d, %%[rsB0]" % RANGE[0], "v_mov_b32_e32 v%d, %%[rsB1]" % RANGE[1], ".Lf3_rsp2_%=:"]
     for g in (0, 1):
         L += [i.text for i in mask_ops(g, 0, RANGE[g])]
-    L += ["s_cmp_eq_u32 %s, 1" % S_REDO, "s_cbranch_scc1 .Lf3_mrdone_%="]      # (the repeat: the reference is the measured row maximum)
+    L += ["s_cmp_lg_u32 %s, 0" % S_REDO, "s_cbranch_scc1 .Lf3_mrdone_%="]      # (a repeat: the references are the first pass's, some of them raised)
     for g, t in ((0, V_T0), (1, V_T1)):
         x = XS[(g, 0)]
         L += ["v_max3_f32 v%d, v%d, v%d, v%d" % (t, x, x + 1, V_NINF)] + ["v_max3_f32 v%d, v%d, v%d, v%d" % (t, x + 2 * i, x + 2 * i + 1, t) for i in range(1, 8)]
@@ -601,6 +602,7 @@ def emit(out):
     T = (V_T0, V_T1)
     R0, R1, R2 = RING, RING + 1, RING + 2
     FLAG = (SRC, (82, 83))      # which lanes repeat, per group (s[82:83] = S_SEG / S_FLD: loop-only)
+    L += ["s_cmp_ge_u32 %s, %d" % (S_REDO, MAX_REDO), "s_cbranch_scc1 .Lf3_exit_%="]      # (uniform over the workgroup: every wave has counted the same repeats)
     for g in (0, 1):
         L += ["v_max3_f32 v%d, v%d, v%d, v%d" % (T[g], L2[g], L2[g] + 1, L2[g] + 2), "v_max_f32_e32 v%d, v%d, v%d" % (T[g], T[g], L2[g] + 3),
               "v_mov_b32_e32 v%d, v%d" % (R0, T[g]), "s_nop 1", "v_permlane32_swap_b32_e32 v%d, v%d" % (T[g], R0), "s_nop 1",
@@ -618,7 +620,7 @@ def emit(out):
     # have landed before the next pass requests into the same slots
     for g in (0, 1):
         L += ["s_mov_b64 vcc, %s" % sp(FLAG[g]), "v_add_f32_e32 v%d, 0x%08x, v%d" % (T[g], REDO_STEP, MREF[g]), "v_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (MREF[g], MREF[g], T[g])]
-    L += ["s_mov_b32 %s, 1" % S_REDO, "s_mov_b32 %s, 0" % S_PF, "s_waitcnt vmcnt(0)", "s_branch .Lf3_pass_%="]
+    L += ["s_add_u32 %s, %s, 1" % (S_REDO, S_REDO), "s_mov_b32 %s, 0" % S_PF, "s_waitcnt vmcnt(0)", "s_branch .Lf3_pass_%="]
     # ---------------- way out.  Every wave has passed the vote's barrier: the ring slot of the item's last tile is free (the other three hold the next
     # item's first tiles).  Per row group g: [the NEXT item's Q rows of the group requested by LDS-DMA into this wave's 8 KiB of that slot - whole
     # 1-KiB pieces through a descriptor over the next sequence's Q rows, rows outside it arrive as zeros] [this item's rows of the group: O = O^T / l,

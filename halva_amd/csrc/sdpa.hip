@@ -1614,6 +1614,7 @@ __global__ __launch_bounds__(512) void sdpa_bwd_dq2_kernel(const SdpaParams p) {
 
 #include "sdpa_dkv3.h"
 #include "sdpa_fwd3.h"
+#include "sdpa_fwd3_twin.h"
 
 // HALVA_SDPA_DKV3=0: the two-role dK/dV kernel of rounds 1-2 instead of sdpa_bwd_dkv3; HALVA_DKV3_ASM=0: sdpa_bwd_dkv3 with every step in
 // plain HIP (the generated loop off) - A/B and debugging switches, read on every call like the one below.
@@ -1690,6 +1691,14 @@ int launch_fwd3(SdpaParams p, int S, hipStream_t st) {
     {
         const char* e = getenv("HALVA_FWD3_GRID");      // diagnostic: workgroups of the persistent launch (0 = one per virtual block: no pipelining across items)
         if (e) cus = atoi(e) > 0 ? atoi(e) : (1 << 30);
+    }
+    {
+        const char* e = getenv("HALVA_FWD3_ASM");      // 0: the plain-HIP twin of the generated block (sdpa_fwd3_twin.h; one workgroup per row block)
+        if (e && e[0] == '0') {
+            hipLaunchKernelGGL((sdpa_fwd3_twin_kernel<true>), dim3((unsigned)((int64_t)p.nblk * p.npairs)), dim3(256), 0, st, p);
+            HALVA_CHECK_LAUNCH("sdpa_fwd3_twin");
+            return HALVA_OK;
+        }
     }
     const int64_t total = (int64_t)((p.nblk + 1) / 2) * p.npairs;
     hipLaunchKernelGGL((sdpa_fwd3_kernel<true>), dim3((unsigned)std::min<int64_t>(total, cus)), dim3(256), FWD3_LDS, st, p);

@@ -170,3 +170,50 @@ def test_dkv3_plain_hip_twin_matches_the_generated_loop():
     hip = _bwd_bits(S, T, H, D, lens, starts, br, 9, {"HALVA_DKV3_ASM": "0"})
     assert torch.isfinite(asm).all()
     assert torch.equal(asm, hip)
+
+
+@pytest.mark.parametrize("case", ["packed_ragged", "left_padded", "plain_2048", "repeat"])
+def test_fwd3_plain_hip_twin_matches_the_generated_loop(case, monkeypatch):
+    """HALVA_FWD3_ASM=0 runs the causal forward as sdpa_fwd3_twin_kernel (csrc/sdpa_fwd3_twin.h): the readable statement of what the generated
+    block computes - the fixed exponent reference per row block, P = exp2(fma(S, sc, -m_ref)), four partial row sums per lane, the vote on them
+    and the repeat with raised references, O / l - with none of its machinery (tile ring, LDS, persistence, masks as visible-key counts).  Same
+    MFMAs on the same operand slots in the same order, same fp32 operations: the outputs and the log-sum-exp agree to the last bit.
+    Cases: packed rows cut by branch points with ragged lengths (blocks wholly inside branch B: the walk's jump); left padding; the layer
+    shape; scores that outgrow the reference (the repeat path: one and two repeats)."""
+    import math
+    D = 128
+    g = torch.Generator().manual_seed(17)
+    br = None
+    if case == "packed_ragged":
+        S, T, H, lens, starts, br = 2, 1216, 3, [1216, 1100], [0, 0], ([300, 290], [768, 704])
+    elif case == "left_padded":
+        S, T, H, lens, starts = 3, 640, 2, [640, 333, 70], [0, 64, 500]
+    elif case == "plain_2048":
+        S, T, H, lens, starts = 1, 2048, 2, [2048], [0]
+    else:
+        S, T, H, lens, starts = 1, 256, 2, [256], [0]
+    qkv = bf(torch.randn(S, T, 3, H, D, generator=g))
+    if case == "repeat":      # keys whose scores grow by ~50, ~130, ~325 log2 units from tile to tile (test_sdpa_exponent_reference_moves_...)
+        u = torch.randn(H, D, generator=g)
+        u = u / u.norm(dim=-1, keepdim=True) * math.sqrt(D)
+        c = torch.tensor([0.1, 3.0, 8.0, 20.0]).repeat_interleave(64) * (11.3 / math.sqrt(D))
+        qkv[0, :, 0] = bf(u[None] + 0.05 * torch.randn(T, H, D, generator=g))
+        qkv[0, :, 1] = bf(c[:, None, None] * (u[None] + 0.3 * torch.randn(T, H, D, generator=g)))
+    mk = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HALVA_FWD3_ASM", mode)
+        from halva_amd.hip import call, ptr, stream_ptr      # (through the C ABI: the log-sum-exp is an output of its own)
+        x = qkv.to(DEV).view(S, T, 3 * H * D).clone()
+        o = torch.full((S, T, H * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+        lse = torch.full((S, H, T), float("nan"), dtype=torch.float32, device=DEV)
+        a_, b_ = (mk(br[0]), mk(br[1])) if br else (None, None)
+        st_, ln_ = mk(starts), mk(lens)      # (kept alive across the call: a temporary's memory is handed to the next allocation)
+        call("halva_sdpa_branch_fwd", ptr(x), ptr(o), H * D, ptr(lse), ptr(st_), ptr(ln_), ptr(a_), ptr(b_), S, T, H, D, 0.0, stream_ptr())
+        torch.cuda.synchronize()
+        out[mode] = (o.float().cpu(), lse.cpu())
+    assert torch.isfinite(out["1"][0]).all() and torch.isfinite(out["1"][1]).all()      # (every row of the tensor is written: the buffers started as NaN)
+    # equal as VALUES everywhere (a padded row's zeros may differ in sign: 0 * a negative sum), i.e. the same bits wherever the value is not zero
+    assert torch.equal(out["1"][0], out["0"][0]) and torch.equal(out["1"][1], out["0"][1])
+    for s in range(S):
+        assert float(out["1"][0][s, starts[s]:starts[s] + lens[s]].abs().min()) > 0      # the sequences' own rows hold no zeros: bit for bit there
