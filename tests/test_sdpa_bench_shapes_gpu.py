@@ -217,3 +217,23 @@ def test_fwd3_plain_hip_twin_matches_the_generated_loop(case, monkeypatch):
     assert torch.equal(out["1"][0], out["0"][0]) and torch.equal(out["1"][1], out["0"][1])
     for s in range(S):
         assert float(out["1"][0][s, starts[s]:starts[s] + lens[s]].abs().min()) > 0      # the sequences' own rows hold no zeros: bit for bit there
+
+
+@pytest.mark.timeout(120)
+def test_forward_with_nan_and_inf_inputs_terminates():
+    """A row block whose row sums are not finite is repeated with raised exponent references - at most 8 times (gen_fwd3_loop.py: MAX_REDO): NaN or
+    inf in q / k (a diverged run) must come out as NaN rows, not as a kernel that repeats for ever; the other sequences are untouched."""
+    S, T, H, D = 2, 512, 2, 128
+    g = torch.Generator().manual_seed(23)
+    qkv = bf(torch.randn(S, T, 3, H, D, generator=g))
+    clean = qkv.clone()
+    qkv[0, 100, 1, 0, 5] = float("nan")      # one NaN in a key row of (sequence 0, head 0)
+    qkv[0, 300, 0, 1, 7] = float("inf")      # one inf in a query row of (sequence 0, head 1)
+    mk = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    ss, sl = mk([0, 0]), mk([T, T])
+    with torch.no_grad():
+        o = K().sdpa_causal(qkv.to(DEV).view(S, T, 3 * H * D), ss, sl, H, D).view(S, T, H, D).float().cpu()
+        oc = K().sdpa_causal(clean.to(DEV).view(S, T, 3 * H * D), ss, sl, H, D).view(S, T, H, D).float().cpu()
+    torch.cuda.synchronize()
+    assert not torch.isfinite(o[0, 100:, 0]).all() and not torch.isfinite(o[0, 300, 1]).all()
+    assert torch.equal(o[1], oc[1]) and torch.equal(o[0, :100, 0], oc[0, :100, 0])      # rows that cannot see the bad values are the clean run's
