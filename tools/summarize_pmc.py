@@ -22,5 +22,9 @@ for k, c in acc.items():
         if "SQ_ACTIVE_INST_LDS" in c: der["lds_inst_active_frac(quad-cycles/CU)"] = c["SQ_ACTIVE_INST_LDS"] * 4 / 256 / cyc
         if "SQ_LDS_BANK_CONFLICT" in c: der["lds_bank_conflict_cycles_per_cu_frac"] = c["SQ_LDS_BANK_CONFLICT"] / 256 / cyc
         if "SQ_LDS_IDX_ACTIVE" in c: der["lds_idx_active_frac"] = c["SQ_LDS_IDX_ACTIVE"] / 256 / cyc
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
+        der["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    if "TCC_EA0_RDREQ_sum" in c:      # read requests that leave the L2 for the fabric: 64-byte ones unless counted as 32-byte
+        der["l2_to_fabric_read_bytes"] = 64.0 * (c["TCC_EA0_RDREQ_sum"] - c.get("TCC_EA0_RDREQ_32B_sum", 0.0)) + 32.0 * c.get("TCC_EA0_RDREQ_32B_sum", 0.0)
     acc[k] = {"derived": der, "raw_per_launch": c}
 print(json.dumps(acc, indent=1))
