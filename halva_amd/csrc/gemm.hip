@@ -188,17 +188,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 //   * two stages (64 KiB: two workgroups per CU): iteration t waits for its own requests of tile t, barrier (tile t complete for everyone; everyone
 //     has finished tile t - 1), requests tile t + 1 into the other stage, multiplies tile t.
 // Same arithmetic and summation order inside a slab as gemm_kernel<true, true>: bitwise the same partials.
+// KT = 64: two stages, one tile in flight per workgroup while it multiplies.  KT = 32: FOUR stages of half the height - tile t + 3 is requested
+// when tile t has landed, so three tiles (48 KiB per workgroup) stay in flight all the time, at twice the barriers (HALVA_WGRAD_KT=32).
+template <int KT>
 __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const GemmParams p) {
-    constexpr int TILE = 128 * 64 * 2;
+    constexpr int TILE = 128 * KT * 2, NST = 128 / KT, PPW = KT / 16;      // bytes of an operand tile; stages; 1-KiB pieces per wave and operand
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* a_lds = smem;               // [2][TILE]
-    char* b_lds = smem + 2 * TILE;    // [2][TILE]
+    char* a_lds = smem;                 // [NST][TILE]
+    char* b_lds = smem + NST * TILE;    // [NST][TILE]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
     const int64_t kb = (int64_t)blockIdx.z * p.ksplit;
     const int K = (int)min((int64_t)p.ksplit, p.K - kb);
-    const int nk = (K + 63) / 64;
+    const int nk = (K + KT - 1) / KT;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -223,9 +226,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const GemmParams p) {
     const unsigned lds_a = (unsigned)(size_t)(__attribute__((address_space(3))) char*)a_lds, lds_b = (unsigned)(size_t)(__attribute__((address_space(3))) char*)b_lds;
     auto request = [&](int it, int stage) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < PPW; ++i) {
             const int piece = wave + 4 * i;
-            const unsigned sa = (unsigned)(((int64_t)it * 64 + 4 * piece) * p.lda * 2), sb = (unsigned)(((int64_t)it * 64 + 4 * piece) * p.ldb * 2);
+            const unsigned sa = (unsigned)(((int64_t)it * KT + 4 * piece) * p.lda * 2), sb = (unsigned)(((int64_t)it * KT + 4 * piece) * p.ldb * 2);
             const unsigned dst_a = lds_a + stage * TILE + piece * 1024, dst_b = lds_b + stage * TILE + piece * 1024;
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %7 offen lds\n\t"
@@ -233,15 +236,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const GemmParams p) {
                          : "=&s"(keep) : "v"(voa), "v"(vob), "s"(da), "s"(db), "s"(dst_a), "s"(dst_b), "s"(sa), "s"(sb) : "memory");
         }
     };
-    request(0, 0);
+    // NST - 1 tiles ahead (every wave issues 2 PPW requests per tile, whether the tile exists or not: rows past the slab bring zeros and the
+    // counted wait stays the same to the end)
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) request(t, t);
 #pragma unroll 1
     for (int it = 0; it < nk; ++it) {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // tile `it` is complete for every wave; every wave is through with tile it - 1
-        if (it + 1 < nk) request(it + 1, (it + 1) & 1);
-        const char* at = a_lds + (it & 1) * TILE;
-        const char* bt = b_lds + (it & 1) * TILE;
+        // tile `it` is complete for every wave (the NST - 2 younger tiles may stay in flight); every wave is through with tile it - 1
+        if (NST == 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");      // (NST = 4: 2 tiles x 4 requests)
+        request(it + NST - 1, (it + NST - 1) % NST);
+        const char* at = a_lds + (it % NST) * TILE;
+        const char* bt = b_lds + (it % NST) * TILE;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < KT / 16; ++ks) {
             s16x8 af[2], bf[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) af[i] = Operand<true>::frag(at, 64 * wm + 32 * i, ks, lane);
@@ -255,6 +263,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const GemmParams p) {
                                                                        __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the requests past the slab's end)
     float* cz = (float*)p.C + (int64_t)blockIdx.z * p.M * p.ldc;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -394,8 +403,14 @@ extern "C" int halva_wgrad_accumulate(const void* A, int64_t lda, const void* B,
     if (!(e_dma && e_dma[0] == '0') && M % 128 == 0 && N % 128 == 0 && slab_bytes < (1ll << 31)) {
         const dim3 grid(N / 128, M / 128, splits);
         const size_t lds = 4 * 128 * 64 * 2;
-        (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(wgrad_dma_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
+        const char* e_kt = getenv("HALVA_WGRAD_KT");
+        if (e_kt && atoi(e_kt) == 32) {
+            (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(wgrad_dma_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, p);
+        } else {
+            (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(wgrad_dma_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, p);
+        }
         HALVA_CHECK_LAUNCH("wgrad_dma");
     } else {
         const int rc = launch_gemm<true, true>(p, (hipStream_t)stream);
