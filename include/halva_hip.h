@@ -120,10 +120,11 @@ int halva_sdpa_branch_bwd(const void* qkv, const void* out, int64_t ld_out, cons
  * (query, key) tile pair instead of the seven of the split backward above (S and dP are otherwise formed in both kernels).  Same
  * results to bf16 rounding of dS (which the split backward applies as well before its dQ/dK products); bitwise reproducible.
  * ds_ws == NULL: identical to halva_sdpa_branch_bwd.  The workspace holds no state between calls.
- * Since round 3 the workspace also carries, behind the dS region, [S, H, T] f32 of lse * log2(e) (+ one padding row) that the delta pass
- * writes for the dK/dV kernel, and delta_ws then receives -delta: the dK/dV kernel of this path (sdpa_bwd_dkv3, one wave per SIMD, its
- * steps in generated inline-asm blocks - halva_amd/csrc/sdpa_dkv3.h) fetches both as plain rows by LDS-DMA and starts its dP chain
- * from -delta; and 1 KiB of work-queue counters (zeroed by the delta pass of each call): that kernel runs as one persistent workgroup per
+ * Behind the dS region the workspace also carries the row statistics of the dK/dV kernel of this path (sdpa_bwd_dkv3, one wave per SIMD, its
+ * steps in generated inline-asm blocks - halva_amd/csrc/sdpa_dkv3.h), written by the delta pass: per (sequence, head) ceil(T / 64) records
+ * of 512 bytes, one per 64-row step in sequence coordinates, [lse * log2(e) x 64][-delta x 64] f32 (round 4; round 3 kept two [S, H, T]
+ * arrays and wrote -delta to delta_ws, which this path now leaves untouched) - one LDS-DMA request per step fetches both, the dP chain
+ * starts from -delta; and 1 KiB of work-queue counters (zeroed by the delta pass of each call): that kernel runs as one persistent workgroup per
  * CU drawing (sequence, head, key block) items from a queue per XCD.  The workspace still holds no state between calls, but one workspace
  * serves ONE call at a time.  HALVA_SDPA_DKV3=0 selects the two-role kernel of rounds 1-2 instead (same results up to bf16 rounding of P
  * before dZ). */
