@@ -37,6 +37,9 @@ import sys
 LOOKAHEAD, CAP, CAP_MASKED = 6, 5, 9
 WAIT_AGE = int(os.environ.get("DKV3_WAIT_AGE", "4"))      # 0: one wait per first use (rounds 2-3)
 CARRY_K = 4
+# cache policy of the dS stores: " nt" (rounds 2-4: written once, read once) or "" (experiments/ds_residency: does the Infinity Cache keep them
+# for a consumer that follows closely?)
+DS_STORE_POLICY = {"nt": " nt", "plain": "", "sc1": " sc1"}[os.environ.get("DKV3_DS_POLICY", "nt")]
 X = [64, 96]; Y = [80, 112]; PB = [128, 144]; ZB = [136, 152]; SL = 160; RING = 176
 QRE, QRO, DRE, DRO, QC0, QC1, DC0, DC1, STAT, DSOFF, LANE4, LANE, V_LO, V_T, V_NINF = 208, 209, 210, 211, 212, 213, 214, 215, 216, 217, 218, 219, 220, 221, 222
 S_SLOT, S_CNT, S_DMALEFT, S_TOFF, S_TMP, S_TMP2 = "s72", "s73", "s74", "s75", "s80", "s81"
@@ -259,7 +262,7 @@ def build_body():
         g0 = last_gap_writing(regs(ZB[sub], 8)) + 1
         for half in (0, 1):
             assert g0 + half < WAIT_GAP           # (the vmcnt arithmetic assumes the step's stores are issued in front of its wait)
-            gaps[g0 + half].append(Ins("global_store_dwordx4 v%d, %s, %s offset:%d nt" % (DSOFF, vr(ZB[sub] + 4 * half, 4), sp(DSP), 2048 * sub + 1024 * half),
+            gaps[g0 + half].append(Ins("global_store_dwordx4 v%d, %s, %s offset:%d%s" % (DSOFF, vr(ZB[sub] + 4 * half, 4), sp(DSP), 2048 * sub + 1024 * half, DS_STORE_POLICY),
                                        "vmem", reads=regs(ZB[sub] + 4 * half, 4) + ["v%d" % DSOFF]))
     dma, ool = dma_groups()
     # gap WAIT_GAP (behind the reads of MFMA 63): tile t+1 has landed for every wave; move on to its slot

@@ -1469,6 +1469,9 @@ __device__ __forceinline__ int ds_piece_off(int key, int qgroup) {      // byte 
 // factor of two by an XOR of the chunk position, applied by the LDS-DMA lanes (lane l fetches chunk l ^ swizzle; LDS-DMA writes lane l to
 // byte 16 l) - zero conflicts, but the requests no longer ask for their 1 KiB in lane order and the kernel, which is HBM-bound, ran 1.6 % SLOWER
 // (950-959 -> 971-973 us at the step's shapes, same box).
+#ifndef HALVA_DQ2_DS_POLICY
+#define HALVA_DQ2_DS_POLICY " nt"      // (experiments/ds_residency builds it with "" as well)
+#endif
 constexpr int DS_LDS_PIECE = 1024 + 128, DS_LDS_STRIP = 2 * DS_LDS_PIECE, DS_LDS_SLOT = 2 * DS_LDS_STRIP;
 __device__ __forceinline__ int ds_lds_off(int key, int qgroup) {      // (inside a strip)
     return DS_LDS_PIECE * (qgroup >> 2) + 16 * (key + 32 * (qgroup & 1)) + 8 * ((qgroup >> 1) & 1);
@@ -1524,7 +1527,7 @@ __device__ __forceinline__ void sdpa_bwd_dq2_block(const SdpaParams& p, char* sm
                 const char* rows = src + (c >> 1) * 4096 + (c & 1) * 1024;
                 unsigned keep;
                 // nt: these bytes are read once, by this CU only - they must not evict the K tiles the XCD's workgroups share in L2
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3" HALVA_DQ2_DS_POLICY "\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rows) : "memory");
             }
         }
@@ -1782,6 +1785,19 @@ int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st) {
             rc2 = slow ? launch_one(sdpa_bwd_dkv2_kernel<D, CAUSAL, true>, p, CAUSAL, 128, 512, lds_dkv, S, st, "sdpa_bwd_dkv2")
                        : launch_one(sdpa_bwd_dkv2_kernel<D, CAUSAL, false>, p, CAUSAL, 128, 512, lds_dkv, S, st, "sdpa_bwd_dkv2");
         if (rc2 != HALVA_OK) return rc2;
+#ifdef HALVA_DS_EVICT_EXP      // experiments/ds_residency only: push the dS just written out of the Infinity Cache before the dQ kernel reads it
+        if (const char* ev = getenv("HALVA_DS_EVICT_MB")) {
+            static char* scratch = nullptr;
+            static size_t scratch_bytes = 0;
+            const size_t want = (size_t)atoll(ev) << 20;
+            if (want > scratch_bytes) {
+                if (scratch) (void)hipFree(scratch);
+                (void)hipMalloc(&scratch, want);
+                scratch_bytes = want;
+            }
+            if (want) (void)hipMemsetAsync(scratch, 0, want, st);
+        }
+#endif
         const size_t lds_dq2 = 3 * 64 * D * 2 + 8 * 3 * DS_LDS_SLOT;
         return slow ? launch_one(sdpa_bwd_dq2_kernel<D, true>, p, true, 256, 512, lds_dq2, S, st, "sdpa_bwd_dq2")
                     : launch_one(sdpa_bwd_dq2_kernel<D, false>, p, true, 256, 512, lds_dq2, S, st, "sdpa_bwd_dq2");
