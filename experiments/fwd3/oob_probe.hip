@@ -24,7 +24,7 @@ __global__ void probe(const unsigned* src, unsigned* out, unsigned num_records, 
 }
 
 int main() {
-    const int n = 1 << 16;
+    const int n = 1 << 16;      // (256 KiB: soffset 1024 + 3 * 16384 still lies inside the allocation - a missing check would show as loaded data, not a fault)
     std::vector<unsigned> h(n);
     for (int i = 0; i < n; ++i) h[i] = i;      // dword i holds i
     unsigned *src, *out;
@@ -36,6 +36,10 @@ int main() {
         {1024 + 512, 1024, 16, "num_records = 1536 B, soffset 1024: lanes 32..63 beyond it ONLY if the scalar offset counts"},
         {1024, 1024, 16, "num_records = 1024 B, soffset 1024: every lane beyond it if the scalar offset counts"},
         {40 * 16 + 8, 0, 16, "num_records = 648 B: lane 40 straddles (its first 8 bytes in range)"},
+        // round-4 advice: soffset BEYOND num_records - what sdpa_fwd3 (tile requests up to three tiles past the sequence), sdpa_bwd_dkv3 (statistics of steps
+        // past the last record) and wgrad_dma_kernel (rows past the slab) issue.  A raw-buffer check written as offset >= num_records - soffset would wrap.
+        {1024, 1024 + 3 * 16384, 16, "num_records = 1024 B, soffset 1024 + 3 * 16384: every lane far beyond it"},
+        {1024, 2048, 16, "num_records = 1024 B, soffset 2048: every lane beyond it (soffset - num_records = 1024 = what a wrapped check would accept)"},
     };
     for (auto& c : cases) {
         hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, src, out, c.nrec, c.soff, c.vstride);

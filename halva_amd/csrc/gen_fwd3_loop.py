@@ -5,9 +5,9 @@ A wave is alone on its SIMD (512 registers) and owns 64 QUERIES - two groups g o
 O^T accumulators (a[0:127]) - and per 64-key tile t of the workgroup's K / V ring computes
     S^T_g[key][query] = K Q_g^T      A = K tile rows from LDS (one A operand serves both groups), B = Q fragments; lane = query, registers = keys:
                                       a query's row statistics are per LANE, no cross-lane work inside the loop
-    P = exp2(S^T sc - m_ref)         in place; m_ref is a per-query REFERENCE fixed for the whole item (set in the prologue from the first half
-                                      tile's row maximum, or handed in); the running maximum is only tracked (v_max3) - the caller repeats the
-                                      item with m_ref = the true maximum in the rare case that it outgrew the reference by more than 2^64
+    P = exp2(S^T sc - m_ref)         in place; m_ref is a per-query REFERENCE fixed for the whole pass (set in the prologue from the first half
+                                      tile's row maximum, or handed in); nothing is tracked in the loop - the row SUMS are judged at the end of
+                                      the pass and the item is repeated here, reference raised by 120, while one is not below 2^100 (MAX_REDO)
     O^T_g[d][query] += V^T P_g       A = V^T by transposed LDS reads (shared by both groups again), B = P packed to bf16
 = 64 MFMAs per tile.  The stream is the one measured in experiments/fwd3 (2 804 cycles per step; 3 020-3 042 with the tiles streamed by LDS-DMA;
 masked variant 3 339), ROTATED by half a step so that ALL vector work of an iteration belongs to ONE tile (its mask state is per iteration):
@@ -17,25 +17,28 @@ masked variant 3 339), ROTATED by half a step so that ALL vector work of an iter
     n = 48..63  S(t+1) keys  0..31
 K / V tiles: a ring of FOUR slots (K at 0, V at 64 KiB, 16 KiB per tile) fed by LDS-DMA: the item's prologue requests tiles 0..2, iteration t waits
 for tile t+1 (ONE counted vmcnt + s_barrier, gap 25) and then requests tile t+3 into the slot tile t-1 left (gaps 32..39); requests past the
-item's last tile still go out (into a dummy chunk) so that every iteration has the same eight vector-memory operations.  The tile WALK may
-jump once (a row block wholly inside branch B of a packed row skips the tiles of [br.a, br.b)); the sequence's partial last tile is fetched
-with per-piece clamped lane offsets (out of line).
+item's last tile still go out (rows past the sequence's end of the bounds-checked descriptor: zeros) so that every iteration has the same eight
+vector-memory operations.  The tile WALK may
+jump once (a row block wholly inside branch B of a packed row skips the tiles of [br.a, br.b)); the sequence's partial last tile needs no case of its
+own (rows past the descriptor arrive as zeros).
 Iterations come in two bodies: PLAIN (every key of the tile visible to every query of the wave) and MASKED (every score compared with the lane's
 visible-key count: causal diagonal, sequence tail, branch edge, wholly hidden tiles); an item is [plain n0][masked n1, rsA][plain n2][masked n3, rsB].
 Machinery as gen_dkv3_loop.py: 8-slot A-operand ring filled LOOKAHEAD MFMAs ahead, <= CAP issue units of vector work per MFMA gap, every
 s_waitcnt lgkmcnt(N) from a simulation of the in-order LDS queue, hazard checks.
 
-Operands (by NAME): o0-o7 the O^T accumulators of group 0 / 1 ("=a", fixed a[0:127]: zeroed here), q0-q15 the Q fragments ("a", fixed a[128:191]:
-possibly still in flight at entry - the block's first wait covers them), l0 / mx0 / mr0, l1 / mx1 / mr1 outputs: row sum, running maximum (raw
-scores), reference used (log2 units) per lane ("=&v"); rowrel / colrel row-read / transposed-read lane offsets, voff the lane offset of a wave's tile
-piece, alt0-alt3 the same for the four pieces of a partial last tile ("v"); rsA, rsB0/1 per-lane visible-key counts (minus 4 h) of the first tile of
-masked run 1 (the same for both groups: br.a) / of masked run 2; mri0/1 the reference handed in (ctl bit 3); k_lo/k_hi first K row of the first
-tile (a uniform value in VECTOR registers), vdlo / vdhi = v - k in bytes, safe_k always-valid K rows for the dummy requests ("s", 64 bit); sc = scale * log2 e, n01 =
-n0 | n1 << 16, n23, nreq = tiles to request | requests before the walk's jump << 16 (0xffff: no jump), jlo / jhi the jump in bytes, wave,
-piece = bytes between a wave's pieces (16 rows), ctl: bits 0-1 ring slot of tile 0, bit 2 the last tile is partial, bit 3 reference handed in,
-bit 4 tiles 0..2 were requested by the previous item's block, bits 5-6 tiles of the NEXT item (first rows nk_lo.. / nv_lo.., "v") that this
-block's last iterations request once its own are all under way, bit 7 (with bit 4) the predecessor issued exactly 18 stores behind this
-item's Q loads, bits 8-9 the first tile's mask state (0 plain, 1 masked run 1, 2 masked run 2) ("s")."""
+Operands (by NAME; the authoritative list is the asm statement in sdpa_fwd3_call.h): q0-q15 the Q fragments ("+a", fixed a[128:191]: this item's
+on entry - possibly still in flight, the block's first wait covers them - the NEXT item's, landed, on exit); the O^T accumulators a[0:127] are the
+block's own (clobbered: it zeroes them, normalises and stores the item's rows and lse itself - o_lo / o_hi, lse_lo / lse_hi, ooffc, rows8o, loff0/1,
+nt01); rowrel / colrel row-read / transposed-read lane offsets, voff the lane offset of a wave's tile piece ("v"); rsA, rsB0/1 per-lane visible-key
+counts (minus 4 h) of the first tile of masked run 1 (the same for both groups: br.a) / of masked run 2; k_lo / k_hi / nrec / soff0 the buffer
+descriptor (base, bytes) over the sequence's K rows of this head and the first tile's byte offset (uniform values in VECTOR registers: scalar
+operands are scarce), vdlo = v - k in bytes ("s"); nk_* / nnrec / nsoff0 the same for the NEXT item (its first tiles are requested by this item's last
+iterations), nq_* / nqrec / nqsoff0/1 / nqvA/B / rows8 / nqg0/1 its Q rows (requested by the tail); sc = scale * log2 e, n01 = n0 | n1 << 16, n23,
+nreq = tiles to request | requests before the walk's jump << 16 (0xffff: no jump), jlo the jump in bytes, wave, piece = bytes between a wave's
+pieces (16 rows), ctl: bits 0-1 ring slot of tile 0, bit 4 tiles 0..2 were requested by the previous item's block, bits 5-6 tiles of the NEXT item
+that this block's last iterations request once its own are all under way, bits 8-9 the first tile's mask state (0 plain, 1 masked run 1, 2 masked
+run 2), bit 10 which of the two vote-word sets this item uses, bit 11 the next item's Q rows are gathered by plain loads instead of LDS-DMA ("s")."""
+
 import os
 import re
 import sys

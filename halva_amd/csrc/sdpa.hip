@@ -100,6 +100,7 @@ struct SdpaParams {
     char* ds_ws;          // backward: dS = P o (dP - delta) as bf16 in the dK/dV kernel's register layout (see ds_chunk), or nullptr
     int ds_nkb, ds_nt;    // key blocks of 128 / query steps of 64 per (sequence, head) in ds_ws
     float scale;          // softmax scale
+    int repair;           // sdpa_fwd_kernel behind sdpa_fwd3: redo only the row blocks that hold a valid row with a non-finite lse (launch_fwd)
 };
 
 // Two responses sharing one prefix are packed as [prefix | A | pad | B] in one sequence: B (rows >= b, b a multiple of 64 so
@@ -810,6 +811,24 @@ __global__ __launch_bounds__(512) void sdpa_fwd_kernel(const SdpaParams p) {
         int first, second;
         paired_blocks(p.nblk, start, br, b, first, second);
         if (second == first) second = -1;
+        if (p.repair) {
+            // sdpa_fwd3 fixes a row block's exponent reference on the row's first visible keys and repeats the block a bounded number of times when
+            // later keys outgrow it (gen_fwd3_loop.py: MAX_REDO); a FINITE row whose maximum lies further out than that leaves it with l = inf, i.e.
+            // lse = inf and zeros for output.  This kernel tracks a running maximum and has no such bound (as flash-attn): launched behind every
+            // sdpa_fwd3 launch, a workgroup looks at the lse of its two blocks' valid rows and recomputes a block only if one of them is not finite
+            // (NaN / inf inputs are recomputed to the same NaN / inf).  Ordinary activations: 2 x 256 loads and an exit.
+            bool did = false;
+            for (int k = 0; k < 2; ++k) {
+                const int qb = k ? second : first;
+                if (qb < 0) continue;
+                const int gq = qb * 256 + (threadIdx.x & 255), ql = gq - start;
+                const bool bad = threadIdx.x < 256 && gq < p.T && ql >= 0 && ql < len && !__builtin_isfinite(p.lse[((int64_t)s * p.H + hd) * p.T + gq]);
+                if (!__syncthreads_or(bad)) continue;
+                sdpa_fwd_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, qb, -1, false, !did, qf, start, len, br);
+                did = true;
+            }
+            return;
+        }
         sdpa_fwd_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, first, second, false, true, qf, start, len, br);
         if (second >= 0) sdpa_fwd_block<D, CAUSAL, SLOW_TR>(p, smem, s, hd, second, -1, true, false, qf, start, len, br);
     } else {
@@ -1720,7 +1739,13 @@ int launch_fwd(const SdpaParams& p_in, int S, hipStream_t st) {
         // sdpa_fwd3: one wave per SIMD, the tile loop in generated asm (sdpa_fwd3.h).  HALVA_SDPA_FWD3=0: the two-waves-per-SIMD kernel of
         // rounds 1-3 (A/B and debugging switch, read on every call).  (Its tile counts travel as 16-bit fields, a sequence's K / V rows are
         // addressed through one 32-bit buffer descriptor.)
-        if (!slow_tr_requested() && p.T < (1 << 21) && (int64_t)p.T * p.ld_qkv * 2 < (1ll << 31) && env_flag_on("HALVA_SDPA_FWD3")) return launch_fwd3(p, S, st);
+        if (!slow_tr_requested() && p.T < (1 << 21) && (int64_t)p.T * p.ld_qkv * 2 < (1ll << 31) && env_flag_on("HALVA_SDPA_FWD3")) {
+            const int rc = launch_fwd3(p, S, st);
+            // the unbounded-range repair pass over the row blocks sdpa_fwd3 gave up on (sdpa_fwd_kernel, p.repair; HALVA_FWD3_REPAIR=0: off - A/B)
+            if (rc != HALVA_OK || !env_flag_on("HALVA_FWD3_REPAIR")) return rc;
+            p.repair = 1;
+            return launch_one(sdpa_fwd_kernel<D, CAUSAL, false>, p, CAUSAL, 256, 512, lds, S, st, "sdpa_fwd (repair)");
+        }
     }
     return slow_tr_requested() ? launch_one(sdpa_fwd_kernel<D, CAUSAL, true>, p, CAUSAL, 256, 512, lds, S, st, "sdpa_fwd")
                                : launch_one(sdpa_fwd_kernel<D, CAUSAL, false>, p, CAUSAL, 256, 512, lds, S, st, "sdpa_fwd");
@@ -1775,8 +1800,10 @@ int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st) {
     const bool slow = slow_tr_requested();
     if (p.ds_ws != nullptr && D == 128) {      // dS formed once: delta (+ zero-fill of padded dq rows) -> dK/dV (+ dS store) -> dQ = dS K
         const int64_t rows = (int64_t)S * p.T;
+        // (its step counts travel as 16-bit fields, its scheduler divides in fp32, and a sequence's Q / dO rows are addressed through 32-bit
+        // buffer descriptors - q_rec / do_rec / *_soff in sdpa_dkv3.h are (rows * ld * 2) as unsigned: the same bound as launch_fwd's)
         const bool dkv3 = !slow && p.lse2 != nullptr && rows >= 16 && p.T < (1 << 22) && (int64_t)S * p.H * ((p.T + 127) / 128) < (1 << 23) &&
-                          env_flag_on("HALVA_SDPA_DKV3");      // (its step counts travel as 16-bit fields, its scheduler divides in fp32)
+                          (int64_t)p.T * std::max(p.ld_qkv, p.ld_do) * 2 < (1ll << 31) && env_flag_on("HALVA_SDPA_DKV3");
         hipLaunchKernelGGL((sdpa_bwd_delta_kernel<D>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, S, dkv3 ? 1 : 0);
         HALVA_CHECK_LAUNCH("sdpa_bwd_delta");      // (a failed launch would leave stale delta / unzeroed padded dq rows for the two kernels below)
         int rc2;

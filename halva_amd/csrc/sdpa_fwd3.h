@@ -10,17 +10,19 @@
 // inside ONE generated inline-asm block (sdpa_fwd3_loop.inc <- gen_fwd3_loop.py): prologue (requests of the first three K / V tiles, zeroed
 // accumulators, the first score half-tile, the exponent reference), the iterations (plain | masked bodies), the last O product.
 // The exponent reference m_ref of a query is FIXED for the row block: P = exp2(S sc - m_ref), O^T and l accumulate un-rescaled (O^T lives in the
-// accumulator file, which the vector unit cannot touch), the running maximum is only tracked.  m_ref comes from the row's first 32 visible
-// keys; a later score may exceed it by 2^64 (RESCALE_AT of the two-wave kernel) before anything is lost.  In the rare case that one does, the
-// WHOLE row block is repeated with m_ref = the true row maximum, which the first pass has just measured exactly - no approximation, no other
-// kernel involved (test_sdpa_exponent_reference_moves_when_later_keys_dominate).
+// accumulator file, which the vector unit cannot touch) and NOTHING is tracked inside the loop.  m_ref comes from the row's first 32 visible
+// keys; any reference within ~100 log2 units of the row's true maximum gives the same result.  At the end of the pass the workgroup votes on
+// the row SUMS: a partial sum not below 2^100 repeats the WHOLE row block, inside the same asm block, with the reference of those rows raised
+// by 120, at most MAX_REDO = 8 times (gen_fwd3_loop.py; test_sdpa_exponent_reference_moves_when_later_keys_dominate).  A finite row whose
+// maximum lies further out than 8 x 120 log2 units (~660 nats above its first keys) leaves this kernel with lse = inf: launch_fwd follows every
+// sdpa_fwd3 launch with the running-maximum kernel in repair mode (SdpaParams::repair), which redoes exactly the row blocks that hold a
+// non-finite lse (test_sdpa_forward_far_beyond_the_repeat_budget_is_repaired).
 // LDS: K ring [4][64][128] bf16 at 0, V ring at 64 KiB, the workgroup's vote words, 4 KiB per wave for the transposition of its output rows.
 
 constexpr int FWD3_TILE = 64 * 128 * 2;
 constexpr int FWD3_MAIL = 8 * FWD3_TILE;      // (gen_fwd3_loop.py: MAIL_LDS)
 constexpr int FWD3_OSTAGE = FWD3_MAIL + 128;      // (gen_fwd3_loop.py: OSTAGE_LDS) 4 x 4 KiB: the waves' staging areas for their output rows
 constexpr int FWD3_LDS = FWD3_OSTAGE + 4 * 4096;
-constexpr float FWD3_RESCALE_AT = 64.f;      // log2 units
 
 // Everything the generated block needs to know about one (sequence, head, 256-row block) item; wave-uniform unless noted.
 struct Fwd3Geom {

@@ -325,15 +325,22 @@ class HalvaTrainer:
                 for old in self._checkpoint_dirs()[:-limit]:
                     import shutil
                     shutil.rmtree(old, ignore_errors=True)
+        # rank 0's folder (with halva_state.pt) exists before any other rank looks for it - and every rank must SEE it: the per-rank files below
+        # are only of use beside rank 0's state, so output_dir has to be on a filesystem all ranks share.  A rank that does not see the folder
+        # (node-local output_dir on a multi-node run) used to write its accumulator into a private folder without halva_state.pt, which the
+        # resumed run then could not load, or loaded from a stale one (round-4 advice); now every rank fails together, at save time.
+        dp.barrier(self.dist)
+        seen = os.path.exists(os.path.join(folder, "halva_state.pt"))
+        if dp.max_scalar(0.0 if seen else 1.0, self.dist) > 0:
+            raise RuntimeError("checkpoint folder %s written by rank 0 is not visible to every rank (this rank %d: %s): --output_dir must be on "
+                               "a filesystem shared by all ranks" % (folder, self.dist.rank, "visible" if seen else "NOT visible"))
         # An end-of-epoch checkpoint can fall INSIDE an accumulation group (micro-batches are counted across epochs, 4.31's
         # total_batched_samples): the fp32 accumulator then holds the group's first micro-batches, which the resumed run must not lose.
         # Every rank's accumulator is its own (nothing has been exchanged yet), so every rank writes its own file.
         # `pending` counts the micro-batches accumulated since the last optimizer step (NOT total % accum: a step forced by an epoch
-        # shorter than one group zeroes the accumulator at any count).  The folder is created by every rank: on a multi-node run
-        # without a shared output_dir rank 0's makedirs is not visible to the other nodes.
+        # shorter than one group zeroes the accumulator at any count).
         pending = int(self._pos.get("pending", 0))
         if pending:
-            os.makedirs(folder, exist_ok=True)
             torch.save({"grad": self._flat.grad.detach().cpu(), "pending_micro": pending},
                        os.path.join(folder, "halva_pending_grad_rank%d.pt" % self.dist.rank))
         dp.barrier(self.dist)

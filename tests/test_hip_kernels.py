@@ -264,6 +264,40 @@ def test_sdpa_exponent_reference_moves_when_later_keys_dominate(D):
         assert rel_err(dq[:, :, i], r.grad[:, :, i]) < 2e-2, name
 
 
+@pytest.mark.gpu
+def test_sdpa_forward_far_beyond_the_repeat_budget_is_repaired(monkeypatch):
+    """Round-4 advice: sdpa_fwd3 repeats a row block at most 8 times (+120 log2 units each); a FINITE row whose maximum lies ~2 200 nats above its
+    first 32 keys used to come back as zeros with lse = inf.  The launch is now followed by the running-maximum kernel in repair mode
+    (sdpa.hip: SdpaParams::repair), which redoes exactly the row blocks that hold a non-finite lse.  HALVA_FWD3_REPAIR=0 shows the failure."""
+    T, H, S, D = 256, 2, 1, 128
+    g = torch.Generator().manual_seed(12)
+    u = torch.randn(H, D, generator=g)
+    u = u / u.norm(dim=-1, keepdim=True) * math.sqrt(D)
+    c = torch.tensor([0.1, 3.0, 8.0, 200.0]).repeat_interleave(64)             # ~1, 34, 90, 2 260 nats
+    qkv = torch.zeros(S, T, 3, H, D)
+    w = torch.randn(T, H, D, generator=g)
+    w = w - (w * u[None]).sum(-1, keepdim=True) / D * u[None]
+    w = w / w.norm(dim=-1, keepdim=True) * math.sqrt(D)
+    qkv[0, :, 0] = u[None] + 0.05 * torch.randn(T, H, D, generator=g)
+    qkv[0, :, 1] = c[:, None, None] * (u[None] + w)
+    qkv[0, :, 2] = torch.randn(T, H, D, generator=g)
+    qkv = bf(qkv)
+    ss = torch.zeros(S, dtype=torch.int32, device=DEV)
+    sl = torch.full((S,), T, dtype=torch.int32, device=DEV)
+    ref = _attn_ref(qkv.float(), [0], [T])
+
+    def run():
+        with torch.no_grad():
+            return K().sdpa_causal(qkv.to(DEV).view(S, T, 3 * H * D), ss, sl, H, D).view(S, T, H, D).cpu().float()
+
+    o = run()
+    assert torch.isfinite(o).all()
+    assert rel_err(o, ref) < 1e-2 and float((o - ref).abs().max()) < 4e-2
+    monkeypatch.setenv("HALVA_FWD3_REPAIR", "0")
+    broken = run()
+    assert rel_err(broken[0, 192:], ref[0, 192:]) > 0.5      # (the rows of the last tile: what the repair pass is for)
+
+
 def _branch_ref(qkv, starts, lens, br_a, br_b):
     """fp32 dense-mask reference of the branched attention: causal inside [start, start+len), rows >= br_b do not see rows in
     [br_a, br_b) (local indices); padded rows produce zeros."""
