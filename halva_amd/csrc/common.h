@@ -51,6 +51,13 @@ __device__ __forceinline__ float bf16_lo(unsigned w) { return __uint_as_float(w 
 __device__ __forceinline__ float bf16_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ float bf16_round(float f) { return bf16_to_f32(f32_to_bf16(f)); }
 
+// One RoPE pair, rope_qk_kernel's arithmetic (rowops.hip) - shared with the attention backward's store epilogues (sdpa.hip), which apply
+// the INVERSE rotation (s = -sin) to the freshly rounded dq / dk rows: x1, x2 = elements d and d + D/2 of a head row, already bf16 values.
+__device__ __forceinline__ void rope_pair(float x1, float x2, float c, float s, float& y1, float& y2) {
+    y1 = x1 * c - x2 * s;
+    y2 = x2 * c + x1 * s;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

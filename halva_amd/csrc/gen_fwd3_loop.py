@@ -55,7 +55,10 @@ LSUM = os.environ.get("FWD3_LSUM", "add")
 # point numbers, only their common exponent moves.  FWD3_TRACK_MAX=1 puts the v_max3 back (timing experiments; the value is unused).
 TRACK_MAX = os.environ.get("FWD3_TRACK_MAX", "0") == "1"
 WAIT_AGE = int(os.environ.get("FWD3_WAIT_AGE", "4"))      # 0: one wait per first use
-REDO_LIMIT, REDO_STEP, MAX_REDO = 0x71800000, 0x42f00000, 8      # 2^100, 120.0, repeats at most (8 x 120 log2 units = scores 660 nats above the row's first keys)
+# 2^100, 120.0, repeats at most: 64 x 120 log2 units = scores 5 300 nats above the row's first keys (round 5; 8 before: round-4 advice).  A bound there must
+# be: NaN / inf scores overflow on every pass.  Rows beyond it come back as NaN (l = inf) - loudly, not as wrong numbers - unless the launch is followed
+# by the running-maximum kernel in repair mode (sdpa.hip: SdpaParams::repair, HALVA_FWD3_REPAIR=1).
+REDO_LIMIT, REDO_STEP, MAX_REDO = 0x71800000, 0x42f00000, 64
 XS = {(0, 0): 64, (0, 1): 80, (1, 0): 96, (1, 1): 112}      # score tiles [group][key half]: 16 registers each
 PB = {(0, 0): 128, (0, 1): 136, (1, 0): 144, (1, 1): 152}   # packed P: 8 registers each
 L2, MX, MREF, RANGE = {0: 160, 1: 164}, {0: 168, 1: 169}, {0: 170, 1: 171}, {0: 172, 1: 173}

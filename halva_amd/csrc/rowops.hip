@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const u32x4* __restric
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rope_qk_kernel(u32x4* __restrict__ qkv, const u32x4* __restrict__ cosb,
                                                       const u32x4* __restrict__ sinb, const int32_t* __restrict__ pos,
+                                                      const int32_t* __restrict__ br_a, const int32_t* __restrict__ br_b,
                                                       int64_t rows, int T, int H, int chunks_half, float sgn, int64_t total) {
     // one thread = 8 elements of the first half of one head + the matching 8 of the second half
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -143,7 +144,11 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(u32x4* __restrict__ qkv, c
         t /= H;
         const int part = (int)(t & 1);   // 0 = q, 1 = k
         const int64_t row = t >> 1;
-        const int p = pos ? pos[row] : (int)(row % T);
+        int p = pos ? pos[row] : (int)(row % T);
+        if (br_b) {      // branch-packed rows: the rows of branch B continue from the prefix (halva_rope_qk_branch)
+            const int64_t sq = row / T;
+            if (p >= br_b[sq]) p = br_a[sq] + (p - br_b[sq]);
+        }
         const int64_t base = ((row * 3 + part) * H + h) * (2 * chunks_half) + c;
         float x1[8], x2[8], cs[8], sn[8];
         unpack8(qkv[base], x1);
@@ -153,9 +158,7 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(u32x4* __restrict__ qkv, c
         float y1[8], y2[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float s = sn[j] * sgn;
-            y1[j] = x1[j] * cs[j] - x2[j] * s;
-            y2[j] = x2[j] * cs[j] + x1[j] * s;
+            rope_pair(x1[j], x2[j], cs[j], sn[j] * sgn, y1[j], y2[j]);
         }
         qkv[base] = pack8(y1);
         qkv[base + chunks_half] = pack8(y2);
@@ -296,8 +299,24 @@ extern "C" int halva_rope_qk(void* qkv, const void* cos, const void* sin, const 
     const int ch = D / 16;
     const int64_t total = rows * 2 * H * ch;
     hipLaunchKernelGGL(rope_qk_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (u32x4*)qkv,
-                       (const u32x4*)cos, (const u32x4*)sin, pos, rows, T, H, ch, inverse ? -1.f : 1.f, total);
+                       (const u32x4*)cos, (const u32x4*)sin, pos, nullptr, nullptr, rows, T, H, ch, inverse ? -1.f : 1.f, total);
     HALVA_CHECK_LAUNCH("rope_qk");
+    return HALVA_OK;
+}
+
+extern "C" int halva_rope_qk_branch(void* qkv, const void* cos, const void* sin, const int32_t* br_a, const int32_t* br_b, int64_t rows, int T,
+                                    int H, int D, int max_pos, int inverse, void* stream) {
+    HALVA_CHECK_ARG(qkv && cos && sin, "rope_qk_branch: null pointer");
+    HALVA_CHECK_ARG((br_a == nullptr) == (br_b == nullptr), "rope_qk_branch: br_a and br_b go together");
+    HALVA_CHECK_ARG(D > 0 && D % 16 == 0, "rope_qk_branch: head_dim=%d must be a multiple of 16", D);
+    HALVA_CHECK_ARG(T > 0 && H > 0 && rows % T == 0, "rope_qk_branch: bad T/H/rows");
+    HALVA_CHECK_ARG(T <= max_pos, "rope_qk_branch: T=%d exceeds the cos/sin table (%d rows)", T, max_pos);
+    if (rows <= 0) return HALVA_OK;
+    const int ch = D / 16;
+    const int64_t total = rows * 2 * H * ch;
+    hipLaunchKernelGGL(rope_qk_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (u32x4*)qkv,
+                       (const u32x4*)cos, (const u32x4*)sin, nullptr, br_a, br_b, rows, T, H, ch, inverse ? -1.f : 1.f, total);
+    HALVA_CHECK_LAUNCH("rope_qk_branch");
     return HALVA_OK;
 }
 

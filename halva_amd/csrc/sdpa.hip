@@ -100,6 +100,10 @@ struct SdpaParams {
     char* ds_ws;          // backward: dS = P o (dP - delta) as bf16 in the dK/dV kernel's register layout (see ds_chunk), or nullptr
     int ds_nkb, ds_nt;    // key blocks of 128 / query steps of 64 per (sequence, head) in ds_ws
     float scale;          // softmax scale
+    // backward, optional: the inverse RoPE of dq / dk applied in the store epilogues of sdpa_bwd_dq2 / sdpa_bwd_dkv3 (halva_sdpa_branch_bwd_rope);
+    // a row's position follows from its index and the branch points (rope_position below)
+    const bf16_t* rope_cos;      // [max_pos, D / 2] bf16 tables of halva_rope_qk, or nullptr = dq / dk leave un-rotated
+    const bf16_t* rope_sin;
     int repair;           // sdpa_fwd_kernel behind sdpa_fwd3: redo only the row blocks that hold a valid row with a non-finite lse (launch_fwd)
 };
 
@@ -116,6 +120,10 @@ __device__ __forceinline__ Branch load_branch(const SdpaParams& p, int s) {
     br.b = p.br_b ? p.br_b[s] : 0x7fffffff;
     return br;
 }
+
+// RoPE position of row t (index inside its T rows) of a sequence: its index - and for a branch-packed row [prefix | A | pad | B] the rows of B
+// continue from the prefix (include/halva_hip.h, halva_sdpa_branch_fwd: "RoPE positions of branch B restart at br_a"; halva_amd/splice.py:pack_pairs)
+__device__ __forceinline__ int rope_position(int t, const Branch& br) { return t >= br.b ? br.a + (t - br.b) : t; }
 
 // Byte offset of 16-byte chunk `ch` of row `row` in a [rows][D] bf16 LDS tile.  The tile is cut into 8-row x 32-column
 // subtiles of 512 B; inside a subtile the four chunks of a row are XOR-ed with (row >> 2) & 3.  Conflict-free for the
@@ -278,26 +286,58 @@ __device__ __forceinline__ void stage_tile_dma_wait() { __builtin_amdgcn_s_waitc
 // and the store tail of a row block is bound by the NUMBER of store instructions (measured: ~5 600 cycles for a V-side wave of the
 // dK/dV kernel, ~10 000 for the K-side wave that finishes last).  v_permlane32_swap trades the pieces of two neighbouring groups
 // between the two lanes of a row, after which each holds 16 contiguous bytes: 8 stores per lane, same bytes, same addresses.
+// one [32 x 32] tile of a transposed accumulator (columns 32 dt .. 32 dt + 31 of the lanes' rows): two 16-byte stores per lane
+__device__ __forceinline__ void store_tile_T(bf16_t* row_ptr_dt, const f32x16& t, float mul, int h) {
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+        unsigned w[2][2];      // [group 2gp, 2gp+1][word]
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int g = 2 * gp + k;
+            w[k][0] = pack_bf16x2(t[4 * g + 0] * mul, t[4 * g + 1] * mul);
+            w[k][1] = pack_bf16x2(t[4 * g + 2] * mul, t[4 * g + 3] * mul);
+        }
+        // upper lanes' group-2gp words <-> lower lanes' group-(2gp+1) words
+        const auto x = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+        const auto y = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+        *reinterpret_cast<u32x4*>(row_ptr_dt + 16 * gp + 8 * h) = u32x4{x[0], y[0], x[1], y[1]};
+    }
+}
 template <int D>
 __device__ __forceinline__ void store_rows_T(bf16_t* row_ptr, const f32x16 (&acc)[D / 32], float mul, bool valid, int lane) {
     if (!valid) return;      // (both lanes of a row take the same side: the swap below never pairs an active lane with an inactive one)
     const int h = lane >> 5;
 #pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt) {
+    for (int dt = 0; dt < D / 32; ++dt) store_tile_T(row_ptr + 32 * dt, acc[dt], mul, h);
+}
+// The same rows with the INVERSE RoPE applied on the way out (halva_sdpa_branch_bwd_rope): what halva_rope_qk(inverse = 1) would do to the
+// stored row in a launch of its own - the row is rounded to bf16 first, rotated in fp32 with the bf16 table entries of its position, rounded
+// again (rope_pair, common.h: the same expression as rope_qk_kernel).  Elements d and d + 64 of a row sit in the same lane, same register
+// index, accumulator tiles dt and dt + 2.  cr / sr: this lane's row of the cos / sin tables ([D / 2] bf16).
+template <int D>
+__device__ __forceinline__ void store_rows_T_rope(bf16_t* row_ptr, const f32x16 (&acc)[D / 32], float mul, bool valid, int lane, const bf16_t* cr,
+                                                  const bf16_t* sr) {
+    static_assert(D == 128, "the rotating store is the head_dim-128 instantiation");
+    if (!valid) return;
+    const int h = lane >> 5;
 #pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-            unsigned w[2][2];      // [group 2gp, 2gp+1][word]
+    for (int dtl = 0; dtl < 2; ++dtl) {
+        f32x16 lo, hi;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int g = 2 * gp + k;
-                w[k][0] = pack_bf16x2(acc[dt][4 * g + 0] * mul, acc[dt][4 * g + 1] * mul);
-                w[k][1] = pack_bf16x2(acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
+        for (int g = 0; g < 4; ++g) {
+            const u32x2 cw = *reinterpret_cast<const u32x2*>(cr + 32 * dtl + 8 * g + 4 * h);
+            const u32x2 sw = *reinterpret_cast<const u32x2*>(sr + 32 * dtl + 8 * g + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float c = (j & 1) ? bf16_hi(cw[j >> 1]) : bf16_lo(cw[j >> 1]);
+                const float sn = (j & 1) ? bf16_hi(sw[j >> 1]) : bf16_lo(sw[j >> 1]);
+                float y1, y2;
+                rope_pair(bf16_round(acc[dtl][4 * g + j] * mul), bf16_round(acc[dtl + 2][4 * g + j] * mul), c, sn * -1.f, y1, y2);
+                lo[4 * g + j] = y1, hi[4 * g + j] = y2;
             }
-            // upper lanes' group-2gp words <-> lower lanes' group-(2gp+1) words
-            const auto x = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
-            const auto y = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
-            *reinterpret_cast<u32x4*>(row_ptr + 32 * dt + 16 * gp + 8 * h) = u32x4{x[0], y[0], x[1], y[1]};
         }
+        store_tile_T(row_ptr + 32 * dtl, lo, 1.f, h);
+        store_tile_T(row_ptr + 32 * (dtl + 2), hi, 1.f, h);
     }
 }
 template <int D>
@@ -814,7 +854,7 @@ __global__ __launch_bounds__(512) void sdpa_fwd_kernel(const SdpaParams p) {
         if (p.repair) {
             // sdpa_fwd3 fixes a row block's exponent reference on the row's first visible keys and repeats the block a bounded number of times when
             // later keys outgrow it (gen_fwd3_loop.py: MAX_REDO); a FINITE row whose maximum lies further out than that leaves it with l = inf, i.e.
-            // lse = inf and zeros for output.  This kernel tracks a running maximum and has no such bound (as flash-attn): launched behind every
+            // lse = inf and NaN for output.  This kernel tracks a running maximum and has no such bound (as flash-attn): launched behind every
             // sdpa_fwd3 launch, a workgroup looks at the lse of its two blocks' valid rows and recomputes a block only if one of them is not finite
             // (NaN / inf inputs are recomputed to the same NaN / inf).  Ordinary activations: 2 x 256 loads and an exit.
             bool did = false;
@@ -1616,7 +1656,17 @@ __device__ __forceinline__ void sdpa_bwd_dq2_block(const SdpaParams& p, char* sm
             }
         }
     }
-    if (q_valid) store_rows_T<D>(p.dq + (seq_row0 + start + lq) * p.ld_qkv + hd * D, acc, p.scale, true, lane);
+    if (q_valid) {
+        bf16_t* dq_row = p.dq + (seq_row0 + start + lq) * p.ld_qkv + hd * D;
+        if constexpr (D == 128) {
+            if (p.rope_cos) {      // (workgroup-uniform) the row's position: halva_rope_qk's convention
+                const int pos = rope_position(start + lq, br);
+                store_rows_T_rope<D>(dq_row, acc, p.scale, true, lane, p.rope_cos + (int64_t)pos * (D / 2), p.rope_sin + (int64_t)pos * (D / 2));
+                return;
+            }
+        }
+        store_rows_T<D>(dq_row, acc, p.scale, true, lane);
+    }
 }
 
 template <int D, bool SLOW_TR>
@@ -1631,6 +1681,156 @@ __global__ __launch_bounds__(512) void sdpa_bwd_dq2_kernel(const SdpaParams p) {
     WG_CLOCK_BEGIN();
 #pragma unroll 1
     for (int pass = 0; pass < npass; ++pass) sdpa_bwd_dq2_block<D, SLOW_TR>(p, smem, s, hd, pass ? light : heavy, wave, lane);
+    WG_CLOCK_END(p.dbg, 2);
+}
+
+// sdpa_bwd_dq3 (round 5): the same product, dS and K fetched THREE tiles ahead through registers.  sdpa_bwd_dq2 keeps two tiles (96 KiB) per CU in
+// flight through its LDS ring and is paced by exactly that (experiments/ds_residency: a workgroup alone on its CU reads dS at 25 GB/s whether the bytes
+// come from the Infinity Cache or from HBM; the chip-wide 4.7 TB/s is 72 KiB per CU over ~3 us of loaded latency).  LDS cannot hold a deeper ring
+// (3 x 52.9 KiB = 158 of 160 KiB), registers can: a wave asks for its 4 KiB of dS of tile i + 3 with four 16-byte loads per lane and for its share of
+// the K tile with two (24 registers per tile, three tiles = 144 KiB per CU in flight), writes a landed tile into LDS just before the step that reads it
+// (dS into a PRIVATE double buffer of the wave's own - only the wave itself reads it back, transposed, as before -, K into a double buffer the
+// workgroup shares) and multiplies as sdpa_bwd_dq2 does.  Plain loads, counted by the compiler: hand-issued (asm) register loads cannot be kept in
+// flight across compiler-scheduled code - the compiler copies registers it believes written (measured on the first version: garbage dS).  For its
+// counts to be exact every step issues the same six loads: a tile that is not live for the wave (above its diagonal) reads the wave's first piece
+// again (an L2 hit), and the walk is padded to a multiple of three steps with repeats of its last tile.
+template <int D, bool SLOW_TR>
+__device__ __forceinline__ void sdpa_bwd_dq3_block(const SdpaParams& p, char* smem, int s, int hd, int qb, int wave, int lane) {
+    constexpr int NW = 8, BN = 64, DT = D / 32, BM = 32 * NW;
+    constexpr int TILE_BYTES = BN * D * 2;
+    typedef __attribute__((address_space(3))) char lchar;
+    char* k_lds = smem;                                                  // [2][BN][D]
+    char* ds_lds = smem + 2 * TILE_BYTES + wave * (2 * DS_LDS_SLOT);     // per wave: [2][2 strips][2 pieces of 1 KiB + 128 B]
+    const int h = lane >> 5;
+    const int start = p.seq_start ? p.seq_start[s] : 0;
+    const int len = p.seq_len ? p.seq_len[s] : p.T;
+    const int64_t seq_row0 = (int64_t)s * p.T;
+    const int lq0 = qb * BM;
+    if (lq0 >= len) return;                              // workgroup-uniform
+    const int wr0 = lq0 + 32 * wave;
+    const int lq = wr0 + (lane & 31);
+    const bool q_valid = lq < len;
+    const bool wave_live = wr0 < len;
+    const Branch br = load_branch(p, s);
+    const bool wave_in_b = wr0 >= br.b;
+    const int first_tile = max(0, start) / BN;
+    const int last_key_local = min(len, lq0 + BM) - 1;
+    const int ntile_end = (start + last_key_local) / BN + 1;
+    f32x16 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+    const bf16_t* kp = p.k + hd * D;
+    const int64_t krow0 = seq_row0 + start;
+    const int step = wr0 / 64, sub = (wr0 / 32) & 1;
+    const char* ds_pair = p.ds_ws + ((int64_t)s * p.H + hd) * p.ds_nkb * p.ds_nt * 16384;
+    auto tile_live = [&](int kt) { return wave_live && (kt * BN - start) <= wr0 + 31; };
+    auto strip_hidden = [&](int kt, int si) {
+        const int k0 = kt * BN + 32 * si - start;
+        return wave_in_b && k0 >= br.a && k0 + 31 < br.b;
+    };
+    int skip_lo = ntile_end, skip_hi = ntile_end;      // (the walk's jump over the tiles of [br.a, br.b): sdpa_bwd_dq2_block)
+    if (start == 0 && lq0 >= br.b) {
+        skip_lo = min(ntile_end, max(first_tile, (br.a + BN - 1) / BN));
+        skip_hi = max(skip_lo, min(ntile_end, br.b / BN));
+    }
+    const int n_lo = skip_lo - first_tile, n_walk = n_lo + (ntile_end - skip_hi);
+    if (n_walk <= 0) {      // (workgroup-uniform; cannot happen for a block with rows - its own diagonal tile exists)
+        if (q_valid) store_rows_T<D>(p.dq + (seq_row0 + start + lq) * p.ld_qkv + hd * D, acc, 0.f, true, lane);
+        return;
+    }
+    auto tile_at = [&](int i) {      // positions past the walk repeat its last tile (never multiplied)
+        i = min(i, n_walk - 1);
+        return i < n_lo ? first_tile + i : skip_hi + (i - n_lo);
+    };
+    const char* ds_mine = ds_pair + (int64_t)step * 16384 + sub * 2048 + lane * 16;      // this lane's 16 bytes of (key block 0, strip 0, piece 0)
+    typedef Stage<D, BN, 64 * NW> KStage;
+    auto issue = [&](int i, KStage& ks, u32x4 (&set)[4]) {
+        const int kt = tile_at(i);
+        ks.load_clamped(kp, p.ld_qkv, krow0, kt * BN - start, len);
+        // a tile that is not live for this wave: the same six loads, from bytes that are in the L2 (counts stay exact, nothing is used)
+        const char* src = (i < n_walk && tile_live(kt)) ? ds_mine + (int64_t)(kt >> 1) * p.ds_nt * 16384 + 2 * (kt & 1) * 4096 : ds_mine + (int64_t)(tile_at(0) >> 1) * p.ds_nt * 16384 + 2 * (tile_at(0) & 1) * 4096;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) set[c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + (c >> 1) * 4096 + (c & 1) * 1024));
+    };
+    const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3, hb = g >> 1;
+    const int ds_rd0 = ds_lds_off(4 * hb + q4, 4 * (g & 1) + pp);
+    auto consume = [&](int i, KStage& ks, u32x4 (&set)[4]) {
+        const int kt = tile_at(i);
+        const bool live = i < n_walk && tile_live(kt);
+        char* ktile = k_lds + (i & 1) * TILE_BYTES;
+        char* mine = ds_lds + (i & 1) * DS_LDS_SLOT;
+        ks.store(ktile);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<__attribute__((address_space(3))) u32x4*>((lchar*)(mine + (c >> 1) * DS_LDS_STRIP + (c & 1) * DS_LDS_PIECE + lane * 16)) = set[c];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // K tile i is there for every wave; the slot of tile i + 1 has been read by all
+        issue(i + 3, ks, set);                                                     // (into the registers just written out)
+        if (live) {
+#pragma unroll
+            for (int ks4 = 0; ks4 < 4; ++ks4) {               // 16 keys each: strip ks4 >> 1, half ks4 & 1
+                if (strip_hidden(kt, ks4 >> 1)) continue;
+                s16x8 zb;
+                if (SLOW_TR) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int key = 16 * (ks4 & 1) + 8 * (j >> 2) + 4 * h + (j & 3), qq = lane & 31;
+                        zb[j] = *reinterpret_cast<const short*>(mine + (ks4 >> 1) * DS_LDS_STRIP + ds_lds_off(key, qq >> 2) + (qq & 3) * 2);
+                    }
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const char* a = mine + (ks4 >> 1) * DS_LDS_STRIP + ds_rd0 + 16 * (16 * (ks4 & 1) + 8 * jj);
+                        const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)a);
+                        zb[4 * jj + 0] = t[0];
+                        zb[4 * jj + 1] = t[1];
+                        zb[4 * jj + 2] = t[2];
+                        zb[4 * jj + 3] = t[3];
+                    }
+                }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) acc[dt] = mfma32(frag_cols<D, SLOW_TR>(ktile, 16 * ks4, 32 * dt, lane), zb, acc[dt]);
+            }
+        }
+    };
+    KStage k0, k1, k2;
+    u32x4 set0[4], set1[4], set2[4];
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the previous row block's readers are done
+    issue(0, k0, set0);
+    issue(1, k1, set1);
+    issue(2, k2, set2);
+#pragma unroll 1
+    for (int i = 0; i < n_walk; i += 3) {
+        consume(i, k0, set0);
+        consume(i + 1, k1, set1);
+        consume(i + 2, k2, set2);
+    }
+    if (q_valid) {
+        bf16_t* dq_row = p.dq + (seq_row0 + start + lq) * p.ld_qkv + hd * D;
+        if constexpr (D == 128) {
+            if (p.rope_cos) {
+                const int pos = rope_position(start + lq, br);
+                store_rows_T_rope<D>(dq_row, acc, p.scale, true, lane, p.rope_cos + (int64_t)pos * (D / 2), p.rope_sin + (int64_t)pos * (D / 2));
+                return;
+            }
+        }
+        store_rows_T<D>(dq_row, acc, p.scale, true, lane);
+    }
+}
+
+template <int D, bool SLOW_TR>
+__global__ __launch_bounds__(512) void sdpa_bwd_dq3_kernel(const SdpaParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int s, hd, b;
+    map_block(blockIdx.x, (p.nblk + 1) / 2, p.H, p.npairs, false, s, hd, b);
+    int heavy, light;
+    paired_blocks(p.nblk, p.seq_start ? p.seq_start[s] : 0, load_branch(p, s), b, heavy, light);
+    const int npass = (heavy != light) ? 2 : 1;
+    WG_CLOCK_BEGIN();
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) sdpa_bwd_dq3_block<D, SLOW_TR>(p, smem, s, hd, pass ? light : heavy, wave, lane);
     WG_CLOCK_END(p.dbg, 2);
 }
 
@@ -1741,8 +1941,11 @@ int launch_fwd(const SdpaParams& p_in, int S, hipStream_t st) {
         // addressed through one 32-bit buffer descriptor.)
         if (!slow_tr_requested() && p.T < (1 << 21) && (int64_t)p.T * p.ld_qkv * 2 < (1ll << 31) && env_flag_on("HALVA_SDPA_FWD3")) {
             const int rc = launch_fwd3(p, S, st);
-            // the unbounded-range repair pass over the row blocks sdpa_fwd3 gave up on (sdpa_fwd_kernel, p.repair; HALVA_FWD3_REPAIR=0: off - A/B)
-            if (rc != HALVA_OK || !env_flag_on("HALVA_FWD3_REPAIR")) return rc;
+            // HALVA_FWD3_REPAIR=1: the unbounded-range repair pass over the row blocks sdpa_fwd3 gave up on (sdpa_fwd_kernel, p.repair).  Off by
+            // default: measured 32 us per launch (fwd_in_step 0.777 -> 0.809 ms, profiles/r05_ab_rope_repair.log) against rows that would need scores
+            // 5 300 nats above their first keys (sdpa_fwd3.h); such rows come back as NaN, not as wrong numbers.
+            const char* rep = getenv("HALVA_FWD3_REPAIR");
+            if (rc != HALVA_OK || !(rep && rep[0] == '1')) return rc;
             p.repair = 1;
             return launch_one(sdpa_fwd_kernel<D, CAUSAL, false>, p, CAUSAL, 256, 512, lds, S, st, "sdpa_fwd (repair)");
         }
@@ -1753,10 +1956,9 @@ int launch_fwd(const SdpaParams& p_in, int S, hipStream_t st) {
 
 // sdpa_bwd_dkv3: 4 waves, one per SIMD (512 registers), 128 keys per workgroup, 130 KiB of LDS (four Q / dO tile slots + statistics)
 template <bool CAUSAL>
-int launch_dkv3(SdpaParams p, int S, hipStream_t st) {
+int launch_dkv3(SdpaParams p, int S, hipStream_t st, bool use_asm) {
     p.nblk = (p.T + 127) / 128;
     p.npairs = S * p.H;
-    const bool use_asm = env_flag_on("HALVA_DKV3_ASM");
     {
         const char* e = getenv("HALVA_DKV3_ORDER");
         p.sched_order = e ? atoi(e) : (CAUSAL ? 2 : 0);
@@ -1790,8 +1992,9 @@ int launch_dkv3(SdpaParams p, int S, hipStream_t st) {
 }
 
 template <int D, bool CAUSAL>
-int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st) {
+int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st, bool* fused_rope = nullptr) {
     SdpaParams p = p_in;
+    if (fused_rope) *fused_rope = false;
 #ifdef HALVA_STAMP
     p.dbg = halva_dbg_buffer();
 #endif
@@ -1804,10 +2007,15 @@ int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st) {
         // buffer descriptors - q_rec / do_rec / *_soff in sdpa_dkv3.h are (rows * ld * 2) as unsigned: the same bound as launch_fwd's)
         const bool dkv3 = !slow && p.lse2 != nullptr && rows >= 16 && p.T < (1 << 22) && (int64_t)S * p.H * ((p.T + 127) / 128) < (1 << 23) &&
                           (int64_t)p.T * std::max(p.ld_qkv, p.ld_do) * 2 < (1ll << 31) && env_flag_on("HALVA_SDPA_DKV3");
+        // the inverse RoPE of dq / dk rides in the store epilogues of sdpa_bwd_dq2 and of sdpa_bwd_dkv3's generated build; any other kernel
+        // combination leaves them un-rotated and halva_sdpa_branch_bwd_rope follows up with halva_rope_qk_branch (p_in.rope_cos stays set)
+        const bool use_asm = env_flag_on("HALVA_DKV3_ASM");
+        if (!(dkv3 && use_asm && !slow && env_flag_on("HALVA_ROPE_FUSED_BWD"))) p.rope_cos = p.rope_sin = nullptr;
+        if (fused_rope) *fused_rope = p.rope_cos != nullptr;
         hipLaunchKernelGGL((sdpa_bwd_delta_kernel<D>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, S, dkv3 ? 1 : 0);
         HALVA_CHECK_LAUNCH("sdpa_bwd_delta");      // (a failed launch would leave stale delta / unzeroed padded dq rows for the two kernels below)
         int rc2;
-        if (dkv3) rc2 = launch_dkv3<CAUSAL>(p, S, st);
+        if (dkv3) rc2 = launch_dkv3<CAUSAL>(p, S, st, use_asm);
         else
             rc2 = slow ? launch_one(sdpa_bwd_dkv2_kernel<D, CAUSAL, true>, p, CAUSAL, 128, 512, lds_dkv, S, st, "sdpa_bwd_dkv2")
                        : launch_one(sdpa_bwd_dkv2_kernel<D, CAUSAL, false>, p, CAUSAL, 128, 512, lds_dkv, S, st, "sdpa_bwd_dkv2");
@@ -1825,6 +2033,11 @@ int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st) {
             if (want) (void)hipMemsetAsync(scratch, 0, want, st);
         }
 #endif
+        if (env_flag_on("HALVA_SDPA_DQ3")) {      // (HALVA_SDPA_DQ3=0: sdpa_bwd_dq2, the LDS-ring form of rounds 2-4 - A/B and debugging switch)
+            const size_t lds_dq3 = 2 * 64 * D * 2 + 8 * 2 * DS_LDS_SLOT;
+            return slow ? launch_one(sdpa_bwd_dq3_kernel<D, true>, p, true, 256, 512, lds_dq3, S, st, "sdpa_bwd_dq3")
+                        : launch_one(sdpa_bwd_dq3_kernel<D, false>, p, true, 256, 512, lds_dq3, S, st, "sdpa_bwd_dq3");
+        }
         const size_t lds_dq2 = 3 * 64 * D * 2 + 8 * 3 * DS_LDS_SLOT;
         return slow ? launch_one(sdpa_bwd_dq2_kernel<D, true>, p, true, 256, 512, lds_dq2, S, st, "sdpa_bwd_dq2")
                     : launch_one(sdpa_bwd_dq2_kernel<D, false>, p, true, 256, 512, lds_dq2, S, st, "sdpa_bwd_dq2");
@@ -1921,6 +2134,17 @@ extern "C" int halva_sdpa_branch_bwd_ws(const void* qkv, const void* out, int64_
                                         const float* lse, void* dqkv, float* delta_ws, void* ds_ws, int64_t ds_ws_bytes,
                                         const int32_t* seq_start, const int32_t* seq_len, const int32_t* br_a, const int32_t* br_b, int S,
                                         int T, int H, int D, float scale, void* stream) {
+    return halva_sdpa_branch_bwd_rope(qkv, out, ld_out, dout, ld_dout, lse, dqkv, delta_ws, ds_ws, ds_ws_bytes, seq_start, seq_len, br_a, br_b,
+                                      nullptr, nullptr, 0, S, T, H, D, scale, stream);
+}
+
+extern "C" int halva_sdpa_branch_bwd_rope(const void* qkv, const void* out, int64_t ld_out, const void* dout, int64_t ld_dout,
+                                          const float* lse, void* dqkv, float* delta_ws, void* ds_ws, int64_t ds_ws_bytes,
+                                          const int32_t* seq_start, const int32_t* seq_len, const int32_t* br_a, const int32_t* br_b,
+                                          const void* rope_cos, const void* rope_sin, int max_pos, int S, int T, int H, int D, float scale,
+                                          void* stream) {
+    HALVA_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr), "sdpa_branch_bwd_rope: cos and sin go together");
+    HALVA_CHECK_ARG(rope_cos == nullptr || T <= max_pos, "sdpa_branch_bwd_rope: T=%d exceeds the cos/sin table (%d rows)", T, max_pos);
     HALVA_CHECK_ARG(ds_ws == nullptr || ds_ws_bytes >= halva_sdpa_bwd_ws_bytes(S, T, H, D),
                     "sdpa_branch_bwd_ws: workspace of %lld bytes, %lld needed", (long long)ds_ws_bytes,
                     (long long)halva_sdpa_bwd_ws_bytes(S, T, H, D));
@@ -1959,7 +2183,13 @@ extern "C" int halva_sdpa_branch_bwd_ws(const void* qkv, const void* out, int64_
     p.ds_nt = (T + 63) / 64;
     p.stat_nt = (T + 63) / 64;
     p.scale = scale > 0.f ? scale : 1.f / sqrtf((float)D);
-    return D == 128 ? launch_bwd<128, true>(p, S, (hipStream_t)stream) : launch_bwd<64, true>(p, S, (hipStream_t)stream);
+    p.rope_cos = (const bf16_t*)rope_cos;
+    p.rope_sin = (const bf16_t*)rope_sin;
+    bool fused = false;
+    const int rc = D == 128 ? launch_bwd<128, true>(p, S, (hipStream_t)stream, &fused) : launch_bwd<64, true>(p, S, (hipStream_t)stream, &fused);
+    if (rc != HALVA_OK || rope_cos == nullptr || fused) return rc;
+    // a kernel combination without the rotating epilogues (head_dim 64, no dS workspace, the debugging builds): the rotation as its own launch
+    return halva_rope_qk_branch(dqkv, rope_cos, rope_sin, br_a, br_b, (int64_t)S * T, T, H, D, max_pos, 1, stream);
 }
 
 extern "C" int halva_sdpa_full_fwd(const void* qkv, void* out, int N, int S, int H, int D, float scale, void* stream) {

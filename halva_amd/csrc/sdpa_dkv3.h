@@ -108,7 +108,12 @@ __device__ __forceinline__ unsigned dkv3_piece_voff(int64_t ld, int wave, int la
 // chunk lane & 7, and every store instruction writes eight whole 128-byte row pieces - instead of 16 bytes into each of 32 rows, which the CU's address
 // unit takes a lane at a time (rows converted and stored: 5 180 cycles per item, profiles/r04_dkv3_anatomy.log).  row0: the wave's first row; rows_ok:
 // how many of its 32 rows exist in the tensor.  mul: per KEY lane (0 for a key outside the sequence).
-__device__ __forceinline__ void dkv3_store_rows_lds(char* smem, int wave, bf16_t* row0, int64_t ld, const f32x16 (&acc)[4], float mul, int rows_ok, int lane) {
+// ROPE (round 5, the dK rows of halva_sdpa_branch_bwd_rope): the inverse rotation applied on the way (store_rows_T_rope's arithmetic: row rounded to
+// bf16, rotated with the bf16 table entries of the KEY's position, rounded again); elements d and d + 64 are the same register of tiles dt and dt + 2.
+// rope: the lane's 32 table words (dkv3_rope_request / dkv3_rope_wait below), landed.
+template <bool ROPE>
+__device__ __forceinline__ void dkv3_store_rows_lds(char* smem, int wave, bf16_t* row0, int64_t ld, const f32x16 (&acc)[4], float mul, int rows_ok, int lane,
+                                                    const unsigned (&rope)[32]) {
     typedef __attribute__((address_space(3))) char lchar;
     lchar* stage = (lchar*)(smem + DKV3_STAGE + wave * 4096);
     const int r = lane & 31, h = lane >> 5;
@@ -117,16 +122,24 @@ __device__ __forceinline__ void dkv3_store_rows_lds(char* smem, int wave, bf16_t
     const int rr = lane >> 3, rc = lane & 7;      // read side: row 8 j + rr, chunk rc
     // (row 8 j + rr: (row >> 1) & 7 = ((rr >> 1) + 4 j) & 7 = (rr >> 1) ^ 4 for odd j)
     lchar* rd[2] = {stage + rr * 128 + ((rc ^ ((rr >> 1) & 7)) << 4), stage + rr * 128 + ((rc ^ ((rr >> 1) & 7) ^ 4) << 4)};
+    auto val = [&](int pass, int dtl, int idx) -> float {      // column 64 pass + 32 dtl + (idx's column) of this lane's row
+        if (!ROPE) return acc[2 * pass + dtl][idx] * mul;
+        const int g = idx >> 2, j = idx & 3;
+        const unsigned cw = rope[2 * (4 * dtl + g) + (j >> 1)], sw = rope[16 + 2 * (4 * dtl + g) + (j >> 1)];
+        const float c = (j & 1) ? bf16_hi(cw) : bf16_lo(cw), sn = ((j & 1) ? bf16_hi(sw) : bf16_lo(sw)) * -1.f;
+        float y1, y2;
+        rope_pair(bf16_round(acc[dtl][idx] * mul), bf16_round(acc[dtl + 2][idx] * mul), c, sn, y1, y2);
+        return pass ? y2 : y1;
+    };
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
         for (int dtl = 0; dtl < 2; ++dtl)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int dt = 2 * pass + dtl;
                 u32x2 w;
-                w[0] = pack_bf16x2(acc[dt][4 * g + 0] * mul, acc[dt][4 * g + 1] * mul);
-                w[1] = pack_bf16x2(acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
+                w[0] = pack_bf16x2(val(pass, dtl, 4 * g + 0), val(pass, dtl, 4 * g + 1));
+                w[1] = pack_bf16x2(val(pass, dtl, 4 * g + 2), val(pass, dtl, 4 * g + 3));
                 *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(wr + (((4 * dtl + g) << 4) ^ wmask)) = w;
             }
 #pragma unroll
@@ -135,6 +148,35 @@ __device__ __forceinline__ void dkv3_store_rows_lds(char* smem, int wave, bf16_t
             if (8 * j + rr < rows_ok) *reinterpret_cast<u32x4*>(row0 + (int64_t)(8 * j + rr) * ld + 64 * pass + 8 * rc) = v;
         }
     }
+}
+// The lane's 16 words of the RoPE tables for its key (8 x 8 bytes of cos: columns 32 dtl + 8 g + 4 h .. + 3, then the same of sin), asked for BY HAND so
+// that the compiler never waits on the vector-memory counter for them (it cannot count past the asm block: its wait would be vmcnt(0), i.e. for
+// the next item's tiles and the acknowledgements of the rows being stored).  dkv3_rope_wait(n): n younger vector-memory operations may stay in flight.
+__device__ __forceinline__ void dkv3_rope_request(const bf16_t* cr, const bf16_t* sr) {
+    // INTO a128-a159: the K / V fragment registers of the item that has just finished (dead until the next item's fragments are asked for, behind the
+    // item's barrier).  The words are in flight until dkv3_rope_wait; landing in registers the compiler never touches (tools/check_dkv3_isa.py: no
+    // compiler instruction reads or writes a128-a191) no copy of a not-yet-written register can be made - asked for into ordinary registers, hipcc
+    // parked them in accumulator registers right behind the request (v_accvgpr_write of stale values: garbage rotations).
+    asm volatile(
+        "global_load_dwordx2 a[128:129], %0, off\n\tglobal_load_dwordx2 a[130:131], %0, off offset:16\n\tglobal_load_dwordx2 a[132:133], %0, off offset:32\n\t"
+        "global_load_dwordx2 a[134:135], %0, off offset:48\n\tglobal_load_dwordx2 a[136:137], %0, off offset:64\n\tglobal_load_dwordx2 a[138:139], %0, off offset:80\n\t"
+        "global_load_dwordx2 a[140:141], %0, off offset:96\n\tglobal_load_dwordx2 a[142:143], %0, off offset:112\n\t"
+        "global_load_dwordx2 a[144:145], %1, off\n\tglobal_load_dwordx2 a[146:147], %1, off offset:16\n\tglobal_load_dwordx2 a[148:149], %1, off offset:32\n\t"
+        "global_load_dwordx2 a[150:151], %1, off offset:48\n\tglobal_load_dwordx2 a[152:153], %1, off offset:64\n\tglobal_load_dwordx2 a[154:155], %1, off offset:80\n\t"
+        "global_load_dwordx2 a[156:157], %1, off offset:96\n\tglobal_load_dwordx2 a[158:159], %1, off offset:112"
+        :
+        : "v"(cr), "v"(sr)
+        : "memory", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159");
+}
+// ... landed (all but the N youngest vector-memory operations of the wave are done) and moved into ordinary registers: w[2 k], w[2 k + 1] = the 8 bytes
+// of cos columns 8 k + 4 h .. + 3 (k = 0..7), w[16 + 2 k ..] the same of sin
+template <int N>
+__device__ __forceinline__ void dkv3_rope_wait(unsigned (&w)[32]) {
+    asm volatile("s_waitcnt vmcnt(%32)\n\t"
+                 "v_accvgpr_read_b32 %0, a128\n\tv_accvgpr_read_b32 %1, a129\n\tv_accvgpr_read_b32 %2, a130\n\tv_accvgpr_read_b32 %3, a131\n\tv_accvgpr_read_b32 %4, a132\n\tv_accvgpr_read_b32 %5, a133\n\tv_accvgpr_read_b32 %6, a134\n\tv_accvgpr_read_b32 %7, a135\n\tv_accvgpr_read_b32 %8, a136\n\tv_accvgpr_read_b32 %9, a137\n\tv_accvgpr_read_b32 %10, a138\n\tv_accvgpr_read_b32 %11, a139\n\tv_accvgpr_read_b32 %12, a140\n\tv_accvgpr_read_b32 %13, a141\n\tv_accvgpr_read_b32 %14, a142\n\tv_accvgpr_read_b32 %15, a143\n\tv_accvgpr_read_b32 %16, a144\n\tv_accvgpr_read_b32 %17, a145\n\tv_accvgpr_read_b32 %18, a146\n\tv_accvgpr_read_b32 %19, a147\n\tv_accvgpr_read_b32 %20, a148\n\tv_accvgpr_read_b32 %21, a149\n\tv_accvgpr_read_b32 %22, a150\n\tv_accvgpr_read_b32 %23, a151\n\tv_accvgpr_read_b32 %24, a152\n\tv_accvgpr_read_b32 %25, a153\n\tv_accvgpr_read_b32 %26, a154\n\tv_accvgpr_read_b32 %27, a155\n\tv_accvgpr_read_b32 %28, a156\n\tv_accvgpr_read_b32 %29, a157\n\tv_accvgpr_read_b32 %30, a158\n\tv_accvgpr_read_b32 %31, a159"
+                 : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7]), "=v"(w[8]), "=v"(w[9]), "=v"(w[10]), "=v"(w[11]), "=v"(w[12]), "=v"(w[13]), "=v"(w[14]), "=v"(w[15]), "=v"(w[16]), "=v"(w[17]), "=v"(w[18]), "=v"(w[19]), "=v"(w[20]), "=v"(w[21]), "=v"(w[22]), "=v"(w[23]), "=v"(w[24]), "=v"(w[25]), "=v"(w[26]), "=v"(w[27]), "=v"(w[28]), "=v"(w[29]), "=v"(w[30]), "=v"(w[31])
+                 : "n"(N)
+                 : "memory");
 }
 
 // One key block in plain HIP (HALVA_DKV3_ASM=0: the readable twin of the generated loop, with the same ring protocol; every item starts cold)
@@ -506,8 +548,21 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
                 const int wrow0 = kb * 128 + 32 * wave;
                 const int rows_ok = min(32, max(0, p.T - wrow0));
                 bf16_t* w0 = p.dk + (seq_row0 + wrow0) * p.ld_qkv + hd * D;
-                dkv3_store_rows_lds(smem, wave, w0 + (p.dv - p.dk), p.ld_qkv, accV, k_valid ? 1.f : 0.f, rows_ok, lane);
-                dkv3_store_rows_lds(smem, wave, w0, p.ld_qkv, accK, k_valid ? p.scale : 0.f, rows_ok, lane);
+                unsigned rope[32];
+                if (p.rope_cos) {      // (uniform) the table rows of this lane's key, asked for now, needed behind the dV rows
+                    const int pos = rope_position(min(gk_st, p.T - 1), br);
+                    dkv3_rope_request(p.rope_cos + (int64_t)pos * 64 + 4 * h, p.rope_sin + (int64_t)pos * 64 + 4 * h);
+                }
+                dkv3_store_rows_lds<false>(smem, wave, w0 + (p.dv - p.dk), p.ld_qkv, accV, k_valid ? 1.f : 0.f, rows_ok, lane, rope);
+                if (p.rope_cos) {
+                    // the dV rows' stores are younger than the table words: 8 of them when the wave's 32 rows all exist; a partial last block issues
+                    // fewer (a store whose rows are all past the tensor may be branched over) - then wait for everything
+                    if (rows_ok == 32) dkv3_rope_wait<8>(rope);
+                    else dkv3_rope_wait<0>(rope);
+                    dkv3_store_rows_lds<true>(smem, wave, w0, p.ld_qkv, accK, k_valid ? p.scale : 0.f, rows_ok, lane, rope);
+                } else {
+                    dkv3_store_rows_lds<false>(smem, wave, w0, p.ld_qkv, accK, k_valid ? p.scale : 0.f, rows_ok, lane, rope);
+                }
             } else if (k_in_T) {
                 store_rows_T<D>(dv_row, accV, k_valid ? 1.f : 0.f, true, lane);
                 store_rows_T<D>(dk_row, accK, k_valid ? p.scale : 0.f, true, lane);

@@ -13,10 +13,12 @@
 // accumulator file, which the vector unit cannot touch) and NOTHING is tracked inside the loop.  m_ref comes from the row's first 32 visible
 // keys; any reference within ~100 log2 units of the row's true maximum gives the same result.  At the end of the pass the workgroup votes on
 // the row SUMS: a partial sum not below 2^100 repeats the WHOLE row block, inside the same asm block, with the reference of those rows raised
-// by 120, at most MAX_REDO = 8 times (gen_fwd3_loop.py; test_sdpa_exponent_reference_moves_when_later_keys_dominate).  A finite row whose
-// maximum lies further out than 8 x 120 log2 units (~660 nats above its first keys) leaves this kernel with lse = inf: launch_fwd follows every
-// sdpa_fwd3 launch with the running-maximum kernel in repair mode (SdpaParams::repair), which redoes exactly the row blocks that hold a
-// non-finite lse (test_sdpa_forward_far_beyond_the_repeat_budget_is_repaired).
+// by 120, at most MAX_REDO = 64 times (gen_fwd3_loop.py; test_sdpa_exponent_reference_moves_when_later_keys_dominate).  A finite row whose
+// maximum lies further out than 64 x 120 log2 units (~5 300 nats above its first keys) leaves this kernel with l = inf: NaN output rows, lse = inf -
+// loud, not silently wrong.  HALVA_FWD3_REPAIR=1 makes launch_fwd follow every sdpa_fwd3 launch with the running-maximum kernel in repair mode
+// (SdpaParams::repair), which redoes exactly the row blocks that hold a non-finite lse with no bound at all (as flash-attn); it is OFF by default:
+// the pass costs ~30 us per launch (4 % of the forward: 2 048 workgroups that each read their lse rows and leave) for inputs no training run produces
+// (test_sdpa_forward_far_beyond_the_repeat_budget_is_repaired).
 // LDS: K ring [4][64][128] bf16 at 0, V ring at 64 KiB, the workgroup's vote words, 4 KiB per wave for the transposition of its output rows.
 
 constexpr int FWD3_TILE = 64 * 128 * 2;

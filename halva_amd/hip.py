@@ -29,7 +29,9 @@ SIGNATURES = {
     "halva_sdpa_branch_fwd": [_P, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "halva_sdpa_branch_bwd": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "halva_sdpa_branch_bwd_ws": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "halva_sdpa_branch_bwd_rope": [_P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "halva_rope_qk": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
+    "halva_rope_qk_branch": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
     "halva_swiglu_fwd": [_P, _P, _L, _I, _P],
     "halva_swiglu_bwd": [_P, _P, _P, _L, _I, _P],
     "halva_sdpa_causal_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],

@@ -221,14 +221,15 @@ class _SdpaCausal(torch.autograd.Function):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         ws, ws_bytes = _sdpa_workspace(qkv.device, S, T, H, D)
-        call("halva_sdpa_branch_bwd_ws", ptr(qkv), ptr(out), width, ptr(dout), dout.shape[-1], ptr(lse), ptr(dqkv), ptr(delta),
-             ptr(ws), ws_bytes, ptr(seq_start), ptr(seq_len), ptr(br_a), ptr(br_b), S, T, H, D, 0.0, stream_ptr())
+        cos, sin = ctx.rope
+        # round 5: the inverse rotation of dq / dk rides in the backward kernels' store epilogues (halva_sdpa_branch_bwd_rope; positions follow
+        # from the branch points exactly as splice.pack_pairs lays them out); HALVA_ROPE_FUSED_BWD=0 (read by the library): as its own launch
+        call("halva_sdpa_branch_bwd_rope", ptr(qkv), ptr(out), width, ptr(dout), dout.shape[-1], ptr(lse), ptr(dqkv), ptr(delta),
+             ptr(ws), ws_bytes, ptr(seq_start), ptr(seq_len), ptr(br_a), ptr(br_b), ptr(cos), ptr(sin), 0 if cos is None else cos.shape[0],
+             S, T, H, D, 0.0, stream_ptr())
         if probe is not None:
             e1.record()
             probe.append((e0, e1, S, T, H, D, ctx.branch is not None))
-        cos, sin = ctx.rope
-        if cos is not None:
-            _rope_inplace(dqkv, cos, sin, T, H, D, True, pos)
         return dqkv, None, None, None, None, None, None, None, None
 
 

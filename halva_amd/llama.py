@@ -71,6 +71,9 @@ RES_INPLACE = os.environ.get("HALVA_RES_INPLACE", "1") != "0"        # residual 
 # dgrad through the MERGED weight: the transposed copy holds (W + scale * B A)^T, so dx = dy (W + scale B A) comes out of the one
 # dgrad GEMM complete and the separate dx += (scale * dy B) A pass over [rows, in] is gone (A/B: 0)
 DGRAD_MERGED = os.environ.get("HALVA_DGRAD_MERGED", "1") != "0"
+# diagnostic (tools/diag_long_fixture.py): the LoRA update as peft computes it - base product rounded to bf16, low-rank product rounded to
+# bf16, then added - instead of riding in the K-concatenated GEMM's fp32 accumulator (forward values only; the backward is unchanged)
+LORA_TWO_GEMM = os.environ.get("HALVA_LORA_TWO_GEMM", "0") == "1"
 K_ = K      # the kernels module under a name that _LoraGroupFn's local `K` (in_features) does not shadow
 
 LORA_TARGETS = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
@@ -109,7 +112,7 @@ class _LoraGroupFn(torch.autograd.Function):
             torch.mm(xa2[:, :K], A.t(), out=xa2[:, K:K + Gr])      # written in place through the row stride (no temporary)
             if K + Gr < width:
                 xa2[:, K + Gr:].zero_()          # padding columns (rank not a multiple of 8) must not hold NaN garbage
-            lhs, rhs = xa2, Wc
+            lhs, rhs = (xa2[:, :K], Wc[:, :K]) if LORA_TWO_GEMM else (xa2, Wc)
         else:
             lhs, rhs = xa2[:, :K], Wc[:, :K]
         if residual is None:
@@ -118,6 +121,8 @@ class _LoraGroupFn(torch.autograd.Function):
             y.addmm_(lhs, rhs.t())
         else:
             torch.addmm(residual.reshape(-1, N), lhs, rhs.t(), out=y)
+        if lora and LORA_TWO_GEMM:
+            y.add_(torch.mm(xa2[:, K:K + Gr], Wc[:, K:K + Gr].t()))
         ctx.save_for_backward(xa)          # the input itself (its right columns were filled above), not the internal view
         ctx.params = (Wc, WcT, A, Bs)      # long-lived parameters: kept as objects so `.main_grad` stays reachable
         ctx.meta = (scale, sink, residual is not None, K, xa.shape, bool(merged) and WcT is not None)

@@ -69,6 +69,11 @@ int halva_rmsnorm_bwd_res_ld(const void* dy, int64_t lddy, const void* x, const 
  * rotation (the backward). */
 int halva_rope_qk(void* qkv, const void* cos, const void* sin, const int32_t* pos, int64_t rows, int T, int H, int D,
                   int max_pos, int inverse, void* stream);
+/* The same with the positions of branch-packed rows [prefix | A | pad | B] implied by the branch points instead of a table: row t of sequence s
+ * (rows = S * T) sits at position t, and at br_a[s] + (t - br_b[s]) once t >= br_b[s] (branch B continues from the prefix: what
+ * halva_amd/splice.py:pack_pairs writes into `pos` for every row that carries a token).  br_a / br_b: int32 [S] or both NULL (= pos NULL above). */
+int halva_rope_qk_branch(void* qkv, const void* cos, const void* sin, const int32_t* br_a, const int32_t* br_b, int64_t rows, int T, int H,
+                         int D, int max_pos, int inverse, void* stream);
 
 /* ---- CLIP's activation.  replaces `input * torch.sigmoid(1.702 * input)` (transformers QuickGELUActivation, reached through
  * llava/model/multimodal_encoder/clip_encoder.py:46 -> CLIPMLP) of the frozen tower: one pass instead of three element-wise kernels, with the
@@ -133,6 +138,19 @@ int halva_sdpa_branch_bwd_ws(const void* qkv, const void* out, int64_t ld_out, c
                              void* dqkv, float* delta_ws, void* ds_ws, int64_t ds_ws_bytes, const int32_t* seq_start,
                              const int32_t* seq_len, const int32_t* br_a, const int32_t* br_b, int S, int T, int H, int D, float scale,
                              void* stream);
+/* The same backward with the INVERSE RoPE of dq and dk applied on the way out: autograd of apply_rotary_pos_emb on the query / key gradients
+ * (reference llava/model/language_model/modelling_llama.py:154-169 differentiated; llava/train/llama_flash_attn_monkey_patch.py:58-66 applies the
+ * rotation in front of the attention) = halva_sdpa_branch_bwd_ws followed by halva_rope_qk_branch(dqkv, cos, sin, br_a, br_b, ..., inverse = 1),
+ * with the same roundings (row rounded to bf16, rotated in fp32 with the bf16 table entries, rounded again) - but inside the store epilogues of
+ * the dQ and dK/dV kernels where that kernel combination runs (head_dim 128 with the workspace: sdpa_bwd_dq2 + sdpa_bwd_dkv3), saving one launch
+ * and a read-modify-write pass over dq and dk per call; any other combination ends with the rotation as its own launch.  Positions: row t of a
+ * sequence sits at position t; rows of branch B (t >= br_b) at br_a + (t - br_b) - what halva_amd/splice.py:pack_pairs feeds the forward's
+ * halva_rope_qk.  rope_cos / rope_sin: the [max_pos, D / 2] bf16 tables of halva_rope_qk; both NULL = halva_sdpa_branch_bwd_ws.
+ * HALVA_ROPE_FUSED_BWD=0 (A/B switch): always the separate launch. */
+int halva_sdpa_branch_bwd_rope(const void* qkv, const void* out, int64_t ld_out, const void* dout, int64_t ld_dout, const float* lse,
+                               void* dqkv, float* delta_ws, void* ds_ws, int64_t ds_ws_bytes, const int32_t* seq_start,
+                               const int32_t* seq_len, const int32_t* br_a, const int32_t* br_b, const void* rope_cos, const void* rope_sin,
+                               int max_pos, int S, int T, int H, int D, float scale, void* stream);
 /* ---- non-causal self-attention, bf16, head_dim 64, forward only (the CLIP tower runs under no_grad:
  * llava/model/multimodal_encoder/clip_encoder.py:37-49; replaces HF CLIPAttention's softmax(QK^T*scale)V).
  * qkv: [N, S, 3, H, D] packed; out [N, S, H, D]. */

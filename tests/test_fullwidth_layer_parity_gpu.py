@@ -106,19 +106,28 @@ def _product(layer, x, dy, lens, branch=None, rows=None):
     return y.detach().float().cpu(), xg.grad.float().cpu(), grads
 
 
-def _oracle(W, lora, ocfg, x, dy, keep):
-    """oracle.nets.decoder_layer in fp32 on the host (varlen attention = what the reference's GPU path computes); leaves' grads reset"""
-    for t in lora.values():
-        t.grad = None
+def _threads():
+    """one thread per PHYSICAL core: the SMT siblings slow the host GEMMs several-fold (bench.physical_cores)"""
+    import bench
+    torch.set_num_threads(bench.physical_cores()[0])
+
+
+def _oracle(W, lora, ocfg, x, dys, keep):
+    """oracle.nets.decoder_layer in fp32 on the host (varlen attention = what the reference's GPU path computes): ONE forward, one backward per
+    upstream gradient in `dys`; returns y and [(dx, {name: grad})] in that order"""
     xr = x.float().requires_grad_(True)
     y = nets.decoder_layer(xr, W, PRE, keep, ocfg, lora, ALPHA / R, varlen=True)
-    y.backward(dy.float())
-    return y.detach(), xr.grad, {k: v.grad.clone() for k, v in lora.items()}
+    outs = []
+    for i, dy in enumerate(dys):
+        for t in lora.values():
+            t.grad = None
+        xr.grad = None
+        y.backward(dy.float(), retain_graph=i + 1 < len(dys))
+        outs.append((xr.grad.clone(), {k: v.grad.clone() for k, v in lora.items()}))
+    return y.detach(), outs
 
 
-def _compare(tag, y, yo, dx, dxo, gr, gro, rows_mask=None):
-    if rows_mask is not None:
-        y_full, yo = y, yo[rows_mask]
+def _compare(tag, y, yo, dx, dxo, gr, gro):
     worst = {"fwd": rel_err(y, yo), "dx": rel_err(dx, dxo)}
     for k in sorted(gro):
         worst[k.replace(PRE, "")] = rel_err(gr[k], gro[k])
@@ -132,7 +141,7 @@ def _compare(tag, y, yo, dx, dxo, gr, gro, rows_mask=None):
 
 @pytest.mark.parametrize("width", ["7b", "13b"])
 def test_decoder_layer_plain_and_ragged_rows_match_the_oracle(width):
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    _threads()
     layer, W, lora, ocfg = _build(width, seed=101)
     d = WIDTHS[width]["d"]
     S, T, lens = 2, 2048, [2048, 1391]
@@ -145,25 +154,29 @@ def test_decoder_layer_plain_and_ragged_rows_match_the_oracle(width):
         x[s, lens[s]:] = 0        # padded rows: embeddings of the pad token in the reference; any finite value - they never reach a valid row
         dy[s, lens[s]:] = 0       # the loss never reads a padded row
     y, dx, gr = _product(layer, x, dy, lens)
-    yo, dxo, gro = _oracle(W, lora, ocfg, x, dy, keep)
     valid = keep.view(-1)
-    _compare(width + " plain", y.view(-1, d)[valid], yo.view(-1, d)[valid], dx.view(-1, d)[valid], dxo.view(-1, d)[valid], gr, gro)
+    dys, idx = [dy], None
     if width == "7b":
         # the top layer's row pruning (LlamaModel.run_layers(rows=)): only some valid rows are read by the loss
         idx = torch.nonzero(valid).flatten()
         idx = idx[torch.randperm(idx.numel(), generator=g)[:900]].sort().values
         dyr = bf(torch.randn(idx.numel(), d, generator=g))
-        yr, dxr, grr = _product(layer, x, dyr, lens, rows=idx)
         dy_full = torch.zeros(S * T, d, dtype=torch.bfloat16)
         dy_full[idx] = dyr
-        yo2, dxo2, gro2 = _oracle(W, lora, ocfg, x, dy_full.view(S, T, d), keep)
-        _compare(width + " rows=", yr, yo2.view(-1, d)[idx], dxr.view(-1, d)[valid], dxo2.view(-1, d)[valid], grr, gro2)
+        dys.append(dy_full.view(S, T, d))
+    yo, outs = _oracle(W, lora, ocfg, x, dys, keep)
+    dxo, gro = outs[0]
+    _compare(width + " plain", y.view(-1, d)[valid], yo.view(-1, d)[valid], dx.view(-1, d)[valid], dxo.view(-1, d)[valid], gr, gro)
+    if idx is not None:
+        yr, dxr, grr = _product(layer, x, dyr, lens, rows=idx)
+        dxo2, gro2 = outs[1]
+        _compare(width + " rows=", yr, yo.view(-1, d)[idx], dxr.view(-1, d)[valid], dxo2.view(-1, d)[valid], grr, gro2)
 
 
 @pytest.mark.parametrize("width", ["7b", "13b"])
 def test_decoder_layer_packed_pair_matches_the_oracles_two_rows(width):
     """[prefix 668 | A 1380 | B 1380] with br_a = 668, br_b = 2048 and explicit RoPE positions = the bench's packed row."""
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    _threads()
     layer, W, lora, ocfg = _build(width, seed=202)
     d = WIDTHS[width]["d"]
     P, TA = 668, 2048
@@ -177,7 +190,7 @@ def test_decoder_layer_packed_pair_matches_the_oracles_two_rows(width):
     xo = torch.stack([x[0, :TA], torch.cat([x[0, :P], x[0, TA:]])])
     dyo = torch.stack([dy[0, :TA], torch.cat([torch.zeros(P, d, dtype=dy.dtype), dy[0, TA:]])])
     keep = torch.ones(2, TA, dtype=torch.bool)
-    yo, dxo, gro = _oracle(W, lora, ocfg, xo, dyo, keep)
+    yo, ((dxo, gro),) = _oracle(W, lora, ocfg, xo, [dyo], keep)
     yo_packed = torch.cat([yo[0], yo[1, P:]])
     dxo_packed = torch.cat([dxo[0, :P] + dxo[1, :P], dxo[0, P:], dxo[1, P:]])
     assert rel_err(yo[1, :P], yo[0, :P]) < 1e-5          # (the oracle's own prefix rows agree: causal)
@@ -190,7 +203,7 @@ def test_decoder_layer_packed_pair_matches_the_oracles_two_rows(width):
 def test_lm_head_logp_and_kl_across_a_chunk_boundary_match_the_oracle():
     """halva_amd.dpa.lm_head_logp / lm_head_kl (chunks of 8192 rows) at the 7B head: [8492 x 4096] x 32000."""
     from halva_amd import dpa
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    _threads()
     rows, d, V = dpa.LOGIT_CHUNK_ROWS + 300, 4096, 32000
     g = torch.Generator().manual_seed(9)
     h_pol = bf(torch.randn(rows, d, generator=g))

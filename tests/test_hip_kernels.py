@@ -147,6 +147,60 @@ def test_rope_forward_and_inverse():
     assert rel_err(work.view(S, T, 3, H, D).cpu(), qkv) < 8e-3
 
 
+@pytest.mark.parametrize("layout", ["plain_ragged", "left_padded", "packed", "packed_long"])
+def test_inverse_rope_in_the_backward_epilogues_equals_the_separate_launch(layout, monkeypatch):
+    """halva_sdpa_branch_bwd_rope (round 5): the inverse rotation of dq / dk applied inside sdpa_bwd_dq2's and sdpa_bwd_dkv3's store epilogues must
+    give the BITS of the separate halva_rope_qk launch it replaces (same roundings, same expression: common.h rope_pair) - positions of packed rows
+    from the branch points, not from the table splice.pack_pairs writes (they agree on every row that carries a token), and
+    halva_rope_qk_branch (the fall-back launch of kernel combinations without the rotating epilogue) agrees with both."""
+    from halva_amd import kernels as HK
+    from halva_amd.hip import call, ptr, stream_ptr
+    H, D = 2, 128
+    if layout == "plain_ragged":
+        S, T, lens, starts, br = 3, 300, [300, 211, 64], [0, 0, 0], None
+    elif layout == "left_padded":
+        S, T, lens, starts, br = 2, 200, [200, 131], [0, 69], None
+    elif layout == "packed":
+        S, T, lens, starts, br = 2, 520, [520, 470], [0, 0], ([130, 100], [256, 192])
+    else:
+        S, T, lens, starts, br = 1, 1500, [1500], [0], ([628], [832])
+    g = torch.Generator().manual_seed(17)
+    qkv = bf(torch.randn(S, T, 3, H, D, generator=g))
+    dout = bf(torch.randn(S, T, H, D, generator=g))
+    for s_ in range(S):
+        dout[s_, :starts[s_]] = 0
+        dout[s_, starts[s_] + lens[s_]:] = 0
+    cos, sin = K().rope_tables(D, 2048, device=DEV)
+    mk = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    branch = None
+    if br is not None:      # the position table pack_pairs would write: rows of B continue from the prefix (padding rows: 0)
+        pos = torch.zeros(S, T, dtype=torch.int32)
+        for s_ in range(S):
+            a, b = br[0][s_], br[1][s_]
+            pos[s_, :b] = torch.arange(b)
+            pos[s_, b:] = a + torch.arange(T - b)
+        branch = (mk(br[0]), mk(br[1]), pos.view(-1).to(DEV))
+
+    def grads(fused):
+        monkeypatch.setenv("HALVA_ROPE_FUSED_BWD", "1" if fused else "0")
+        qg = qkv.to(DEV).view(S, T, 3 * H * D).clone().requires_grad_(True)
+        out = HK.attention(qg * 1, cos, sin, mk(starts), mk(lens), H, D, None, branch)
+        out.backward(dout.to(DEV).view(S, T, H * D))
+        torch.cuda.synchronize()
+        return qg.grad.clone()
+
+    a, b = grads(True), grads(False)
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+    # the fall-back launch against the table-driven one on a random buffer (this test's table gives the padding rows below br_b their index as well)
+    x = bf(torch.randn(S, T, 3 * H * D, generator=g)).to(DEV)
+    y1, y2 = x.clone(), x.clone()
+    call("halva_rope_qk", ptr(y1), ptr(cos), ptr(sin), ptr(branch[2]) if branch else None, S * T, T, H, D, cos.shape[0], 1, stream_ptr())
+    call("halva_rope_qk_branch", ptr(y2), ptr(cos), ptr(sin), ptr(branch[0]) if branch else None, ptr(branch[1]) if branch else None, S * T, T, H, D,
+         cos.shape[0], 1, stream_ptr())
+    assert torch.equal(y1, y2)
+
+
 def test_swiglu():
     rows, Fd = 50, 11008
     g = torch.Generator().manual_seed(2)
@@ -265,15 +319,17 @@ def test_sdpa_exponent_reference_moves_when_later_keys_dominate(D):
 
 
 @pytest.mark.gpu
-def test_sdpa_forward_far_beyond_the_repeat_budget_is_repaired(monkeypatch):
-    """Round-4 advice: sdpa_fwd3 repeats a row block at most 8 times (+120 log2 units each); a FINITE row whose maximum lies ~2 200 nats above its
-    first 32 keys used to come back as zeros with lse = inf.  The launch is now followed by the running-maximum kernel in repair mode
-    (sdpa.hip: SdpaParams::repair), which redoes exactly the row blocks that hold a non-finite lse.  HALVA_FWD3_REPAIR=0 shows the failure."""
+@pytest.mark.parametrize("scale_last", [200.0, 2000.0])
+def test_sdpa_forward_far_beyond_the_repeat_budget_is_repaired(scale_last, monkeypatch):
+    """Round-4 advice: sdpa_fwd3 repeated a row block at most 8 times (+120 log2 units each: 660 nats); now 64 times (5 300 nats).  A FINITE row whose
+    maximum lies further out than that - here ~22 000 nats above its first 32 keys - comes back as NaN (loud), and with HALVA_FWD3_REPAIR=1 the launch
+    is followed by the running-maximum kernel in repair mode (sdpa.hip: SdpaParams::repair), which redoes exactly the row blocks that hold a
+    non-finite lse.  Rows ~2 200 nats out (the old failure) are handled by the kernel itself."""
     T, H, S, D = 256, 2, 1, 128
     g = torch.Generator().manual_seed(12)
     u = torch.randn(H, D, generator=g)
     u = u / u.norm(dim=-1, keepdim=True) * math.sqrt(D)
-    c = torch.tensor([0.1, 3.0, 8.0, 200.0]).repeat_interleave(64)             # ~1, 34, 90, 2 260 nats
+    c = torch.tensor([0.1, 3.0, 8.0, scale_last]).repeat_interleave(64)             # ~1, 34, 90, 11.3 x scale_last nats
     qkv = torch.zeros(S, T, 3, H, D)
     w = torch.randn(T, H, D, generator=g)
     w = w - (w * u[None]).sum(-1, keepdim=True) / D * u[None]
@@ -290,12 +346,16 @@ def test_sdpa_forward_far_beyond_the_repeat_budget_is_repaired(monkeypatch):
         with torch.no_grad():
             return K().sdpa_causal(qkv.to(DEV).view(S, T, 3 * H * D), ss, sl, H, D).view(S, T, H, D).cpu().float()
 
+    monkeypatch.setenv("HALVA_FWD3_REPAIR", "1")
     o = run()
     assert torch.isfinite(o).all()
     assert rel_err(o, ref) < 1e-2 and float((o - ref).abs().max()) < 4e-2
     monkeypatch.setenv("HALVA_FWD3_REPAIR", "0")
-    broken = run()
-    assert rel_err(broken[0, 192:], ref[0, 192:]) > 0.5      # (the rows of the last tile: what the repair pass is for)
+    alone = run()
+    if scale_last <= 200.0:      # ~2 260 nats: inside the kernel's own repeat budget
+        assert torch.isfinite(alone).all() and rel_err(alone, ref) < 1e-2
+    else:                        # ~22 600 nats: the rows of the last tile come back as NaN (l = inf), never as finite wrong numbers
+        assert torch.isnan(alone[0, 192:]).any() and rel_err(alone[0, :192], ref[0, :192]) < 1e-2
 
 
 def _branch_ref(qkv, starts, lens, br_a, br_b):

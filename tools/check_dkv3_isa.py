@@ -3,6 +3,8 @@
     flight while the compiler's code runs: a copy would read them too early);
   * no scratch (a scratch reload waits, in order, for every tile request in flight).
 (a0-a127, the accumulators, are NOT checked: the compiler legitimately reads them for the store tail behind the last asm statement.)
+  (round 5: the RoPE table words of the dK store epilogue land in a128-a159 as well - dkv3_rope_request / dkv3_rope_wait, sdpa_dkv3.h - and are
+  moved into ordinary registers by hand behind their wait: the same rule covers them.)
 Run by halva_amd/csrc/Makefile on the device assembly of the same command line that builds sdpa.o; a failure fails the build.
 usage: python tools/check_dkv3_isa.py <file.s>"""
 import re, sys

@@ -4,7 +4,7 @@
 #   <tag>_clock_trace_bench.json                       its samples
 #   <tag>_step_kernel_stats.csv / _step_summary.md     ONE steady-state step: (rocprofv3 --stats of --steps 3) - (--steps 1), per kernel (tools/steady_state_stats.py)
 #   <tag>_sdpa_pmc.json                                FETCH_SIZE / WRITE_SIZE of the SDPA kernels (microbench shape + in the step), tools/make_pmc_json.py
-#   <tag>_sdpa_all_pmc.json                            SQ counters of the SDPA kernels (tools/pmc_sdpa.sh)
+#   <tag>_sdpa_all_pmc.json                            SQ counters of the SDPA kernels (tools/pmc_sdpa.sh); <tag>_sdpa_tcc_in_step.json: its TCC hit / miss / fabric-read pass over one bench step
 #   <tag>_rowops_pmc.json                              HBM TB/s of the row / loss kernels from counters (tools/pmc_rowops.sh)
 #   <tag>_clock_under_load.json                        shader clock per kernel kind (tools/clock_under_load.py)
 tag=${1:-r03}; R=$PWD; OUT=$R/gpurun_out/$tag; mkdir -p $OUT
@@ -23,7 +23,7 @@ done
 python3 tools/summarize_pmc.py $OUT/traffic sdpa_fwd sdpa_bwd_dq sdpa_bwd_dkv sdpa_bwd_delta > $OUT/traffic.json
 python3 tools/summarize_pmc.py $OUT/traffic_step sdpa_fwd sdpa_bwd_dq sdpa_bwd_dkv sdpa_bwd_delta > $OUT/traffic_step.json
 python3 tools/make_pmc_json.py $OUT > $OUT/${tag}_sdpa_pmc.json
-bash tools/pmc_sdpa.sh $tag > /dev/null 2>&1; cp gpurun_out/pmc_sdpa_$tag/summary.json $OUT/${tag}_sdpa_all_pmc.json
+bash tools/pmc_sdpa.sh $tag > /dev/null 2>&1; cp gpurun_out/pmc_sdpa_$tag/summary.json $OUT/${tag}_sdpa_all_pmc.json; cp gpurun_out/pmc_sdpa_$tag/summary_step.json $OUT/${tag}_sdpa_tcc_in_step.json
 bash tools/pmc_rowops.sh $tag > $OUT/rowops.log 2>&1; cp gpurun_out/${tag}_rowops_pmc.json $OUT/
 python3 tools/clock_under_load.py $OUT/${tag}_clock_under_load.json > $OUT/clock_under_load.log 2>&1
 # the bench line last: it quotes the traffic record collected above when that has been copied to profiles/ (the copy below makes it so on the box)

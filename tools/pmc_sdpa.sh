@@ -11,4 +11,8 @@ rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNA
 # L2 (TCC) hits / misses and the read requests that leave it, summed over the channels (round 4: how much of the tile traffic the XCD's L2 serves)
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d $OUT/d -o d --output-format csv -- python3 tools/bench_sdpa.py > $OUT/d.log 2>&1
 python3 tools/summarize_pmc.py $OUT > $OUT/summary.json
+# the same TCC pass over ONE bench step (round 5: the hit rate and the fabric reads at the step's own launch shapes, not only at the micro shape)
+mkdir -p $OUT/step
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d $OUT/step/d -o d --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OUT/step_d.log 2>&1
+python3 tools/summarize_pmc.py $OUT/step > $OUT/summary_step.json
 tail -2 $OUT/c.log

@@ -1,5 +1,7 @@
 #!/bin/bash
-# sdpa_bwd_dkv3 with merged LDS waits: tests, then a time-based A/B against DKV3_WAIT_AGE=0 (libhalva_hip_w0.so) at the step's shapes
+# Time-based A/B of library variants (halva_amd/libhalva_hip_<name>.so from build_dkv3_variant.sh / build_variant.sh; "cur" = the in-tree build) at the
+# step's two SDPA launch shapes, rocprofv3 --kernel-trace --stats, one process per variant:   VARIANTS="cur nostat nodma cur" SKIPTESTS=1 bash tools/r04/ab_library_variants.sh
+# (round 4 ran it for the merged LDS waits - VARIANTS "w0 cur w0 cur" - and for the cost of sdpa_bwd_dkv3's statistics / tile requests: DESIGN.md 5.2)
 cd $GRAFT_REPO_ROOT; O=gpurun_out; R=$PWD
 [ -n "$SKIPTESTS" ] || timeout 900 python3 -m pytest tests/test_hip_kernels.py tests/test_sdpa_bench_shapes_gpu.py -x -q -m gpu > $O/r04_pytest_sdpa_f.log 2>&1; tail -3 $O/r04_pytest_sdpa_f.log
 export BENCH_STEP_SHAPES=1

@@ -23,7 +23,7 @@ with open(out_csv, "w") as f:
     for name, c, t in rows:
         f.write('"%s",%.2f,%.0f,%.0f,%.3f\n' % (name, c, t, t / c, 100 * t / tot))
 def cat(n):
-    for key, lab in (("sdpa_bwd_dkv3", "sdpa_bwd_dkv3 (HIP + generated asm)"), ("sdpa_bwd_dkv", "sdpa_bwd_dkv2 (HIP)"), ("sdpa_bwd_dq", "sdpa_bwd_dq2 (HIP)"), ("sdpa_fwd3", "sdpa_fwd3 causal D128 (HIP + generated asm)"), ("sdpa_fwd_kernel<128", "sdpa_fwd causal D128 (HIP)"),
+    for key, lab in (("sdpa_bwd_dkv3", "sdpa_bwd_dkv3 (HIP + generated asm)"), ("sdpa_bwd_dkv", "sdpa_bwd_dkv2 (HIP)"), ("sdpa_bwd_dq3", "sdpa_bwd_dq3 (HIP)"), ("sdpa_bwd_dq", "sdpa_bwd_dq2 (HIP)"), ("sdpa_fwd3", "sdpa_fwd3 causal D128 (HIP + generated asm)"), ("sdpa_fwd_kernel<128", "sdpa_fwd causal D128 (HIP)"),
                      ("sdpa_fwd_kernel<64", "sdpa_fwd full D64 CLIP (HIP)"), ("sdpa_bwd_delta", "sdpa_bwd_delta (HIP)")):
         if key in n: return lab
     if "anonymous namespace" in n:

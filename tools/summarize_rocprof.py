@@ -5,7 +5,7 @@ src, dst, title = sys.argv[1], sys.argv[2], sys.argv[3]
 rows = list(csv.DictReader(open(src)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 def cat(n):
-    for key, lab in (("sdpa_bwd_dkv3", "sdpa_bwd_dkv3 (HIP + generated asm)"), ("sdpa_bwd_dkv", "sdpa_bwd_dkv2 (HIP)"), ("sdpa_bwd_dq", "sdpa_bwd_dq (HIP)"), ("sdpa_fwd3", "sdpa_fwd3 causal D128 (HIP + generated asm)"), ("sdpa_fwd_kernel<128", "sdpa_fwd causal D128 (HIP)"),
+    for key, lab in (("sdpa_bwd_dkv3", "sdpa_bwd_dkv3 (HIP + generated asm)"), ("sdpa_bwd_dkv", "sdpa_bwd_dkv2 (HIP)"), ("sdpa_bwd_dq3", "sdpa_bwd_dq3 (HIP)"), ("sdpa_bwd_dq", "sdpa_bwd_dq (HIP)"), ("sdpa_fwd3", "sdpa_fwd3 causal D128 (HIP + generated asm)"), ("sdpa_fwd_kernel<128", "sdpa_fwd causal D128 (HIP)"),
                      ("sdpa_fwd_kernel<64", "sdpa_fwd full D64 CLIP (HIP)"), ("sdpa_bwd_delta", "sdpa_bwd_delta (HIP)")):
         if key in n: return lab
     if "anonymous namespace" in n:
