@@ -284,6 +284,12 @@ def in_step_roofline(probe, layout, micro):
                                                                                  "the step's SDPA-backward dispatches"),
                 "achieved": round(flop / ms / 1e9, 2), "frac": round(flop / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
                 "launch_ms": round(ms / len(probe), 3), "launches": len(probe),
+                "kernel": "sdpa_causal_bwd_rope (one C-ABI call, halva_sdpa_branch_bwd_rope = delta + dK/dV(+dS store) + dQ=dS.K launches, D=128, "
+                          "with the inverse RoPE of dq / dk inside the store epilogues)",
+                "scope_note": "from round 5 on the timed call includes the inverse rotation of dq / dk (rounds 1-4: a separate rope_qk launch of "
+                              "~0.23 ms per call OUTSIDE these events, profiles/r04_step_summary.md); the FLOP count is unchanged (attention only), "
+                              "so `frac` is not comparable with the rounds before at equal kernel speed: profiles/r05_ab_rope_dq3.log has the "
+                              "same-box A/B (HALVA_ROPE_FUSED_BWD=0 runs the rotation as its own launch inside the same call)",
                 "measured": "HIP events around every sdpa_causal_bwd launch of the timed steps (launch stream); FLOPs of the layouts "
                             "actually run: " + ", ".join("%s: %d launches avg %.3f ms" % (k, v[0], v[1] / v[0]) for k, v in kinds.items()),
                 "microbench": {"shape": micro["shape"], "achieved": micro["achieved"], "frac": micro["frac"], "launch_ms": micro["launch_ms"],
