@@ -212,6 +212,20 @@ def sdpa_roofline(dev, S=8, T=2048, H=32, D=128, iters=10):
         tf += e[0].elapsed_time(e[1])
         tb += e[1].elapsed_time(e[2])
     tf, tb = tf / iters * 1e-3, tb / iters * 1e-3
+    # the same backward WITH the inverse RoPE of dq / dk in its store epilogues (what the step's calls run since round 5): the difference is
+    # what the rotation costs a call at this shape (in_step_roofline scales it by rows to quote the step's calls without it)
+    cos, sin = K.rope_tables(D, T, device=dev)
+    tr = 0.0
+    for it in range(iters + 2):
+        q.grad = None
+        out = K._SdpaCausal.apply(q, ss, sl, H, D, cos, sin, None, None)
+        e[1].record()
+        out.backward(dout)
+        e[2].record()
+        torch.cuda.synchronize()
+        if it >= 2:
+            tr += e[1].elapsed_time(e[2])
+    tr = tr / iters * 1e-3
     fwd_flop = 2.0 * T * T * D * H * S
     bwd_flop = 2.5 * fwd_flop
     traffic = None          # HBM bytes per launch from the newest committed PMC passes of the same kernels at the same shape
@@ -222,6 +236,7 @@ def sdpa_roofline(dev, S=8, T=2048, H=32, D=128, iters=10):
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(bwd_flop / tb / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "traffic_source": None if j is None else _pmc_source(pmc_rel, j, ""),
             "launch_ms": round(tb * 1e3, 3), "shape": {"S": S, "T": T, "H": H, "D": D},
+            "with_rotation_launch_ms": round(tr * 1e3, 3), "rotation_ms": round((tr - tb) * 1e3, 4),
             "fwd": {"achieved": round(fwd_flop / tf / 1e12, 2), "frac": round(fwd_flop / tf / 1e12 / PEAK_BF16_TFLOPS, 4),
                     "launch_ms": round(tf * 1e3, 3)}}
 
@@ -261,8 +276,9 @@ def in_step_roofline(probe, layout, micro):
     """The SDPA-backward launches of the TIMED steps themselves (events recorded by kernels._SdpaCausal.backward on the launch
     stream): algorithmic FLOPs = 2.5 x 4 D x visible pairs x H per sequence, over the summed launch time.  `micro` (the same
     kernels at the plain 8 x 2048 layer shape, timed after the steps) stays in the record for comparison with profiles/."""
-    flop = ms = 0.0
+    flop = ms = rot = 0.0
     kinds = {}
+    micro_rows = micro["shape"]["S"] * micro["shape"]["T"] * micro["shape"]["H"]
     for e0, e1, S, T, H, D, branched in probe:
         if branched and layout is not None and layout[0] == T and len(layout[1]) == S:
             pairs = sum(visible_pairs(T, a, b, n) for a, b, n in zip(*layout[1:]))
@@ -271,6 +287,7 @@ def in_step_roofline(probe, layout, micro):
         t = e0.elapsed_time(e1)
         flop += 2.5 * 4.0 * D * pairs * H
         ms += t
+        rot += max(0.0, micro.get("rotation_ms", 0.0)) * (S * T * H) / micro_rows      # (the rotation is per (row, head) work)
         k = kinds.setdefault("%dx%d%s" % (S, T, " packed" if branched else ""), [0, 0.0])
         k[0] += 1
         k[1] += t
@@ -284,18 +301,25 @@ def in_step_roofline(probe, layout, micro):
                                                                                  "the step's SDPA-backward dispatches"),
                 "achieved": round(flop / ms / 1e9, 2), "frac": round(flop / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
                 "launch_ms": round(ms / len(probe), 3), "launches": len(probe),
+                "frac_attention_only_estimate": round(flop / max(ms - rot, 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 4),
+                "rotation_ms_per_call_estimate": round(rot / len(probe), 4),
                 "kernel": "sdpa_causal_bwd_rope (one C-ABI call, halva_sdpa_branch_bwd_rope = delta + dK/dV(+dS store) + dQ=dS.K launches, D=128, "
                           "with the inverse RoPE of dq / dk inside the store epilogues)",
                 "scope_note": "from round 5 on the timed call includes the inverse rotation of dq / dk (rounds 1-4: a separate rope_qk launch of "
                               "~0.23 ms per call OUTSIDE these events, profiles/r04_step_summary.md); the FLOP count is unchanged (attention only), "
-                              "so `frac` is not comparable with the rounds before at equal kernel speed: profiles/r05_ab_rope_dq3.log has the "
-                              "same-box A/B (HALVA_ROPE_FUSED_BWD=0 runs the rotation as its own launch inside the same call)",
+                              "so `frac` is not comparable with the rounds before at equal kernel speed: `frac_attention_only_estimate` subtracts the "
+                              "rotation's cost as measured after the steps at the micro shape (microbench.rotation_ms, scaled by rows x heads) - an "
+                              "estimate, comparable with the rounds before; profiles/r05_ab_rope_dq3.log has the same-box A/B "
+                              "(HALVA_ROPE_FUSED_BWD=0 runs the rotation as its own launch inside the same call)",
                 "measured": "HIP events around every sdpa_causal_bwd launch of the timed steps (launch stream); FLOPs of the layouts "
                             "actually run: " + ", ".join("%s: %d launches avg %.3f ms" % (k, v[0], v[1] / v[0]) for k, v in kinds.items()),
                 "microbench": {"shape": micro["shape"], "achieved": micro["achieved"], "frac": micro["frac"], "launch_ms": micro["launch_ms"],
+                               "with_rotation_launch_ms": micro.get("with_rotation_launch_ms"), "rotation_ms": micro.get("rotation_ms"),
                                "traffic": micro["traffic"],
                                "note": "same kernels at the plain per-layer shape the traffic counters were collected on"}})
     out.pop("shape", None)
+    out.pop("with_rotation_launch_ms", None)      # (micro-shape figures: they live under "microbench")
+    out.pop("rotation_ms", None)
     return out
 
 
