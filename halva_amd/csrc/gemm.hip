@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 // Same arithmetic and summation order inside a slab as gemm_kernel<true, true>: bitwise the same partials.
 // KT = 64: two stages, one tile in flight per workgroup while it multiplies.  KT = 32: FOUR stages of half the height - tile t + 3 is requested
 // when tile t has landed, so three tiles (48 KiB per workgroup) stay in flight all the time, at twice the barriers (HALVA_WGRAD_KT=32).
-template <int KT>
+template <int KT, int NT_MODE>      // NT_MODE bit 0: A streamed nontemporally, bit 1: B (see `request`)
 __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const GemmParams p) {
     constexpr int TILE = 128 * KT * 2, NST = 128 / KT, PPW = KT / 16;      // bytes of an operand tile; stages; 1-KiB pieces per wave and operand
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -230,10 +230,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const GemmParams p) {
             const int piece = wave + 4 * i;
             const unsigned sa = (unsigned)(((int64_t)it * KT + 4 * piece) * p.lda * 2), sb = (unsigned)(((int64_t)it * KT + 4 * piece) * p.ldb * 2);
             const unsigned dst_a = lds_a + stage * TILE + piece * 1024, dst_b = lds_b + stage * TILE + piece * 1024;
+            // An operand whose 128-column slab is read by ONE workgroup of the grid (the wide side of a LoRA factor's gradient: gridDim.x == 1 for A,
+            // gridDim.y == 1 for B: NT_MODE, chosen by the launcher) is streamed nontemporally - read once, it would only push the other operand's slab, which every workgroup of the
+            // row / column re-reads, out of the L2 (round 5: the row kernels gained 6-16 % from the same policy, experiments/rowops_stream).
             unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %7 offen lds\n\t"
-                         "s_mov_b32 m0, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %8 offen lds\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(voa), "v"(vob), "s"(da), "s"(db), "s"(dst_a), "s"(dst_b), "s"(sa), "s"(sb) : "memory");
+#define WGRAD_REQ(NTA, NTB)                                                                                                                  \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %7 offen" NTA " lds\n\t"                  \
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %8 offen" NTB " lds\n\ts_mov_b32 m0, %0"                      \
+                 : "=&s"(keep) : "v"(voa), "v"(vob), "s"(da), "s"(db), "s"(dst_a), "s"(dst_b), "s"(sa), "s"(sb) : "memory")
+            if constexpr (NT_MODE == 0) WGRAD_REQ("", "");
+            else if constexpr (NT_MODE == 1) WGRAD_REQ(" nt", "");
+            else if constexpr (NT_MODE == 2) WGRAD_REQ("", " nt");
+            else WGRAD_REQ(" nt", " nt");
+#undef WGRAD_REQ
         }
     };
     // NST - 1 tiles ahead (every wave issues 2 PPW requests per tile, whether the tile exists or not: rows past the slab bring zeros and the
@@ -404,13 +413,17 @@ extern "C" int halva_wgrad_accumulate(const void* A, int64_t lda, const void* B,
         const dim3 grid(N / 128, M / 128, splits);
         const size_t lds = 4 * 128 * 64 * 2;
         const char* e_kt = getenv("HALVA_WGRAD_KT");
-        if (e_kt && atoi(e_kt) == 32) {
-            (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(wgrad_dma_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, p);
-        } else {
-            (void)hipFuncSetAttribute((const void*)wgrad_dma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(wgrad_dma_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, p);
-        }
+        const bool kt32 = e_kt && atoi(e_kt) == 32;
+        const int nt_mode = (grid.x == 1 ? 1 : 0) | (grid.y == 1 ? 2 : 0);
+        auto go = [&](auto kern) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, p);
+        };
+        if (kt32) go(wgrad_dma_kernel<32, 0>);
+        else if (nt_mode == 0) go(wgrad_dma_kernel<64, 0>);
+        else if (nt_mode == 1) go(wgrad_dma_kernel<64, 1>);
+        else if (nt_mode == 2) go(wgrad_dma_kernel<64, 2>);
+        else go(wgrad_dma_kernel<64, 3>);
         HALVA_CHECK_LAUNCH("wgrad_dma");
     } else {
         const int rc = launch_gemm<true, true>(p, (hipStream_t)stream);

@@ -54,6 +54,7 @@ LSUM = os.environ.get("FWD3_LSUM", "add")
 # (log2 units), as often as it takes.  Any reference within ~100 of the row's true maximum gives the same result: P, l and O^T are floating
 # point numbers, only their common exponent moves.  FWD3_TRACK_MAX=1 puts the v_max3 back (timing experiments; the value is unused).
 TRACK_MAX = os.environ.get("FWD3_TRACK_MAX", "0") == "1"
+O_STORE_POLICY = " nt" if os.environ.get("FWD3_O_NT", "0") == "1" else ""      # (experiment: the output rows written nontemporally)
 WAIT_AGE = int(os.environ.get("FWD3_WAIT_AGE", "4"))      # 0: one wait per first use
 # 2^100, 120.0, repeats at most: 64 x 120 log2 units = scores 5 300 nats above the row's first keys (round 5; 8 before: round-4 advice).  A bound there must
 # be: NaN / inf scores overflow on every pass.  Rows beyond it come back as NaN (l = inf) - loudly, not as wrong numbers - unless the launch is followed
@@ -462,7 +463,7 @@ def tail_code():
             for j in range(4):      # rows 8 j .. 8 j + 7 of the group, 128 bytes each: lanes of rows beyond the tensor switched off
                 o += ["s_waitcnt lgkmcnt(%d)" % (3 - j), "s_sub_u32 %s, %s, %d" % (S_TMP, S_TMP2, 8 * j), "s_max_i32 %s, %s, 0" % (S_TMP, S_TMP),
                       "v_cmp_gt_u32_e32 vcc, %s, v%d" % (S_TMP, l3), "s_and_saveexec_b64 %s, vcc" % sp(SRC),
-                      "global_store_dwordx4 %%[ooffc], %s, s[%d:%d] offset:%d" % (vr(R + 4 * j, 4), S_OBJ[0], S_OBJ[1], 128 * p),
+                      "global_store_dwordx4 %%[ooffc], %s, s[%d:%d] offset:%d%s" % (vr(R + 4 * j, 4), S_OBJ[0], S_OBJ[1], 128 * p, O_STORE_POLICY),
                       "s_mov_b64 exec, %s" % sp(SRC)]
                 if j < 3:
                     o += ["s_add_u32 s%d, s%d, %%[rows8o]" % (S_OBJ[0], S_OBJ[0]), "s_addc_u32 s%d, s%d, 0" % (S_OBJ[1], S_OBJ[1])]

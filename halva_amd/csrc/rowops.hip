@@ -31,6 +31,9 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
     for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
     return v;
 }
+// bytes that are read once / written once by a streaming row kernel: nontemporal (they would only push the GEMMs' operands out of the caches)
+__device__ __forceinline__ u32x4 stream_load(const u32x4* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void stream_store(u32x4* p, const u32x4& v) { __builtin_nontemporal_store(v, p); }
 
 // ---------------------------------------------------------------------------------------------------
 // RMSNorm (modelling_llama.py:65-70): y = bf16(w * x * rsqrt(mean(x^2) + eps)), one rounding.  (The reference module rounds
@@ -52,8 +55,8 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const u32x4* __restric
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
-            buf[i] = xr[c];
-            if (x_copy) x_copy[row * nchunk + c] = buf[i];      // the residual stream's own buffer (see halva_rmsnorm_fwd_fork_ld)
+            buf[i] = stream_load(xr + c);
+            if (x_copy) stream_store(x_copy + row * nchunk + c, buf[i]);      // the residual stream's own buffer (see halva_rmsnorm_fwd_fork_ld)
             float f[8];
             unpack8(buf[i], f);
 #pragma unroll
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const u32x4* __restric
             unpack8(w[c], g);
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = g[j] * (module_rounding ? bf16_round(f[j] * r) : f[j] * r);
-            yr[c] = pack8(f);
+            stream_store(yr + c, pack8(f));
         }
     }
 }
@@ -96,8 +99,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const u32x4* __restric
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
-            bx[i] = xr[c];
-            bg[i] = dyr[c];
+            bx[i] = stream_load(xr + c);
+            bg[i] = stream_load(dyr + c);
             float fx[8], fd[8], fw[8];
             unpack8(bx[i], fx);
             unpack8(bg[i], fd);
@@ -120,11 +123,11 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const u32x4* __restric
             for (int j = 0; j < 8; ++j) fx[j] = r * (fd[j] * fw[j] - fx[j] * r * dot);
             if (HAS_RES) {      // + the gradient arriving through the residual connection (bf16 sum of two bf16 gradients, as autograd's)
                 float fr[8];
-                unpack8(dres[row * nchunk + c], fr);
+                unpack8(stream_load(dres + row * nchunk + c), fr);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) fx[j] = bf16_round(fx[j]) + fr[j];
             }
-            dxr[c] = pack8(fx);
+            stream_store(dxr + c, pack8(fx));
         }
     }
 }
@@ -151,8 +154,8 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(u32x4* __restrict__ qkv, c
         }
         const int64_t base = ((row * 3 + part) * H + h) * (2 * chunks_half) + c;
         float x1[8], x2[8], cs[8], sn[8];
-        unpack8(qkv[base], x1);
-        unpack8(qkv[base + chunks_half], x2);
+        unpack8(stream_load(qkv + base), x1);
+        unpack8(stream_load(qkv + base + chunks_half), x2);
         unpack8(cosb[(int64_t)p * chunks_half + c], cs);
         unpack8(sinb[(int64_t)p * chunks_half + c], sn);
         float y1[8], y2[8];
@@ -160,8 +163,8 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(u32x4* __restrict__ qkv, c
         for (int j = 0; j < 8; ++j) {
             rope_pair(x1[j], x2[j], cs[j], sn[j] * sgn, y1[j], y2[j]);
         }
-        qkv[base] = pack8(y1);
-        qkv[base + chunks_half] = pack8(y2);
+        stream_store(qkv + base, pack8(y1));
+        stream_store(qkv + base + chunks_half, pack8(y2));
     }
 }
 
@@ -174,11 +177,11 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const u32x4* __restrict
         const int64_t row = i / chunksF;
         const int c = (int)(i - row * chunksF);
         float g[8], u[8];
-        unpack8(gu[row * 2 * chunksF + c], g);
-        unpack8(gu[row * 2 * chunksF + chunksF + c], u);
+        unpack8(stream_load(gu + row * 2 * chunksF + c), g);
+        unpack8(stream_load(gu + row * 2 * chunksF + chunksF + c), u);
 #pragma unroll
         for (int j = 0; j < 8; ++j) g[j] = bf16_round(g[j] / (1.f + __expf(-g[j]))) * u[j];
-        out[row * ldo_chunks + c] = pack8(g);
+        stream_store(out + row * ldo_chunks + c, pack8(g));
     }
 }
 
@@ -188,17 +191,17 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const u32x4* __restrict
         const int64_t row = i / chunksF;
         const int c = (int)(i - row * chunksF);
         float g[8], u[8], d[8], dg[8], du[8];
-        unpack8(gu[row * 2 * chunksF + c], g);
-        unpack8(gu[row * 2 * chunksF + chunksF + c], u);
-        unpack8(dout[row * lddo_chunks + c], d);
+        unpack8(stream_load(gu + row * 2 * chunksF + c), g);
+        unpack8(stream_load(gu + row * 2 * chunksF + chunksF + c), u);
+        unpack8(stream_load(dout + row * lddo_chunks + c), d);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float sg = 1.f / (1.f + __expf(-g[j]));
             du[j] = d[j] * g[j] * sg;
             dg[j] = d[j] * u[j] * sg * (1.f + g[j] * (1.f - sg));
         }
-        dgu[row * 2 * chunksF + c] = pack8(dg);
-        dgu[row * 2 * chunksF + chunksF + c] = pack8(du);
+        stream_store(dgu + row * 2 * chunksF + c, pack8(dg));
+        stream_store(dgu + row * 2 * chunksF + chunksF + c, pack8(du));
     }
 }
 
@@ -218,9 +221,12 @@ __global__ __launch_bounds__(256) void splice_rows_kernel(const u32x4* __restric
     for (int c = lane; c < nchunk; c += 64) to[c] = from ? from[c] : zero;
 }
 
+// One 16-byte chunk per thread, no grid-stride loop (round 5, experiments/rowops_stream: the swiglu_bwd pattern at the step's shape streams at
+// 5.3 TB/s that way against 5.0 with the grid capped at 8192 blocks, and at 5.8 with nontemporal accesses on top - stream_load / stream_store);
+// the kernels keep their loops for grids beyond 2^31 - 1 blocks.
 inline int grid_for(int64_t total, int block) {
     int64_t g = (total + block - 1) / block;
-    const int64_t cap = 256 * 8 * 4;   // grid-stride beyond ~32 blocks per CU
+    const int64_t cap = 0x7fffffff;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 

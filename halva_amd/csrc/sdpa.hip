@@ -286,6 +286,15 @@ __device__ __forceinline__ void stage_tile_dma_wait() { __builtin_amdgcn_s_waitc
 // and the store tail of a row block is bound by the NUMBER of store instructions (measured: ~5 600 cycles for a V-side wave of the
 // dK/dV kernel, ~10 000 for the K-side wave that finishes last).  v_permlane32_swap trades the pieces of two neighbouring groups
 // between the two lanes of a row, after which each holds 16 contiguous bytes: 8 stores per lane, same bytes, same addresses.
+// the dq / dk / dv rows leave through this (experiment switch -DHALVA_ROWS_NT=1: nontemporally)
+#ifndef HALVA_ROWS_NT
+#define HALVA_ROWS_NT 0
+#endif
+#if HALVA_ROWS_NT
+#define HALVA_ROW_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define HALVA_ROW_STORE(ptr, val) (*(ptr) = (val))
+#endif
 // one [32 x 32] tile of a transposed accumulator (columns 32 dt .. 32 dt + 31 of the lanes' rows): two 16-byte stores per lane
 __device__ __forceinline__ void store_tile_T(bf16_t* row_ptr_dt, const f32x16& t, float mul, int h) {
 #pragma unroll
@@ -300,7 +309,7 @@ __device__ __forceinline__ void store_tile_T(bf16_t* row_ptr_dt, const f32x16& t
         // upper lanes' group-2gp words <-> lower lanes' group-(2gp+1) words
         const auto x = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
         const auto y = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
-        *reinterpret_cast<u32x4*>(row_ptr_dt + 16 * gp + 8 * h) = u32x4{x[0], y[0], x[1], y[1]};
+        HALVA_ROW_STORE(reinterpret_cast<u32x4*>(row_ptr_dt + 16 * gp + 8 * h), (u32x4{x[0], y[0], x[1], y[1]}));
     }
 }
 template <int D>
@@ -1486,8 +1495,9 @@ __global__ __launch_bounds__(256) void sdpa_bwd_delta_kernel(const SdpaParams p,
             *reinterpret_cast<u32x4*>(p.dq + row * p.ld_qkv + hd * D + e) = u32x4{0u, 0u, 0u, 0u};
             continue;
         }
-        const u32x4 ov = *reinterpret_cast<const u32x4*>(p.o_in + row * p.ld_o + hd * D + e);
-        const u32x4 dv = *reinterpret_cast<const u32x4*>(p.d_o + row * p.ld_do + hd * D + e);
+        // (out is read here for the last time; dO once more, tile by tile, by the dK/dV kernel - from HBM either way: 0.27 - 0.45 GB per tensor)
+        const u32x4 ov = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.o_in + row * p.ld_o + hd * D + e));
+        const u32x4 dv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.d_o + row * p.ld_do + hd * D + e));
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc += bf16_lo(ov[i]) * bf16_lo(dv[i]) + bf16_hi(ov[i]) * bf16_hi(dv[i]);

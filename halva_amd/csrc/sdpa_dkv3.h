@@ -145,7 +145,7 @@ __device__ __forceinline__ void dkv3_store_rows_lds(char* smem, int wave, bf16_t
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const u32x4 v = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(rd[j & 1] + 1024 * j);
-            if (8 * j + rr < rows_ok) *reinterpret_cast<u32x4*>(row0 + (int64_t)(8 * j + rr) * ld + 64 * pass + 8 * rc) = v;
+            if (8 * j + rr < rows_ok) HALVA_ROW_STORE(reinterpret_cast<u32x4*>(row0 + (int64_t)(8 * j + rr) * ld + 64 * pass + 8 * rc), v);
         }
     }
 }
