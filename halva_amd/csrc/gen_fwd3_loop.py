@@ -54,7 +54,7 @@ LSUM = os.environ.get("FWD3_LSUM", "add")
 # (log2 units), as often as it takes.  Any reference within ~100 of the row's true maximum gives the same result: P, l and O^T are floating
 # point numbers, only their common exponent moves.  FWD3_TRACK_MAX=1 puts the v_max3 back (timing experiments; the value is unused).
 TRACK_MAX = os.environ.get("FWD3_TRACK_MAX", "0") == "1"
-O_STORE_POLICY = " nt" if os.environ.get("FWD3_O_NT", "0") == "1" else ""      # (experiment: the output rows written nontemporally)
+O_STORE_POLICY = " nt" if os.environ.get("FWD3_O_NT", "0") == "1" else ""      # (experiment, round 5: the output rows written nontemporally - +0.6 %, not kept)
 WAIT_AGE = int(os.environ.get("FWD3_WAIT_AGE", "4"))      # 0: one wait per first use
 # 2^100, 120.0, repeats at most: 64 x 120 log2 units = scores 5 300 nats above the row's first keys (round 5; 8 before: round-4 advice).  A bound there must
 # be: NaN / inf scores overflow on every pass.  Rows beyond it come back as NaN (l = inf) - loudly, not as wrong numbers - unless the launch is followed

@@ -286,7 +286,8 @@ __device__ __forceinline__ void stage_tile_dma_wait() { __builtin_amdgcn_s_waitc
 // and the store tail of a row block is bound by the NUMBER of store instructions (measured: ~5 600 cycles for a V-side wave of the
 // dK/dV kernel, ~10 000 for the K-side wave that finishes last).  v_permlane32_swap trades the pieces of two neighbouring groups
 // between the two lanes of a row, after which each holds 16 contiguous bytes: 8 stores per lane, same bytes, same addresses.
-// the dq / dk / dv rows leave through this (experiment switch -DHALVA_ROWS_NT=1: nontemporally)
+// the dq / dk / dv rows leave through this.  -DHALVA_ROWS_NT=1 (with FWD3_O_NT=1 for the forward's generator) writes them nontemporally: measured
+// round 5 and NOT kept - sdpa_bwd_dq2 +4 %, sdpa_bwd_dkv3 +0.5 %, sdpa_fwd3 +0.6 % at the step's shapes (alternating runs, rocprofv3)
 #ifndef HALVA_ROWS_NT
 #define HALVA_ROWS_NT 0
 #endif
