@@ -53,7 +53,8 @@ __device__ __forceinline__ float bf16_round(float f) { return bf16_to_f32(f32_to
 
 // One RoPE pair, rope_qk_kernel's arithmetic (rowops.hip) - shared with the attention backward's store epilogues (sdpa.hip), which apply
 // the INVERSE rotation (s = -sin) to the freshly rounded dq / dk rows: x1, x2 = elements d and d + D/2 of a head row, already bf16 values.
-__device__ __forceinline__ void rope_pair(float x1, float x2, float c, float s, float& y1, float& y2) {
+template <class T>      // float, or a pair of floats (ext_vector_type(2): v_pk_mul_f32 / v_pk_fma_f32 - half the instructions, the same values)
+__device__ __forceinline__ void rope_pair(T x1, T x2, T c, T s, T& y1, T& y2) {
     y1 = x1 * c - x2 * s;
     y2 = x2 * c + x1 * s;
 }

@@ -122,24 +122,40 @@ __device__ __forceinline__ void dkv3_store_rows_lds(char* smem, int wave, bf16_t
     const int rr = lane >> 3, rc = lane & 7;      // read side: row 8 j + rr, chunk rc
     // (row 8 j + rr: (row >> 1) & 7 = ((rr >> 1) + 4 j) & 7 = (rr >> 1) ^ 4 for odd j)
     lchar* rd[2] = {stage + rr * 128 + ((rc ^ ((rr >> 1) & 7)) << 4), stage + rr * 128 + ((rc ^ ((rr >> 1) & 7) ^ 4) << 4)};
-    auto val = [&](int pass, int dtl, int idx) -> float {      // column 64 pass + 32 dtl + (idx's column) of this lane's row
-        if (!ROPE) return acc[2 * pass + dtl][idx] * mul;
-        const int g = idx >> 2, j = idx & 3;
-        const unsigned cw = rope[2 * (4 * dtl + g) + (j >> 1)], sw = rope[16 + 2 * (4 * dtl + g) + (j >> 1)];
-        const float c = (j & 1) ? bf16_hi(cw) : bf16_lo(cw), sn = ((j & 1) ? bf16_hi(sw) : bf16_lo(sw)) * -1.f;
-        float y1, y2;
-        rope_pair(bf16_round(acc[dtl][idx] * mul), bf16_round(acc[dtl + 2][idx] * mul), c, sn, y1, y2);
-        return pass ? y2 : y1;
-    };
+    // ROPE: every element rotated ONCE, two at a time (packed f32: a lone wave pays ~4.5 cycles per instruction whatever it does - the first version,
+    // scalar and recomputed per pass, cost 0.13 - 0.17 ms per backward call, profiles/r05_rope_cost.log).  rot[dt][p] = columns 32 dt + 8 (p >> 1) +
+    // 4 h + 2 (p & 1) .. + 1 of this lane's row.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 rot[4][8];
+    if (ROPE) {
+#pragma unroll
+        for (int dtl = 0; dtl < 2; ++dtl)
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr) {
+                const unsigned cw = rope[8 * dtl + pr], sw = rope[16 + 8 * dtl + pr] ^ 0x80008000u;      // (the inverse rotation: s = -sin, exactly)
+                const f2 c = {bf16_lo(cw), bf16_hi(cw)}, sn = {bf16_lo(sw), bf16_hi(sw)};
+                const f2 m2 = {mul, mul};
+                const f2 a1 = f2{acc[dtl][2 * pr], acc[dtl][2 * pr + 1]} * m2, a2 = f2{acc[dtl + 2][2 * pr], acc[dtl + 2][2 * pr + 1]} * m2;
+                const unsigned w1 = pack_bf16x2(a1[0], a1[1]), w2 = pack_bf16x2(a2[0], a2[1]);      // the rows as the separate launch would have read them
+                const f2 x1 = {bf16_lo(w1), bf16_hi(w1)}, x2 = {bf16_lo(w2), bf16_hi(w2)};
+                rope_pair(x1, x2, c, sn, rot[dtl][pr], rot[dtl + 2][pr]);
+            }
+    }
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
         for (int dtl = 0; dtl < 2; ++dtl)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                const int dt = 2 * pass + dtl;
                 u32x2 w;
-                w[0] = pack_bf16x2(val(pass, dtl, 4 * g + 0), val(pass, dtl, 4 * g + 1));
-                w[1] = pack_bf16x2(val(pass, dtl, 4 * g + 2), val(pass, dtl, 4 * g + 3));
+                if (ROPE) {
+                    w[0] = pack_bf16x2(rot[dt][2 * g][0], rot[dt][2 * g][1]);
+                    w[1] = pack_bf16x2(rot[dt][2 * g + 1][0], rot[dt][2 * g + 1][1]);
+                } else {
+                    w[0] = pack_bf16x2(acc[dt][4 * g + 0] * mul, acc[dt][4 * g + 1] * mul);
+                    w[1] = pack_bf16x2(acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
+                }
                 *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(wr + (((4 * dtl + g) << 4) ^ wmask)) = w;
             }
 #pragma unroll
