@@ -122,8 +122,8 @@ __device__ __forceinline__ void dkv3_store_rows_lds(char* smem, int wave, bf16_t
     const int rr = lane >> 3, rc = lane & 7;      // read side: row 8 j + rr, chunk rc
     // (row 8 j + rr: (row >> 1) & 7 = ((rr >> 1) + 4 j) & 7 = (rr >> 1) ^ 4 for odd j)
     lchar* rd[2] = {stage + rr * 128 + ((rc ^ ((rr >> 1) & 7)) << 4), stage + rr * 128 + ((rc ^ ((rr >> 1) & 7) ^ 4) << 4)};
-    // ROPE: every element rotated ONCE, two at a time (packed f32: a lone wave pays ~4.5 cycles per instruction whatever it does - the first version,
-    // scalar and recomputed per pass, cost 0.13 - 0.17 ms per backward call, profiles/r05_rope_cost.log).  rot[dt][p] = columns 32 dt + 8 (p >> 1) +
+    // ROPE: every element rotated ONCE, two at a time (packed f32: a lone wave pays ~4.5 cycles per instruction whatever it does; against the first
+    // version - scalar, recomputed per pass - it made no measurable difference: +32 .. +50 us per call either way, profiles/r05_rope_cost.log).  rot[dt][p] = columns 32 dt + 8 (p >> 1) +
     // 4 h + 2 (p & 1) .. + 1 of this lane's row.
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 rot[4][8];
