@@ -104,6 +104,7 @@ struct SdpaParams {
     // a row's position follows from its index and the branch points (rope_position below)
     const bf16_t* rope_cos;      // [max_pos, D / 2] bf16 tables of halva_rope_qk, or nullptr = dq / dk leave un-rotated
     const bf16_t* rope_sin;
+    int rope_max_pos;            // rows of the tables
     int repair;           // sdpa_fwd_kernel behind sdpa_fwd3: redo only the row blocks that hold a valid row with a non-finite lse (launch_fwd)
 };
 
@@ -324,19 +325,46 @@ __device__ __forceinline__ void store_rows_T(bf16_t* row_ptr, const f32x16 (&acc
 // stored row in a launch of its own - the row is rounded to bf16 first, rotated in fp32 with the bf16 table entries of its position, rounded
 // again (rope_pair, common.h: the same expression as rope_qk_kernel).  Elements d and d + 64 of a row sit in the same lane, same register
 // index, accumulator tiles dt and dt + 2.  cr / sr: this lane's row of the cos / sin tables ([D / 2] bf16).
+// The table rows of a wave's 32 consecutive positions (pos0 .. pos0 + 31: a 32-row group never straddles a branch point) = 4 KiB of cos + 4 KiB of sin,
+// CONTIGUOUS in the tables: fetched with four coalesced 16-byte loads per lane and table and handed to the lanes through `scratch` (9 KiB of LDS that
+// only this wave touches, rows 144 bytes apart).  The first version let every lane gather its own row - 16 loads of 8 bytes per lane, 32 different
+// 128-byte lines per instruction: +28 .. +40 us per sdpa_bwd_dq2 launch (profiles/r05_rope_cost.log).
+constexpr int ROPE_LDS_ROW = 144, ROPE_LDS_BYTES = 2 * 32 * ROPE_LDS_ROW;
+__device__ __forceinline__ void rope_rows_to_lds(char* scratch, const bf16_t* cos, const bf16_t* sin, int pos0, int max_pos, int lane) {
+    typedef __attribute__((address_space(3))) char lchar;
+    u32x4 c[4], sn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * i + (lane >> 3), ch = lane & 7;
+        const int64_t at = (int64_t)min(pos0 + row, max_pos - 1) * 64 + ch * 8;
+        c[i] = *reinterpret_cast<const u32x4*>(cos + at);
+        sn[i] = *reinterpret_cast<const u32x4*>(sin + at);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * i + (lane >> 3), ch = lane & 7;
+        *reinterpret_cast<__attribute__((address_space(3))) u32x4*>((lchar*)(scratch + row * ROPE_LDS_ROW + ch * 16)) = c[i];
+        *reinterpret_cast<__attribute__((address_space(3))) u32x4*>((lchar*)(scratch + 32 * ROPE_LDS_ROW + row * ROPE_LDS_ROW + ch * 16)) = sn[i];
+    }
+}
+// The same rows with the INVERSE RoPE applied on the way out (halva_sdpa_branch_bwd_rope): what halva_rope_qk(inverse = 1) would do to the
+// stored row in a launch of its own - the row is rounded to bf16 first, rotated in fp32 with the bf16 table entries of its position, rounded
+// again (rope_pair, common.h: the same expression as rope_qk_kernel).  Elements d and d + 64 of a row sit in the same lane, same register
+// index, accumulator tiles dt and dt + 2.  scratch: rope_rows_to_lds' block of this wave (row lane & 31 = this lane's row).
 template <int D>
-__device__ __forceinline__ void store_rows_T_rope(bf16_t* row_ptr, const f32x16 (&acc)[D / 32], float mul, bool valid, int lane, const bf16_t* cr,
-                                                  const bf16_t* sr) {
+__device__ __forceinline__ void store_rows_T_rope(bf16_t* row_ptr, const f32x16 (&acc)[D / 32], float mul, bool valid, int lane, const char* scratch) {
     static_assert(D == 128, "the rotating store is the head_dim-128 instantiation");
-    if (!valid) return;
+    typedef __attribute__((address_space(3))) const char lchar;
     const int h = lane >> 5;
+    lchar* cr = (lchar*)(scratch + (lane & 31) * ROPE_LDS_ROW + 8 * h);
+    lchar* sr = cr + 32 * ROPE_LDS_ROW;
 #pragma unroll
     for (int dtl = 0; dtl < 2; ++dtl) {
         f32x16 lo, hi;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const u32x2 cw = *reinterpret_cast<const u32x2*>(cr + 32 * dtl + 8 * g + 4 * h);
-            const u32x2 sw = *reinterpret_cast<const u32x2*>(sr + 32 * dtl + 8 * g + 4 * h);
+            const u32x2 cw = *reinterpret_cast<__attribute__((address_space(3))) const u32x2*>(cr + 64 * dtl + 16 * g);
+            const u32x2 sw = *reinterpret_cast<__attribute__((address_space(3))) const u32x2*>(sr + 64 * dtl + 16 * g);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float c = (j & 1) ? bf16_hi(cw[j >> 1]) : bf16_lo(cw[j >> 1]);
@@ -346,8 +374,10 @@ __device__ __forceinline__ void store_rows_T_rope(bf16_t* row_ptr, const f32x16 
                 lo[4 * g + j] = y1, hi[4 * g + j] = y2;
             }
         }
-        store_tile_T(row_ptr + 32 * dtl, lo, 1.f, h);
-        store_tile_T(row_ptr + 32 * (dtl + 2), hi, 1.f, h);
+        if (valid) {      // (both lanes of a row take the same side: the swap in store_tile_T never pairs an active lane with an inactive one)
+            store_tile_T(row_ptr + 32 * dtl, lo, 1.f, h);
+            store_tile_T(row_ptr + 32 * (dtl + 2), hi, 1.f, h);
+        }
     }
 }
 template <int D>
@@ -1667,17 +1697,18 @@ __device__ __forceinline__ void sdpa_bwd_dq2_block(const SdpaParams& p, char* sm
             }
         }
     }
-    if (q_valid) {
-        bf16_t* dq_row = p.dq + (seq_row0 + start + lq) * p.ld_qkv + hd * D;
-        if constexpr (D == 128) {
-            if (p.rope_cos) {      // (workgroup-uniform) the row's position: halva_rope_qk's convention
-                const int pos = rope_position(start + lq, br);
-                store_rows_T_rope<D>(dq_row, acc, p.scale, true, lane, p.rope_cos + (int64_t)pos * (D / 2), p.rope_sin + (int64_t)pos * (D / 2));
-                return;
+    bf16_t* dq_row = p.dq + (seq_row0 + start + lq) * p.ld_qkv + hd * D;
+    if constexpr (D == 128) {
+        if (p.rope_cos) {      // (workgroup-uniform) positions: halva_rope_qk's convention; the wave's 32 rows sit at consecutive positions
+            if (wave_live) {   // (wave-uniform)
+                char* scratch = ds_lds;      // the wave's own dS ring: its last tile has been read (the loop's MFMAs consumed it), nobody else touches it
+                rope_rows_to_lds(scratch, p.rope_cos, p.rope_sin, rope_position(start + wr0, br), p.rope_max_pos, lane);
+                store_rows_T_rope<D>(dq_row, acc, p.scale, q_valid, lane, scratch);
             }
+            return;
         }
-        store_rows_T<D>(dq_row, acc, p.scale, true, lane);
     }
+    if (q_valid) store_rows_T<D>(dq_row, acc, p.scale, true, lane);
 }
 
 template <int D, bool SLOW_TR>
@@ -2041,6 +2072,7 @@ extern "C" int halva_sdpa_branch_bwd_rope(const void* qkv, const void* out, int6
     p.scale = scale > 0.f ? scale : 1.f / sqrtf((float)D);
     p.rope_cos = (const bf16_t*)rope_cos;
     p.rope_sin = (const bf16_t*)rope_sin;
+    p.rope_max_pos = max_pos;
     bool fused = false;
     const int rc = D == 128 ? launch_bwd<128, true>(p, S, (hipStream_t)stream, &fused) : launch_bwd<64, true>(p, S, (hipStream_t)stream, &fused);
     if (rc != HALVA_OK || rope_cos == nullptr || fused) return rc;
