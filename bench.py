@@ -199,8 +199,14 @@ def sdpa_roofline(dev, S=8, T=2048, H=32, D=128, iters=10):
         out = K.sdpa_causal(q, ss, sl, H, D)
         out.backward(dout)
     torch.cuda.synchronize()
-    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    tf = tb = 0.0
+    # the same backward WITH the inverse RoPE of dq / dk in its store epilogues (what the step's calls run since round 5), alternating with the plain
+    # one: the difference is what the rotation costs a call at this shape (in_step_roofline scales it by rows x heads to quote the step's calls without it)
+    cos, sin = K.rope_tables(D, T, device=dev)
+    out_r = K._SdpaCausal.apply(q, ss, sl, H, D, cos, sin, None, None)
+    out_r.backward(dout)
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    tf = tb = tr = 0.0
     for _ in range(iters):
         q.grad = None
         e[0].record()
@@ -208,24 +214,16 @@ def sdpa_roofline(dev, S=8, T=2048, H=32, D=128, iters=10):
         e[1].record()
         out.backward(dout)
         e[2].record()
+        q.grad = None
+        out_r = K._SdpaCausal.apply(q, ss, sl, H, D, cos, sin, None, None)
+        e[3].record()
+        out_r.backward(dout)
+        e[4].record()
         torch.cuda.synchronize()
         tf += e[0].elapsed_time(e[1])
         tb += e[1].elapsed_time(e[2])
-    tf, tb = tf / iters * 1e-3, tb / iters * 1e-3
-    # the same backward WITH the inverse RoPE of dq / dk in its store epilogues (what the step's calls run since round 5): the difference is
-    # what the rotation costs a call at this shape (in_step_roofline scales it by rows to quote the step's calls without it)
-    cos, sin = K.rope_tables(D, T, device=dev)
-    tr = 0.0
-    for it in range(iters + 2):
-        q.grad = None
-        out = K._SdpaCausal.apply(q, ss, sl, H, D, cos, sin, None, None)
-        e[1].record()
-        out.backward(dout)
-        e[2].record()
-        torch.cuda.synchronize()
-        if it >= 2:
-            tr += e[1].elapsed_time(e[2])
-    tr = tr / iters * 1e-3
+        tr += e[3].elapsed_time(e[4])
+    tf, tb, tr = tf / iters * 1e-3, tb / iters * 1e-3, tr / iters * 1e-3
     fwd_flop = 2.0 * T * T * D * H * S
     bwd_flop = 2.5 * fwd_flop
     traffic = None          # HBM bytes per launch from the newest committed PMC passes of the same kernels at the same shape

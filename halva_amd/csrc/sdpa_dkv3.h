@@ -110,10 +110,10 @@ __device__ __forceinline__ unsigned dkv3_piece_voff(int64_t ld, int wave, int la
 // how many of its 32 rows exist in the tensor.  mul: per KEY lane (0 for a key outside the sequence).
 // ROPE (round 5, the dK rows of halva_sdpa_branch_bwd_rope): the inverse rotation applied on the way (store_rows_T_rope's arithmetic: row rounded to
 // bf16, rotated with the bf16 table entries of the KEY's position, rounded again); elements d and d + 64 are the same register of tiles dt and dt + 2.
-// rope: the lane's 32 table words (dkv3_rope_request / dkv3_rope_wait below), landed.
+// rope_cos / rope_sin: the wave's 4-KiB blocks of table rows in LDS (dkv3_rope_request_lds below), landed.
 template <bool ROPE>
 __device__ __forceinline__ void dkv3_store_rows_lds(char* smem, int wave, bf16_t* row0, int64_t ld, const f32x16 (&acc)[4], float mul, int rows_ok, int lane,
-                                                    const unsigned (&rope)[32]) {
+                                                    const char* rope_cos, const char* rope_sin) {
     typedef __attribute__((address_space(3))) char lchar;
     lchar* stage = (lchar*)(smem + DKV3_STAGE + wave * 4096);
     const int r = lane & 31, h = lane >> 5;
@@ -132,7 +132,10 @@ __device__ __forceinline__ void dkv3_store_rows_lds(char* smem, int wave, bf16_t
         for (int dtl = 0; dtl < 2; ++dtl)
 #pragma unroll
             for (int pr = 0; pr < 8; ++pr) {
-                const unsigned cw = rope[8 * dtl + pr], sw = rope[16 + 8 * dtl + pr] ^ 0x80008000u;      // (the inverse rotation: s = -sin, exactly)
+                // (words 2 (pr & 1) of chunk 4 dtl + (pr >> 1) of this lane's row; the chunk sits at position chunk ^ (row & 7))
+                const int off = r * 128 + (((4 * dtl + (pr >> 1)) ^ (r & 7)) << 4) + 8 * h + 4 * (pr & 1);
+                const unsigned cw = *reinterpret_cast<__attribute__((address_space(3))) const unsigned*>((lchar*)(rope_cos + off));
+                const unsigned sw = *reinterpret_cast<__attribute__((address_space(3))) const unsigned*>((lchar*)(rope_sin + off)) ^ 0x80008000u;      // (the inverse rotation: s = -sin, exactly)
                 const f2 c = {bf16_lo(cw), bf16_hi(cw)}, sn = {bf16_lo(sw), bf16_hi(sw)};
                 const f2 m2 = {mul, mul};
                 const f2 a1 = f2{acc[dtl][2 * pr], acc[dtl][2 * pr + 1]} * m2, a2 = f2{acc[dtl + 2][2 * pr], acc[dtl + 2][2 * pr + 1]} * m2;
@@ -165,35 +168,30 @@ __device__ __forceinline__ void dkv3_store_rows_lds(char* smem, int wave, bf16_t
         }
     }
 }
-// The lane's 16 words of the RoPE tables for its key (8 x 8 bytes of cos: columns 32 dtl + 8 g + 4 h .. + 3, then the same of sin), asked for BY HAND so
-// that the compiler never waits on the vector-memory counter for them (it cannot count past the asm block: its wait would be vmcnt(0), i.e. for
-// the next item's tiles and the acknowledgements of the rows being stored).  dkv3_rope_wait(n): n younger vector-memory operations may stay in flight.
-__device__ __forceinline__ void dkv3_rope_request(const bf16_t* cr, const bf16_t* sr) {
-    // INTO a128-a159: the K / V fragment registers of the item that has just finished (dead until the next item's fragments are asked for, behind the
-    // item's barrier).  The words are in flight until dkv3_rope_wait; landing in registers the compiler never touches (tools/check_dkv3_isa.py: no
-    // compiler instruction reads or writes a128-a191) no copy of a not-yet-written register can be made - asked for into ordinary registers, hipcc
-    // parked them in accumulator registers right behind the request (v_accvgpr_write of stale values: garbage rotations).
-    asm volatile(
-        "global_load_dwordx2 a[128:129], %0, off\n\tglobal_load_dwordx2 a[130:131], %0, off offset:16\n\tglobal_load_dwordx2 a[132:133], %0, off offset:32\n\t"
-        "global_load_dwordx2 a[134:135], %0, off offset:48\n\tglobal_load_dwordx2 a[136:137], %0, off offset:64\n\tglobal_load_dwordx2 a[138:139], %0, off offset:80\n\t"
-        "global_load_dwordx2 a[140:141], %0, off offset:96\n\tglobal_load_dwordx2 a[142:143], %0, off offset:112\n\t"
-        "global_load_dwordx2 a[144:145], %1, off\n\tglobal_load_dwordx2 a[146:147], %1, off offset:16\n\tglobal_load_dwordx2 a[148:149], %1, off offset:32\n\t"
-        "global_load_dwordx2 a[150:151], %1, off offset:48\n\tglobal_load_dwordx2 a[152:153], %1, off offset:64\n\tglobal_load_dwordx2 a[154:155], %1, off offset:80\n\t"
-        "global_load_dwordx2 a[156:157], %1, off offset:96\n\tglobal_load_dwordx2 a[158:159], %1, off offset:112"
-        :
-        : "v"(cr), "v"(sr)
-        : "memory", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159");
+// The table rows of the wave's 32 keys (positions pos0 .. pos0 + 31, consecutive: a 32-key strip never straddles a branch point) = 4 KiB of cos + 4 KiB of
+// sin, contiguous in the tables, brought by LDS-DMA (four 1-KiB pieces per table, coalesced) into the ring slot the item's LAST tile has just left -
+// the one slot the next item's prefetched tiles do not use; the wave's 4 KiB of its Q half for cos, of its dO half for sin - with the 16-byte chunk
+// position XORed by row & 7 on the SOURCE side (LDS-DMA writes lane l at byte 16 l), so that the lanes' 8-byte reads of their own rows spread over
+// the banks.  No register is in flight (the first version asked for the lane's own 16 + 16 table words with 8-byte gathers - 32 different lines per
+// instruction - into accumulator registers: 68 us of the kernel per call, profiles/r05_rope_cost.log).  The requests are invisible to the compiler:
+// dkv3_rope_landed() waits for them by count.
+__device__ __forceinline__ void dkv3_rope_request_lds(char* cos_dst, char* sin_dst, const bf16_t* cos, const bf16_t* sin, int pos0, int max_pos, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * i + (lane >> 3), ch = (lane & 7) ^ (row & 7);
+        const int64_t at = (int64_t)min(pos0 + row, max_pos - 1) * 64 + ch * 8;
+        const bf16_t* sc = cos + at;
+        const bf16_t* ss = sin + at;
+        const unsigned dc = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(cos_dst + 1024 * i);
+        const unsigned ds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(sin_dst + 1024 * i);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(sc), "v"(ss), "s"(dc), "s"(ds) : "memory");
+    }
 }
-// ... landed (all but the N youngest vector-memory operations of the wave are done) and moved into ordinary registers: w[2 k], w[2 k + 1] = the 8 bytes
-// of cos columns 8 k + 4 h .. + 3 (k = 0..7), w[16 + 2 k ..] the same of sin
-template <int N>
-__device__ __forceinline__ void dkv3_rope_wait(unsigned (&w)[32]) {
-    asm volatile("s_waitcnt vmcnt(%32)\n\t"
-                 "v_accvgpr_read_b32 %0, a128\n\tv_accvgpr_read_b32 %1, a129\n\tv_accvgpr_read_b32 %2, a130\n\tv_accvgpr_read_b32 %3, a131\n\tv_accvgpr_read_b32 %4, a132\n\tv_accvgpr_read_b32 %5, a133\n\tv_accvgpr_read_b32 %6, a134\n\tv_accvgpr_read_b32 %7, a135\n\tv_accvgpr_read_b32 %8, a136\n\tv_accvgpr_read_b32 %9, a137\n\tv_accvgpr_read_b32 %10, a138\n\tv_accvgpr_read_b32 %11, a139\n\tv_accvgpr_read_b32 %12, a140\n\tv_accvgpr_read_b32 %13, a141\n\tv_accvgpr_read_b32 %14, a142\n\tv_accvgpr_read_b32 %15, a143\n\tv_accvgpr_read_b32 %16, a144\n\tv_accvgpr_read_b32 %17, a145\n\tv_accvgpr_read_b32 %18, a146\n\tv_accvgpr_read_b32 %19, a147\n\tv_accvgpr_read_b32 %20, a148\n\tv_accvgpr_read_b32 %21, a149\n\tv_accvgpr_read_b32 %22, a150\n\tv_accvgpr_read_b32 %23, a151\n\tv_accvgpr_read_b32 %24, a152\n\tv_accvgpr_read_b32 %25, a153\n\tv_accvgpr_read_b32 %26, a154\n\tv_accvgpr_read_b32 %27, a155\n\tv_accvgpr_read_b32 %28, a156\n\tv_accvgpr_read_b32 %29, a157\n\tv_accvgpr_read_b32 %30, a158\n\tv_accvgpr_read_b32 %31, a159"
-                 : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7]), "=v"(w[8]), "=v"(w[9]), "=v"(w[10]), "=v"(w[11]), "=v"(w[12]), "=v"(w[13]), "=v"(w[14]), "=v"(w[15]), "=v"(w[16]), "=v"(w[17]), "=v"(w[18]), "=v"(w[19]), "=v"(w[20]), "=v"(w[21]), "=v"(w[22]), "=v"(w[23]), "=v"(w[24]), "=v"(w[25]), "=v"(w[26]), "=v"(w[27]), "=v"(w[28]), "=v"(w[29]), "=v"(w[30]), "=v"(w[31])
-                 : "n"(N)
-                 : "memory");
-}
+template <int N>      // all but the wave's N youngest vector-memory operations are done
+__device__ __forceinline__ void dkv3_rope_landed() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
 // One key block in plain HIP (HALVA_DKV3_ASM=0: the readable twin of the generated loop, with the same ring protocol; every item starts cold)
 template <bool CAUSAL>
@@ -564,20 +562,21 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
                 const int wrow0 = kb * 128 + 32 * wave;
                 const int rows_ok = min(32, max(0, p.T - wrow0));
                 bf16_t* w0 = p.dk + (seq_row0 + wrow0) * p.ld_qkv + hd * D;
-                unsigned rope[32];
-                if (p.rope_cos) {      // (uniform) the table rows of this lane's key, asked for now, needed behind the dV rows
-                    const int pos = rope_position(min(gk_st, p.T - 1), br);
-                    dkv3_rope_request(p.rope_cos + (int64_t)pos * 64 + 4 * h, p.rope_sin + (int64_t)pos * 64 + 4 * h);
-                }
-                dkv3_store_rows_lds<false>(smem, wave, w0 + (p.dv - p.dk), p.ld_qkv, accV, k_valid ? 1.f : 0.f, rows_ok, lane, rope);
+                // the ring slot the item's last tile has left: free until the next item's first step (its prefetched tiles sit in the other three)
+                const int free_slot = (ring_base + ntiles - 1) & 3;
+                char* rope_c = smem + free_slot * DKV3_TILE + wave * 4096;
+                char* rope_s = smem + DKV3_DO + free_slot * DKV3_TILE + wave * 4096;
+                if (p.rope_cos)      // (uniform) the table rows of this wave's keys, asked for now, needed behind the dV rows
+                    dkv3_rope_request_lds(rope_c, rope_s, p.rope_cos, p.rope_sin, rope_position(min(wrow0, p.T - 1), br), p.rope_max_pos, lane);
+                dkv3_store_rows_lds<false>(smem, wave, w0 + (p.dv - p.dk), p.ld_qkv, accV, k_valid ? 1.f : 0.f, rows_ok, lane, nullptr, nullptr);
                 if (p.rope_cos) {
-                    // the dV rows' stores are younger than the table words: 8 of them when the wave's 32 rows all exist; a partial last block issues
+                    // the dV rows' stores are younger than the table requests: 8 of them when the wave's 32 rows all exist; a partial last block issues
                     // fewer (a store whose rows are all past the tensor may be branched over) - then wait for everything
-                    if (rows_ok == 32) dkv3_rope_wait<8>(rope);
-                    else dkv3_rope_wait<0>(rope);
-                    dkv3_store_rows_lds<true>(smem, wave, w0, p.ld_qkv, accK, k_valid ? p.scale : 0.f, rows_ok, lane, rope);
+                    if (rows_ok == 32) dkv3_rope_landed<8>();
+                    else dkv3_rope_landed<0>();
+                    dkv3_store_rows_lds<true>(smem, wave, w0, p.ld_qkv, accK, k_valid ? p.scale : 0.f, rows_ok, lane, rope_c, rope_s);
                 } else {
-                    dkv3_store_rows_lds<false>(smem, wave, w0, p.ld_qkv, accK, k_valid ? p.scale : 0.f, rows_ok, lane, rope);
+                    dkv3_store_rows_lds<false>(smem, wave, w0, p.ld_qkv, accK, k_valid ? p.scale : 0.f, rows_ok, lane, nullptr, nullptr);
                 }
             } else if (k_in_T) {
                 store_rows_T<D>(dv_row, accV, k_valid ? 1.f : 0.f, true, lane);
