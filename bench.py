@@ -199,14 +199,8 @@ def sdpa_roofline(dev, S=8, T=2048, H=32, D=128, iters=10):
         out = K.sdpa_causal(q, ss, sl, H, D)
         out.backward(dout)
     torch.cuda.synchronize()
-    # the same backward WITH the inverse RoPE of dq / dk in its store epilogues (what the step's calls run since round 5), alternating with the plain
-    # one: the difference is what the rotation costs a call at this shape (in_step_roofline scales it by rows x heads to quote the step's calls without it)
-    cos, sin = K.rope_tables(D, T, device=dev)
-    out_r = K._SdpaCausal.apply(q, ss, sl, H, D, cos, sin, None, None)
-    out_r.backward(dout)
-    torch.cuda.synchronize()
-    e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-    tf = tb = tr = 0.0
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    tf = tb = 0.0
     for _ in range(iters):
         q.grad = None
         e[0].record()
@@ -214,16 +208,10 @@ def sdpa_roofline(dev, S=8, T=2048, H=32, D=128, iters=10):
         e[1].record()
         out.backward(dout)
         e[2].record()
-        q.grad = None
-        out_r = K._SdpaCausal.apply(q, ss, sl, H, D, cos, sin, None, None)
-        e[3].record()
-        out_r.backward(dout)
-        e[4].record()
         torch.cuda.synchronize()
         tf += e[0].elapsed_time(e[1])
         tb += e[1].elapsed_time(e[2])
-        tr += e[3].elapsed_time(e[4])
-    tf, tb, tr = tf / iters * 1e-3, tb / iters * 1e-3, tr / iters * 1e-3
+    tf, tb = tf / iters * 1e-3, tb / iters * 1e-3
     fwd_flop = 2.0 * T * T * D * H * S
     bwd_flop = 2.5 * fwd_flop
     traffic = None          # HBM bytes per launch from the newest committed PMC passes of the same kernels at the same shape
@@ -234,7 +222,6 @@ def sdpa_roofline(dev, S=8, T=2048, H=32, D=128, iters=10):
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(bwd_flop / tb / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "traffic_source": None if j is None else _pmc_source(pmc_rel, j, ""),
             "launch_ms": round(tb * 1e3, 3), "shape": {"S": S, "T": T, "H": H, "D": D},
-            "with_rotation_launch_ms": round(tr * 1e3, 3), "rotation_ms": round((tr - tb) * 1e3, 4),
             "fwd": {"achieved": round(fwd_flop / tf / 1e12, 2), "frac": round(fwd_flop / tf / 1e12 / PEAK_BF16_TFLOPS, 4),
                     "launch_ms": round(tf * 1e3, 3)}}
 
@@ -274,9 +261,8 @@ def in_step_roofline(probe, layout, micro):
     """The SDPA-backward launches of the TIMED steps themselves (events recorded by kernels._SdpaCausal.backward on the launch
     stream): algorithmic FLOPs = 2.5 x 4 D x visible pairs x H per sequence, over the summed launch time.  `micro` (the same
     kernels at the plain 8 x 2048 layer shape, timed after the steps) stays in the record for comparison with profiles/."""
-    flop = ms = rot = 0.0
+    flop = ms = 0.0
     kinds = {}
-    micro_rows = micro["shape"]["S"] * micro["shape"]["T"] * micro["shape"]["H"]
     for e0, e1, S, T, H, D, branched in probe:
         if branched and layout is not None and layout[0] == T and len(layout[1]) == S:
             pairs = sum(visible_pairs(T, a, b, n) for a, b, n in zip(*layout[1:]))
@@ -285,7 +271,6 @@ def in_step_roofline(probe, layout, micro):
         t = e0.elapsed_time(e1)
         flop += 2.5 * 4.0 * D * pairs * H
         ms += t
-        rot += max(0.0, micro.get("rotation_ms", 0.0)) * (S * T * H) / micro_rows      # (the rotation is per (row, head) work)
         k = kinds.setdefault("%dx%d%s" % (S, T, " packed" if branched else ""), [0, 0.0])
         k[0] += 1
         k[1] += t
@@ -299,25 +284,18 @@ def in_step_roofline(probe, layout, micro):
                                                                                  "the step's SDPA-backward dispatches"),
                 "achieved": round(flop / ms / 1e9, 2), "frac": round(flop / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
                 "launch_ms": round(ms / len(probe), 3), "launches": len(probe),
-                "frac_attention_only_estimate": round(flop / max(ms - rot, 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 4),
-                "rotation_ms_per_call_estimate": round(rot / len(probe), 4),
                 "kernel": "sdpa_causal_bwd_rope (one C-ABI call, halva_sdpa_branch_bwd_rope = delta + dK/dV(+dS store) + dQ=dS.K launches, D=128, "
                           "with the inverse RoPE of dq / dk inside the store epilogues)",
                 "scope_note": "from round 5 on the timed call includes the inverse rotation of dq / dk (rounds 1-4: a separate rope_qk launch of "
                               "~0.23 ms per call OUTSIDE these events, profiles/r04_step_summary.md); the FLOP count is unchanged (attention only), "
-                              "so `frac` is not comparable with the rounds before at equal kernel speed: `frac_attention_only_estimate` subtracts the "
-                              "rotation's cost as measured after the steps at the micro shape (microbench.rotation_ms, scaled by rows x heads) - an "
-                              "estimate, comparable with the rounds before; profiles/r05_ab_rope_dq3.log has the same-box A/B "
-                              "(HALVA_ROPE_FUSED_BWD=0 runs the rotation as its own launch inside the same call)",
+                              "so `frac` carries the rotation's cost: 0.02 - 0.06 ms per call at these shapes (profiles/r05_rope_cost.log: HIP events, same "
+                              "process, alternating; 0.18 - 0.28 ms as a launch of its own, HALVA_ROPE_FUSED_BWD=0) - about 0.005 of `frac`",
                 "measured": "HIP events around every sdpa_causal_bwd launch of the timed steps (launch stream); FLOPs of the layouts "
                             "actually run: " + ", ".join("%s: %d launches avg %.3f ms" % (k, v[0], v[1] / v[0]) for k, v in kinds.items()),
                 "microbench": {"shape": micro["shape"], "achieved": micro["achieved"], "frac": micro["frac"], "launch_ms": micro["launch_ms"],
-                               "with_rotation_launch_ms": micro.get("with_rotation_launch_ms"), "rotation_ms": micro.get("rotation_ms"),
                                "traffic": micro["traffic"],
                                "note": "same kernels at the plain per-layer shape the traffic counters were collected on"}})
     out.pop("shape", None)
-    out.pop("with_rotation_launch_ms", None)      # (micro-shape figures: they live under "microbench")
-    out.pop("rotation_ms", None)
     return out
 
 
