@@ -221,22 +221,23 @@ def test_lm_head_logp_and_kl_across_a_chunk_boundary_match_the_oracle():
     kl.backward()
     torch.cuda.synchronize()
     dh_kl = hp2.grad.float().cpu()
-    # oracle: [1, rows + 1, V] logits with labels shifted by one (cal_batch_logp gathers logits[:, :-1] at labels[:, 1:])
+    # oracle: ONE [rows, V] fp32 logits matrix serves both heads ([1, rows + 1, V] with labels shifted by one for cal_batch_logp, which gathers
+    # logits[:, :-1] at labels[:, 1:])
     ho = h_pol.float().requires_grad_(True)
-    logits = torch.cat([ho @ Wp.float().t(), torch.zeros(1, V)])[None]
+    pol_logits = ho @ Wp.float().t()
     labels = torch.cat([torch.tensor([-100]), tgt])[None]
-    lo = odpa.cal_batch_logp(logits, labels)[0]
-    lo.backward(gl)
+    lo = odpa.cal_batch_logp(torch.cat([pol_logits, torch.zeros(1, V)])[None], labels)[0]
+    lo.backward(gl, retain_graph=True)
     d_lp = (lp.detach().float().cpu() - lo.detach()).abs()
     print("lm_head_logp: mean |diff| %.2e max %.2e; dh rel %.2e" % (float(d_lp.mean()), float(d_lp.max()), rel_err(dh_logp, ho.grad)))
     assert float(d_lp.mean()) < 4e-3 and float(d_lp.max()) < 4e-2      # bf16 logits: |logit| 2^-9 per entry
     assert rel_err(dh_logp, ho.grad) < 2e-2
-    del logits, lo
-    ho2 = h_pol.float().requires_grad_(True)
-    pol_logits = (ho2 @ Wp.float().t())[None]
-    ref_logits = (h_ref.float() @ Wp.float().t())[None]
-    klo = odpa.kl_to_reference(pol_logits, ref_logits, torch.zeros(1, rows, dtype=torch.long))      # every row counts; B = 1
+    del lo
+    ho.grad = None
+    with torch.no_grad():
+        ref_logits = (h_ref.float() @ Wp.float().t())[None]
+    klo = odpa.kl_to_reference(pol_logits[None], ref_logits, torch.zeros(1, rows, dtype=torch.long))      # every row counts; B = 1
     klo.backward()
-    print("lm_head_kl: product %.4f oracle %.4f; dh rel %.2e" % (float(kl), float(klo), rel_err(dh_kl, ho2.grad)))
-    assert abs(float(kl) - float(klo)) < 1e-2 * abs(float(klo))
-    assert rel_err(dh_kl, ho2.grad) < 2e-2
+    print("lm_head_kl: product %.4f oracle %.4f; dh rel %.2e" % (float(kl.detach()), float(klo.detach()), rel_err(dh_kl, ho.grad)))
+    assert abs(float(kl.detach()) - float(klo.detach())) < 1e-2 * abs(float(klo.detach()))
+    assert rel_err(dh_kl, ho.grad) < 2e-2
