@@ -114,6 +114,40 @@ def test_packed_vila_row_T4096_H40():
         del r, ref
 
 
+@pytest.mark.parametrize("layout", ["packed_bench_row", "plain_T2048"])
+def test_inverse_rope_epilogues_equal_the_separate_launch_at_the_bench_shapes(layout, monkeypatch):
+    """halva_sdpa_branch_bwd_rope at the step's own launches (32 heads; the packed row [668 | 1380 | 1380] with its positions implied by the branch
+    points; two plain rows of 2048): dq / dk with the inverse rotation applied inside sdpa_bwd_dq2's / sdpa_bwd_dkv3's store epilogues - the table rows
+    fetched coalesced through LDS - must carry the BITS of halva_sdpa_branch_bwd_ws followed by the separate rotation launch (HALVA_ROPE_FUSED_BWD=0)."""
+    from halva_amd import kernels as HK
+    H, D = 32, 128
+    if layout == "packed_bench_row":
+        S, T, br = 1, 3428, ([668], [2048])
+    else:
+        S, T, br = 2, 2048, None
+    g = torch.Generator().manual_seed(41)
+    qkv = bf(torch.randn(S, T, 3, H, D, generator=g))
+    dout = bf(torch.randn(S, T, H, D, generator=g))
+    cos, sin = HK.rope_tables(D, 4096, device=DEV)
+    mk = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    branch = None
+    if br is not None:
+        pos = torch.cat([torch.arange(br[1][0]), br[0][0] + torch.arange(T - br[1][0])]).to(torch.int32)
+        branch = (mk(br[0]), mk(br[1]), pos.to(DEV))
+
+    def grads(fused):
+        monkeypatch.setenv("HALVA_ROPE_FUSED_BWD", "1" if fused else "0")
+        qg = qkv.to(DEV).view(S, T, 3 * H * D).clone().requires_grad_(True)
+        out = HK.attention(qg * 1, cos, sin, mk([0] * S), mk([T] * S), H, D, None, branch)
+        out.backward(dout.to(DEV).view(S, T, H * D))
+        torch.cuda.synchronize()
+        return qg.grad.clone()
+
+    a, b = grads(True), grads(False)
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+
+
 def _bwd_bits(S, T, H, D, lens, starts, br, seed, env):
     import os
     old = {k: os.environ.get(k) for k in env}
