@@ -51,3 +51,29 @@ def test_pack_pairs_truncated_rows():
     assert plan.T == 9
     pk = SP.pack_pairs(plan, align=4)
     assert pk.br_a.tolist() == [7] and pk.br_b.tolist() == [12] and pk.seq_len.tolist() == [14]      # 1 + 4 patches + "5 6" shared
+
+
+def test_positions_follow_from_the_branch_points():
+    """halva_sdpa_branch_bwd_rope / halva_rope_qk_branch (round 5) take no position table: row t of a packed row sits at position t, and at
+    br_a + (t - br_b) once t >= br_b (csrc/sdpa.hip:rope_position).  That must be what pack_pairs writes into `pos` for EVERY row that carries a
+    token (the padding rows between the correct rest and br_b carry zero vectors: their gradients are exactly zero, their position is immaterial)."""
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        g = int(rng.integers(1, 4))
+        pos, neg = [], []
+        for _ in range(g):
+            n_pre = int(rng.integers(2, 9))
+            pre = [1] + list(rng.integers(3, 50, n_pre)) + [-200] + list(rng.integers(3, 50, int(rng.integers(1, 6))))
+            pos.append(pre + list(rng.integers(3, 50, int(rng.integers(1, 40)))) + [2])
+            neg.append(pre + list(rng.integers(50, 99, int(rng.integers(1, 40)))) + [2])
+        plan = _plan(pos + neg, n_patch=int(rng.integers(1, 6)))
+        pk = SP.pack_pairs(plan, align=64)
+        P = pk.src.numpy().reshape(g, pk.T)
+        pp = pk.pos.numpy().reshape(g, pk.T)
+        for i in range(g):
+            a, b, n = int(pk.br_a[i]), int(pk.br_b[i]), int(pk.seq_len[i])
+            t = np.arange(pk.T)
+            formula = np.where(t >= b, a + (t - b), t)
+            carries = (t < n) & (P[i] != -1)
+            np.testing.assert_array_equal(pp[i][carries], formula[carries])
+            assert b % 64 == 0 and a <= b
