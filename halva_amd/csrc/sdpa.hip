@@ -1569,6 +1569,9 @@ __device__ __forceinline__ int ds_piece_off(int key, int qgroup) {      // byte 
 // factor of two by an XOR of the chunk position, applied by the LDS-DMA lanes (lane l fetches chunk l ^ swizzle; LDS-DMA writes lane l to
 // byte 16 l) - zero conflicts, but the requests no longer ask for their 1 KiB in lane order and the kernel, which is HBM-bound, ran 1.6 % SLOWER
 // (950-959 -> 971-973 us at the step's shapes, same box).
+#ifndef DQ2_FAST_TILE
+#define DQ2_FAST_TILE 1      // (0: every tile through the general per-strip path, as before round 5)
+#endif
 #ifndef HALVA_DQ2_DS_POLICY
 #define HALVA_DQ2_DS_POLICY " nt"      // (experiments/ds_residency builds it with "" as well)
 #endif
@@ -1616,9 +1619,13 @@ __device__ __forceinline__ void sdpa_bwd_dq2_block(const SdpaParams& p, char* sm
         return wave_in_b && k0 >= br.a && k0 + 31 < br.b;
     };
     // requests of one tile by this wave: its 2 chunks of the shared K tile, and - while the tile is live for it - its own 4 KiB of dS
+    // (-DHALVA_DQ2_DIAG=<bits>, timing experiments only - results are wrong: 1 no matrix work, 2 no dS requests, 4 no K requests, 8 no barriers)
+#ifndef HALVA_DQ2_DIAG
+#define HALVA_DQ2_DIAG 0
+#endif
     auto stage = [&](int kt, int slot) {
-        stage_tile_dma<D, NW>(k_lds + slot * TILE_BYTES, kp, p.ld_qkv, krow0, kt * BN - start, len, wave, lane);
-        if (tile_live(kt)) {
+        if (!(HALVA_DQ2_DIAG & 4)) stage_tile_dma<D, NW>(k_lds + slot * TILE_BYTES, kp, p.ld_qkv, krow0, kt * BN - start, len, wave, lane);
+        if (!(HALVA_DQ2_DIAG & 2) && tile_live(kt)) {
             const char* src = ds_pair + ((int64_t)(kt >> 1) * p.ds_nt + step) * 16384 + 2 * (kt & 1) * 4096 + sub * 2048;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {                 // strip c >> 1, register half c & 1
@@ -1635,6 +1642,12 @@ __device__ __forceinline__ void sdpa_bwd_dq2_block(const SdpaParams& p, char* sm
     // per-lane byte offsets of the transposed reads of dS^T (see frag_cols for the lane roles): key 8 jj + 4 hb + q4, query group 4 (g & 1) + pp
     const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3, hb = g >> 1;
     const int ds_rd0 = ds_lds_off(4 * hb + q4, 4 * (g & 1) + pp);           // jj = 0; jj = 1 adds 8 keys = 128 bytes
+    // frag_cols' addresses in the K tile, as two per-lane bases (jj = 0, 1: rows 8 jj + 4 hb + q4 of a 16-key group) + 4096 ks + 512 dt (tile_off)
+    const unsigned k_u32 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)k_lds;
+    unsigned klane[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+        klane[jj] = 2048 * jj + 64 * (4 * hb + q4) + 16 * ((2 * (g & 1) + (pp >> 1)) ^ ((2 * jj + hb) & 3)) + 8 * (pp & 1);
     // A row block wholly in branch B never needs the key tiles that lie wholly inside [a, b) (the producer wrote no dS for them either):
     // the walk jumps from tile skip_lo - 1 to tile skip_hi, as the forward's does.  In the bench's packed rows [668 | 1380 | 1380] that
     // is 21 of the 33..54 tiles of each of the six B blocks - 30 % of this kernel's tile steps, each a 16-KiB K tile and up to 32 KiB
@@ -1661,16 +1674,76 @@ __device__ __forceinline__ void sdpa_bwd_dq2_block(const SdpaParams& p, char* sm
         const int slot = i % RING;
         // tile i has landed: everything but the requests of tile i + 1 (2 pieces, 6 while that tile is live for this wave)
         if (i + 1 < n_walk) {
-            if (tile_live(tile_at(i + 1))) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if (HALVA_DQ2_DIAG & 6) {      // (diagnostic builds: fewer requests per tile)
+                const bool live = tile_live(tile_at(i + 1));
+                if ((HALVA_DQ2_DIAG & 6) == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (HALVA_DQ2_DIAG & 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else if (live) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if (tile_live(tile_at(i + 1))) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        if (HALVA_DQ2_DIAG & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // ... for every wave; and tile i - 1 has been read by all
         if (i + 2 < n_walk) stage(tile_at(i + 2), (slot + 2) % RING);         // into the slot of tile i - 1
-        if (tile_live(kt)) {
+        if (!(HALVA_DQ2_DIAG & 1) && tile_live(kt)) {
             const char* ktile = k_lds + slot * TILE_BYTES;
             const char* dst_t = ds_lds + slot * DS_LDS_SLOT;
+            if (DQ2_FAST_TILE && !SLOW_TR) {
+                // All 40 operand reads of the tile from three per-lane bases + immediates, asked for ahead of the 16 products (the same products in the
+                // same order as the general path below: identical sums).  Compiled from the loop below, every product waited for operand reads issued just
+                // in front of it (s_waitcnt lgkmcnt(0) x 16 per tile) and each read cost two vector instructions of address arithmetic: without any dS
+                // traffic at all the kernel still took 0.82 of its time (experiments/ds_residency: dq2 anatomy by removal, profiles/r05_dq2_anatomy.log).
+                const unsigned a0 = k_u32 + slot * TILE_BYTES + klane[0], a1 = k_u32 + slot * TILE_BYTES + klane[1];
+                const unsigned da = ds_dst + slot * DS_LDS_SLOT + ds_rd0;
+                auto rd = [](unsigned addr) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)addr); };
+                s16x4 zt[4][2], kt4[4][DT][2];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    zt[ks][0] = rd(da + (ks >> 1) * DS_LDS_STRIP + 256 * (ks & 1));
+                    zt[ks][1] = rd(da + (ks >> 1) * DS_LDS_STRIP + 256 * (ks & 1) + 128);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        kt4[ks][dt][0] = rd(a0 + 4096 * ks + 512 * dt);
+                        kt4[ks][dt][1] = rd(a1 + 4096 * ks + 512 * dt);
+                    }
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    s16x8 zb;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) zb[j] = zt[ks][0][j], zb[4 + j] = zt[ks][1][j];
+                    // a strip the branch mask hides wholly was never written by the producer: its bytes are whatever the workspace held - zeros instead
+                    // (the general path skips its products; adding exact zeros leaves the sums as they are).  ONE path for every tile: with a second one
+                    // the accumulators changed registers between the two (32 moves per tile).
+                    // Branch-free (an AND with a scalar mask): the tile stays one basic block and the order asked for below holds.
+                    {
+                        u32x4 w = __builtin_bit_cast(u32x4, zb);
+                        const unsigned keep = strip_hidden(kt, ks >> 1) ? 0u : 0xffffffffu;
+                        w[0] &= keep, w[1] &= keep, w[2] &= keep, w[3] &= keep;
+                        zb = __builtin_bit_cast(s16x8, w);
+                    }
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        s16x8 ka;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ka[j] = kt4[ks][dt][0][j], ka[4 + j] = kt4[ks][dt][1][j];
+                        acc[dt] = mfma32(ka, zb, acc[dt]);
+                    }
+                }
+                // the order asked of the scheduler: ten reads (the first product's operands and the next one's), then a product per two reads
+                __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
+#pragma unroll
+                for (int i = 0; i < 13; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            } else
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {               // 16 keys each: strip ks >> 1, half ks & 1
                 if (strip_hidden(kt, ks >> 1)) continue;
