@@ -257,6 +257,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const GemmParams p) {
         request(it + NST - 1, (it + NST - 1) % NST);
         const char* at = a_lds + (it % NST) * TILE;
         const char* bt = b_lds + (it % NST) * TILE;
+#ifdef HALVA_WGRAD_DIAG_NOMFMA      // (timing experiment: the request path alone; results are wrong)
+        if (p.K < 0)
+#endif
 #pragma unroll
         for (int ks = 0; ks < KT / 16; ++ks) {
             s16x8 af[2], bf[2];
