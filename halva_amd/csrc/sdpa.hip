@@ -1579,7 +1579,7 @@ constexpr int DS_LDS_PIECE = 1024 + 128, DS_LDS_STRIP = 2 * DS_LDS_PIECE, DS_LDS
 __device__ __forceinline__ int ds_lds_off(int key, int qgroup) {      // (inside a strip)
     return DS_LDS_PIECE * (qgroup >> 2) + 16 * (key + 32 * (qgroup & 1)) + 8 * ((qgroup >> 1) & 1);
 }
-template <int D, bool SLOW_TR>
+template <int D, bool SLOW_TR, bool FAST>
 __device__ __forceinline__ void sdpa_bwd_dq2_block(const SdpaParams& p, char* smem, int s, int hd, int qb, int wave, int lane) {
     constexpr int NW = 8, BN = 64, DT = D / 32, BM = 32 * NW, RING = 3;
     constexpr int TILE_BYTES = BN * D * 2;
@@ -1692,7 +1692,7 @@ __device__ __forceinline__ void sdpa_bwd_dq2_block(const SdpaParams& p, char* sm
         if (!(HALVA_DQ2_DIAG & 1) && tile_live(kt)) {
             const char* ktile = k_lds + slot * TILE_BYTES;
             const char* dst_t = ds_lds + slot * DS_LDS_SLOT;
-            if (DQ2_FAST_TILE && !SLOW_TR) {
+            if (DQ2_FAST_TILE && FAST && !SLOW_TR) {
                 // All 40 operand reads of the tile from three per-lane bases + immediates, asked for ahead of the 16 products (the same products in the
                 // same order as the general path below: identical sums).  Compiled from the loop below, every product waited for operand reads issued just
                 // in front of it (s_waitcnt lgkmcnt(0) x 16 per tile) and each read cost two vector instructions of address arithmetic: without any dS
@@ -1784,7 +1784,7 @@ __device__ __forceinline__ void sdpa_bwd_dq2_block(const SdpaParams& p, char* sm
     if (q_valid) store_rows_T<D>(dq_row, acc, p.scale, true, lane);
 }
 
-template <int D, bool SLOW_TR>
+template <int D, bool SLOW_TR, bool FAST = true>      // (FAST = false: every tile through the general per-strip loop - HALVA_DQ2_FAST_TILE=0, the bitwise twin of the fast tile)
 __global__ __launch_bounds__(512) void sdpa_bwd_dq2_kernel(const SdpaParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1795,7 +1795,7 @@ __global__ __launch_bounds__(512) void sdpa_bwd_dq2_kernel(const SdpaParams p) {
     const int npass = (heavy != light) ? 2 : 1;
     WG_CLOCK_BEGIN();
 #pragma unroll 1
-    for (int pass = 0; pass < npass; ++pass) sdpa_bwd_dq2_block<D, SLOW_TR>(p, smem, s, hd, pass ? light : heavy, wave, lane);
+    for (int pass = 0; pass < npass; ++pass) sdpa_bwd_dq2_block<D, SLOW_TR, FAST>(p, smem, s, hd, pass ? light : heavy, wave, lane);
     WG_CLOCK_END(p.dbg, 2);
 }
 
@@ -1999,8 +1999,9 @@ int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st, bool* fused_rope =
         }
 #endif
         const size_t lds_dq2 = 3 * 64 * D * 2 + 8 * 3 * DS_LDS_SLOT;
-        return slow ? launch_one(sdpa_bwd_dq2_kernel<D, true>, p, true, 256, 512, lds_dq2, S, st, "sdpa_bwd_dq2")
-                    : launch_one(sdpa_bwd_dq2_kernel<D, false>, p, true, 256, 512, lds_dq2, S, st, "sdpa_bwd_dq2");
+        if (slow) return launch_one(sdpa_bwd_dq2_kernel<D, true>, p, true, 256, 512, lds_dq2, S, st, "sdpa_bwd_dq2");
+        return env_flag_on("HALVA_DQ2_FAST_TILE") ? launch_one(sdpa_bwd_dq2_kernel<D, false>, p, true, 256, 512, lds_dq2, S, st, "sdpa_bwd_dq2")
+                                                  : launch_one(sdpa_bwd_dq2_kernel<D, false, false>, p, true, 256, 512, lds_dq2, S, st, "sdpa_bwd_dq2 (general tile)");
     }
     const int rc = slow ? launch_one(sdpa_bwd_dq_kernel<D, CAUSAL, true, 8>, p, CAUSAL, 256, 512, lds_dq, S, st, "sdpa_bwd_dq")
                         : launch_one(sdpa_bwd_dq_kernel<D, CAUSAL, false, 8>, p, CAUSAL, 256, 512, lds_dq, S, st, "sdpa_bwd_dq");

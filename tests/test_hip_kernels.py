@@ -148,6 +148,39 @@ def test_rope_forward_and_inverse():
 
 
 @pytest.mark.parametrize("layout", ["plain_ragged", "left_padded", "packed", "packed_long"])
+def test_dq2_fast_tile_equals_the_general_tile_bit_for_bit(layout, monkeypatch):
+    """sdpa_bwd_dq2's fast tile (round 5: a tile's 40 operand reads issued ahead of its 16 products, a hidden strip's operand zeroed by a mask instead of its
+    products branched over) against the general per-strip loop it replaced (HALVA_DQ2_FAST_TILE=0: sdpa_bwd_dq2_kernel<D, false, false>): the same products in
+    the same order - the gradient of q, k and v must agree bit for bit, packed rows with wholly and partly hidden strips included."""
+    from halva_amd import kernels as HK
+    H, D = 2, 128
+    if layout == "plain_ragged":
+        S, T, lens, starts, br = 3, 700, [700, 411, 64], [0, 0, 0], None
+    elif layout == "left_padded":
+        S, T, lens, starts, br = 2, 600, [600, 531], [0, 69], None
+    elif layout == "packed":
+        S, T, lens, starts, br = 2, 1100, [1100, 1003], [0, 0], ([130, 100], [512, 420])
+    else:
+        S, T, lens, starts, br = 1, 3428, [3428], [0], ([668], [2048])
+    g = torch.Generator().manual_seed(23)
+    qkv = bf(torch.randn(S, T, 3 * H * D, generator=g)).to(DEV)
+    dout = bf(torch.randn(S, T, H * D, generator=g)).to(DEV)
+    mk = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    a_b = (None, None) if br is None else (mk(br[0]), mk(br[1]))
+
+    def grads(fast):
+        monkeypatch.setenv("HALVA_DQ2_FAST_TILE", "1" if fast else "0")
+        qg = qkv.clone().requires_grad_(True)
+        HK.sdpa_causal(qg, mk(starts), mk(lens), H, D, *a_b).backward(dout)
+        torch.cuda.synchronize()
+        return qg.grad.clone()
+
+    a, b = grads(True), grads(False)
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+
+
+@pytest.mark.parametrize("layout", ["plain_ragged", "left_padded", "packed", "packed_long"])
 def test_inverse_rope_in_the_backward_epilogues_equals_the_separate_launch(layout, monkeypatch):
     """halva_sdpa_branch_bwd_rope (round 5): the inverse rotation of dq / dk applied inside sdpa_bwd_dq2's and sdpa_bwd_dkv3's store epilogues must
     give the BITS of the separate halva_rope_qk launch it replaces (same roundings, same expression: common.h rope_pair) - positions of packed rows
