@@ -507,9 +507,16 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
 #endif
             const bool key_hidden = kl >= br.a && kl < br.b;
             const bool block_all_keys_valid = kblk_min >= 0 && kblk_min + 128 <= len;      // workgroup-uniform: no padded key in the block
+#ifdef DKV3_DIAG_SAME_HEAD      // (timing experiment, results wrong: every item reads the Q / dO tiles of sequence 0, head 0 - 1 MiB, resident in every L2:
+                                // what would PERFECT reuse of the tiles among an XCD's workgroups buy?)
+            const bf16_t* qp = qp0;
+            const bf16_t* dop = dop0;
+            const int64_t qrow0 = cur.start;
+#else
             const bf16_t* qp = qp0 + hd * D;
             const bf16_t* dop = dop0 + hd * D;
             const int64_t qrow0 = seq_row0 + cur.start;
+#endif
             // the statistics of this (sequence, head), 512 bytes per 64-row step in sequence coordinates (sdpa.hip:sdpa_bwd_delta_kernel), as a buffer
             // descriptor: a step past the sequence brings zeros; lanes 32..63 of a request lie outside it on purpose (they fill the unused half of the slot)
             const unsigned long long st_base = (unsigned long long)(size_t)(p.lse2 + ((int64_t)s * p.H + hd) * p.stat_nt * 128);
@@ -521,8 +528,13 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
             const unsigned q_rec = len > 0 ? (unsigned)((int64_t)(len - 1) * p.ld_qkv * 2 + D * 2) : 0u;
             const unsigned do_rec = len > 0 ? (unsigned)((int64_t)(len - 1) * p.ld_do * 2 + D * 2) : 0u;
             // the next item's first tiles (requested by this item's last asm call)
+#ifdef DKV3_DIAG_SAME_HEAD
+            const int64_t nrow0 = nxt.start;
+            const unsigned long long nq_ptr = (unsigned long long)(size_t)(qp0 + nrow0 * p.ld_qkv), ndo_ptr = (unsigned long long)(size_t)(dop0 + nrow0 * p.ld_do);
+#else
             const int64_t nrow0 = (int64_t)nxt.s * p.T + nxt.start;
             const unsigned long long nq_ptr = (unsigned long long)(size_t)(qp0 + nxt.hd * D + nrow0 * p.ld_qkv), ndo_ptr = (unsigned long long)(size_t)(dop0 + nxt.hd * D + nrow0 * p.ld_do);
+#endif
             const unsigned nqrec = nxt.len > 0 ? (unsigned)((int64_t)(nxt.len - 1) * p.ld_qkv * 2 + D * 2) : 0u;
             const unsigned ndorec = nxt.len > 0 ? (unsigned)((int64_t)(nxt.len - 1) * p.ld_do * 2 + D * 2) : 0u;
             const unsigned nqsoff = (unsigned)((int64_t)nxt.q_begin * p.ld_qkv * 2), ndosoff = (unsigned)((int64_t)nxt.q_begin * p.ld_do * 2);
