@@ -65,6 +65,20 @@ WAIT_GAP = 64 - LOOKAHEAD - 1
 # last tile (7: none), bit 8 the run's last request is the partial
 # last tile, bits 9-10 ring slot of the first step's tile;  s97 takes the field being looked at
 CTL_NPRO, CTL_PROALT = "s_bfe_u32 s97, %[ctl], 0x20001", "s_bfe_u32 s97, %[ctl], 0x30003"
+# Round 6: the ITEM RECORD.  Everything about an item (sequence, head, key block) that is uniform over the workgroup - its geometry, the run lengths
+# of its first call, the bases / extents of its buffer descriptors, its dS strip, its K / dK rows - is worked out ONCE, by the delta pass of the same
+# C-ABI call (sdpa.hip:dkv3_build_record), as 64 dwords in queue order.  A wave holds an item's record in ONE vector register (lane l = dword l,
+# a ds_read_b32 of the workgroup's mail box) and the block picks its fields with v_readlane_b32; before, ~1 450 compiler instructions per item
+# re-derived them (profiles/r06_dkv3_anatomy.log: 6 600 cycles in front of every block with nothing to overlap them).  REC: dword index by name.
+REC_FIELDS = ["valid", "s", "hd", "kb", "start", "len", "br_a", "br_b", "kblk_min", "q_begin", "ntiles", "last_partial", "lr", "prefetchable",
+              "n02", "n1", "t_side", "ndma", "part", "ctl0",
+              "q_lo", "q_hi", "do_lo", "do_hi", "q_rec", "do_rec", "q_soff0", "do_soff0", "q_soff3", "do_soff3",
+              "st_lo", "st_hi", "st_rec", "st_soff0", "st_soff3", "ds_lo", "ds_hi", "k_lo", "k_hi", "dk_lo", "dk_hi",
+              "rope_pos0", "rope_pos1", "rope_pos2", "rope_pos3", "rows_ok0", "rows_ok1", "rows_ok2", "rows_ok3", "q_in_b0", "all_valid"]
+REC = {n: i for i, n in enumerate(REC_FIELDS)}
+assert len(REC) <= 64
+MAIL_LDS = 131072 + 4096             # DKV3_SCHED (sdpa_dkv3.h): two records of 256 bytes
+V_RECLOAD = RING + 8                 # v[184:187]: wave 0's lanes 0..15 fetch the record of the item after next here (prologue of a block's first call)
 DMA_GAPS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]      # the quiet head of the step (no vector work yet): tile t+3 into the slot tile t-1 left at the last barrier
 
 
@@ -212,11 +226,13 @@ def dma_groups():
     ool += [".Ldkv3_sw%s_%%=:" % PHASE, "s_bitcmp1_b32 %s, 16" % S_DMALEFT, "s_cbranch_scc1 .Ldkv3_swb%s_%%=" % PHASE,      # already switched: nothing left
             "s_lshr_b32 %s, %s, 8" % (S_DMALEFT, S_DMALEFT), "s_or_b32 %s, %s, 0x10000" % (S_DMALEFT, S_DMALEFT),
             "s_and_b32 s97, %s, 0xff" % S_DMALEFT, "s_cmp_eq_u32 s97, 0", "s_cbranch_scc1 .Ldkv3_swb%s_%%=" % PHASE]            # no next item to serve
-    ool += ["v_readfirstlane_b32 s%d, %%[nq_lo]" % QDESC[0], "v_readfirstlane_b32 s%d, %%[nq_hi]" % (QDESC[0] + 1), "v_readfirstlane_b32 s%d, %%[nqrec]" % (QDESC[0] + 2),
-            "v_readfirstlane_b32 s%d, %%[ndo_lo]" % DDESC[0], "v_readfirstlane_b32 s%d, %%[ndo_hi]" % (DDESC[0] + 1), "v_readfirstlane_b32 s%d, %%[ndorec]" % (DDESC[0] + 2),
-            "v_readfirstlane_b32 %s, %%[nqsoff]" % S_SOFFQ, "v_readfirstlane_b32 %s, %%[ndosoff]" % S_SOFFD,
-            "v_readfirstlane_b32 s%d, %%[nst_lo]" % SDESC[0], "v_readfirstlane_b32 s%d, %%[nst_hi]" % (SDESC[0] + 1), "v_readfirstlane_b32 s%d, %%[nst_rec]" % (SDESC[0] + 2),
-            "v_readfirstlane_b32 %s, %%[nst_soff]" % S_SOFFS]
+    def nrl(sreg, field):
+        return "v_readlane_b32 %s, %%[nrec], %d" % (sreg, REC[field])
+    ool += [nrl("s%d" % QDESC[0], "q_lo"), nrl("s%d" % (QDESC[0] + 1), "q_hi"), nrl("s%d" % (QDESC[0] + 2), "q_rec"),
+            nrl("s%d" % DDESC[0], "do_lo"), nrl("s%d" % (DDESC[0] + 1), "do_hi"), nrl("s%d" % (DDESC[0] + 2), "do_rec"),
+            nrl(S_SOFFQ, "q_soff0"), nrl(S_SOFFD, "do_soff0"),
+            nrl("s%d" % SDESC[0], "st_lo"), nrl("s%d" % (SDESC[0] + 1), "st_hi"), nrl("s%d" % (SDESC[0] + 2), "st_rec"),
+            nrl(S_SOFFS, "st_soff0")]
     ool += ["s_nop 3", "s_branch .Ldkv3_swb%s_%%=" % PHASE]
     return groups, ool
 
@@ -384,13 +400,16 @@ def main():
            "s_bfe_u32 %s, %%[ctl], 0x20009" % S_SLOT, "s_mov_b32 %s, %%32" % S_DMALEFT] + \
           ["v_readfirstlane_b32 s%d, %%[ds_%s]" % (DSP[w], "lo" if w == 0 else "hi") for w in (0, 1)] + [
            # the statistics of this (sequence, head): 512 bytes per 64-row step from the sequence's first row on; st_soff: the first step to request
-           "v_readfirstlane_b32 s%d, %%[st_lo]" % SDESC[0], "v_readfirstlane_b32 s%d, %%[st_hi]" % (SDESC[0] + 1), "v_readfirstlane_b32 s%d, %%[st_rec]" % (SDESC[0] + 2),
+           "v_readlane_b32 s%d, %%[rec], %d" % (SDESC[0], REC["st_lo"]), "v_readlane_b32 s%d, %%[rec], %d" % (SDESC[0] + 1, REC["st_hi"]),
+           "v_readlane_b32 s%d, %%[rec], %d" % (SDESC[0] + 2, REC["st_rec"]),
            "s_mov_b32 s%d, 0x00020000" % (SDESC[0] + 3), "v_readfirstlane_b32 %s, %%[st_soff]" % S_SOFFS,
            # the sequence's Q / dO rows of this head as buffer descriptors (base, 0 stride, bytes up to the end of the last row, raw 32-bit format);
            # q_soff / do_soff: the first tile to request, in bytes from the sequence's first row
-           "v_readfirstlane_b32 s%d, %%[q_lo]" % QDESC[0], "v_readfirstlane_b32 s%d, %%[q_hi]" % (QDESC[0] + 1), "v_readfirstlane_b32 s%d, %%[q_rec]" % (QDESC[0] + 2),
+           "v_readlane_b32 s%d, %%[rec], %d" % (QDESC[0], REC["q_lo"]), "v_readlane_b32 s%d, %%[rec], %d" % (QDESC[0] + 1, REC["q_hi"]),
+           "v_readlane_b32 s%d, %%[rec], %d" % (QDESC[0] + 2, REC["q_rec"]),
            "s_mov_b32 s%d, 0x00020000" % (QDESC[0] + 3),
-           "v_readfirstlane_b32 s%d, %%[do_lo]" % DDESC[0], "v_readfirstlane_b32 s%d, %%[do_hi]" % (DDESC[0] + 1), "v_readfirstlane_b32 s%d, %%[do_rec]" % (DDESC[0] + 2),
+           "v_readlane_b32 s%d, %%[rec], %d" % (DDESC[0], REC["do_lo"]), "v_readlane_b32 s%d, %%[rec], %d" % (DDESC[0] + 1, REC["do_hi"]),
+           "v_readlane_b32 s%d, %%[rec], %d" % (DDESC[0] + 2, REC["do_rec"]),
            "s_mov_b32 s%d, 0x00020000" % (DDESC[0] + 3),
            "v_readfirstlane_b32 %s, %%[q_soff]" % S_SOFFQ, "v_readfirstlane_b32 %s, %%[do_soff]" % S_SOFFD,
 
@@ -405,7 +424,11 @@ def main():
     # the s_waitcnt vmcnt(0) below and leaves the block as an ordinary output.  Asked for by the compiler's own atomic it had to be waited for
     # with vmcnt(0) in the middle of the next round (the compiler cannot count past an asm block): ~6 000 cycles per item.
     pro += ["s_cmp_lg_u32 %[wave], 0", "s_cbranch_scc1 .Ldkv3_nodraw_%=", "s_mov_b64 %s, exec" % sp(SRC), "s_mov_b64 exec, 1", "v_mov_b32_e32 v%d, 1" % RING,
-            "global_atomic_add %%[drawn], %%[sched_ptr], v%d, off sc0" % RING, "s_mov_b64 exec, %s" % sp(SRC), ".Ldkv3_nodraw_%=:"]
+            "global_atomic_add %%[drawn], %%[sched_ptr], v%d, off sc0" % RING,
+            # ... and its lanes 0..15 fetch the RECORD of the item after next (rec_ptr: record + 16 lane; thread 0 turned the previous answer of the
+            # counter into a record index in front of the block): 256 bytes that come back under the same wait and go into the mail box below
+            "s_mov_b64 exec, 0xffff", "global_load_dwordx4 %s, %%[rec_ptr], off" % vr(V_RECLOAD, 4),
+            "s_mov_b64 exec, %s" % sp(SRC), ".Ldkv3_nodraw_%=:"]
     # (an accumulator tuple operand cannot be sliced into single registers from here: it is zeroed by an MFMA of zero fragments, D = 0 * 0 + 0)
     pro += ["v_mov_b32_e32 v%d, 0" % (RING + j) for j in range(4)] + ["s_nop 4"]
     for opnd in range(8):
@@ -420,7 +443,12 @@ def main():
             for k in range(4):
                 pro += ["buffer_load_dwordx4 %s, %s, %s offen lds" % (voff, sq(desc), soff), "s_add_u32 %s, %s, %s" % (soff, soff, piece), "s_add_u32 m0, m0, 4096", "s_nop 0"]
         pro += ["s_mov_b32 m0, %s" % S_DSTS, "s_nop 0", "buffer_load_dwordx4 %%[stat_voff], %s, %s offen lds" % (sq(SDESC), S_SOFFS), "s_add_u32 %s, %s, 512" % (S_SOFFS, S_SOFFS)]
-    pro += [".Ldkv3_prodone_%=:", "s_waitcnt vmcnt(0)", "s_barrier", ".Ldkv3_nofirst_%=:"]
+    # the mail box: slot ctl bit 11, 16 bytes per lane; every wave reads it (ds_read_b32, lane l = dword l) behind the round's last barrier
+    pro += [".Ldkv3_prodone_%=:", "s_waitcnt vmcnt(0)", "s_cmp_lg_u32 %[wave], 0", "s_cbranch_scc1 .Ldkv3_nomail_%=",
+            "s_bfe_u32 %s, %%[ctl], 0x1000b" % S_TMP, "s_lshl_b32 %s, %s, 8" % (S_TMP, S_TMP), "s_add_u32 %s, %s, %d" % (S_TMP, S_TMP, MAIL_LDS),
+            "v_add_u32_e32 v%d, %s, v%d" % (V_T, S_TMP, DSOFF), "s_mov_b64 %s, exec" % sp(SRC), "s_mov_b64 exec, 0xffff",
+            "ds_write_b128 v%d, %s" % (V_T, vr(V_RECLOAD, 4)), "s_mov_b64 exec, %s" % sp(SRC), ".Ldkv3_nomail_%=:",
+            "s_barrier", ".Ldkv3_nofirst_%=:"]
     pro += [i.text for i in addr_setup()]
     for n in range(LOOKAHEAD):
         pro += [l.text for l in a_loads(M[n]["a"], n % 8)]
@@ -459,6 +487,9 @@ def main():
     with open(os.environ.get("DKV3_OUT", "sdpa_dkv3_loop.inc").replace(".inc", "_clobbers.inc"), "w") as f:
         f.write("// generated by gen_dkv3_loop.py - do not edit\n")
         f.write(", ".join('"v%d"' % i for i in range(64, 223)) + ",\n" + ", ".join('"s%d"' % i for i in range(70, 100)) + ', "vcc", "scc", "memory"\n')
+    with open(os.environ.get("DKV3_OUT", "sdpa_dkv3_loop.inc").replace(".inc", "_rec.inc"), "w") as f:
+        f.write("// generated by gen_dkv3_loop.py - do not edit: dword index of every field of an item record (gen_dkv3_loop.py:REC_FIELDS)\n")
+        f.write("enum Dkv3Rec : int {\n" + "".join("    DKV3_REC_%s = %d,\n" % (n.upper(), i) for n, i in REC.items()) + "    DKV3_REC_DWORDS = 64\n};\n")
     print("%s: %d asm lines" % (out, len(lines)))
 
 

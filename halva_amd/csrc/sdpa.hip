@@ -87,6 +87,7 @@ struct SdpaParams {
     int stat_nt;          // records per (sequence, head) = ceil(T / 64)
     int sched_order;      // order of the items inside a queue (sdpa_dkv3.h)
     int* sched;           // sdpa_bwd_dkv3's eight work-queue counters, 128 B apart (behind lse2 in the workspace), zeroed by the delta pass
+    int* items;           // sdpa_bwd_dkv3's item records, 64 dwords each in queue order + one all-zero record (behind the counters), written by the delta pass
     const int32_t* seq_start;
     const int32_t* seq_len;
     const int32_t* br_a;  // optional per-sequence branch points (local indices; br_b a multiple of 64), include/halva_hip.h:
@@ -1505,14 +1506,21 @@ __global__ __launch_bounds__(512) void sdpa_bwd_dkv2_kernel(const SdpaParams p) 
 // ===================================================================================================
 // backward with a dS workspace: delta / zero-fill pass, then dK/dV (+ dS store), then dQ = dS K
 // ===================================================================================================
+#include "sdpa_dkv3_items.h"
 // delta[s, h, t] = sum_d dO o O for every valid query row (both later kernels read it), and zeros into dq of the PADDED rows (the dQ
 // kernel below walks a sequence in its own coordinates and only writes its valid rows).  One wave per (row, 4 heads); HBM-bound.
+// for_dkv3: also what sdpa_bwd_dkv3 needs before it starts - its work-queue counters zeroed and (round 6) its item records (sdpa_dkv3_items.h).
 template <int D>
 __global__ __launch_bounds__(256) void sdpa_bwd_delta_kernel(const SdpaParams p, int S, int for_dkv3) {
     constexpr int HPW = 512 / D;                       // heads per wave pass: 64 lanes x 8 elements
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (for_dkv3 && blockIdx.x == 0 && threadIdx.x < 8) p.sched[32 * threadIdx.x] = 0;
+    if (for_dkv3) {      // one thread per record (8 192 - 13 824 of them at the step's shapes: the first few dozen workgroups)
+        const int total = p.npairs * p.nblk;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i <= total; i += (int64_t)gridDim.x * 256)
+            dkv3_build_record<true>(p, (int)i, total, p.items + i * DKV3_REC_DWORDS);
+    }
     if (row >= (int64_t)S * p.T) return;
     const int s = (int)(row / p.T), t = (int)(row % p.T);
     const int start = p.seq_start ? p.seq_start[s] : 0;
@@ -1922,12 +1930,7 @@ int launch_fwd(const SdpaParams& p_in, int S, hipStream_t st) {
 // sdpa_bwd_dkv3: 4 waves, one per SIMD (512 registers), 128 keys per workgroup, 130 KiB of LDS (four Q / dO tile slots + statistics)
 template <bool CAUSAL>
 int launch_dkv3(SdpaParams p, int S, hipStream_t st, bool use_asm) {
-    p.nblk = (p.T + 127) / 128;
-    p.npairs = S * p.H;
-    {
-        const char* e = getenv("HALVA_DKV3_ORDER");
-        p.sched_order = e ? atoi(e) : (CAUSAL ? 2 : 0);
-    }
+    // (p.nblk / p.npairs / p.sched_order: set by launch_bwd in front of the delta pass, which writes the item records from them)
     static std::atomic<int> attr_set[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1977,6 +1980,13 @@ int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st, bool* fused_rope =
         const bool use_asm = env_flag_on("HALVA_DKV3_ASM");
         if (!(dkv3 && use_asm && !slow && env_flag_on("HALVA_ROPE_FUSED_BWD"))) p.rope_cos = p.rope_sin = nullptr;
         if (fused_rope) *fused_rope = p.rope_cos != nullptr;
+        if (dkv3) {
+            static_assert(CAUSAL || D != 128, "sdpa_bwd_dkv3's item records are written for the causal backward (dkv3_build_record<true>)");
+            p.nblk = (p.T + 127) / 128;
+            p.npairs = S * p.H;
+            const char* e = getenv("HALVA_DKV3_ORDER");
+            p.sched_order = e ? atoi(e) : (CAUSAL ? 2 : 0);
+        }
         hipLaunchKernelGGL((sdpa_bwd_delta_kernel<D>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, S, dkv3 ? 1 : 0);
         HALVA_CHECK_LAUNCH("sdpa_bwd_delta");      // (a failed launch would leave stale delta / unzeroed padded dq rows for the two kernels below)
         int rc2;
@@ -2077,11 +2087,12 @@ extern "C" int halva_sdpa_causal_bwd_ld(const void* qkv, const void* out, int64_
 
 static int64_t lse2_region_bytes(int S, int T, int H) { return (((int64_t)S * H * ((T + 63) / 64) * 512 + 256) + 127) / 128 * 128; }
 static int64_t ds_region_bytes(int S, int T, int H) { return (int64_t)S * H * ((T + 127) / 128) * ((T + 63) / 64) * 16384; }
+static int64_t items_region_bytes(int S, int T, int H) { return ((int64_t)S * H * ((T + 127) / 128) + 1) * 256; }      // sdpa_dkv3_items.h: one record per item + the empty one
 
 extern "C" int64_t halva_sdpa_bwd_ws_bytes(int S, int T, int H, int D) {
     if (D != 128) return 0;                                      // the dS path is the head_dim-128 instantiation; others use the 3-product dQ kernel
-    // dS, then [S, H, T] f32 lse * log2(e) for sdpa_bwd_dkv3 (+ one padding row), then its work-queue counters
-    return ds_region_bytes(S, T, H) + lse2_region_bytes(S, T, H) + 1024;
+    // dS, then [S, H, T] f32 lse * log2(e) for sdpa_bwd_dkv3 (+ one padding row), then its work-queue counters, then its item records
+    return ds_region_bytes(S, T, H) + lse2_region_bytes(S, T, H) + 1024 + items_region_bytes(S, T, H);
 }
 
 extern "C" int halva_sdpa_branch_bwd(const void* qkv, const void* out, int64_t ld_out, const void* dout, int64_t ld_dout,
@@ -2140,6 +2151,7 @@ extern "C" int halva_sdpa_branch_bwd_rope(const void* qkv, const void* out, int6
     p.ds_ws = D == 128 ? (char*)ds_ws : nullptr;
     p.lse2 = p.ds_ws ? reinterpret_cast<float*>(p.ds_ws + ds_region_bytes(S, T, H)) : nullptr;
     p.sched = p.ds_ws ? reinterpret_cast<int*>(p.ds_ws + ds_region_bytes(S, T, H) + lse2_region_bytes(S, T, H)) : nullptr;
+    p.items = p.ds_ws ? reinterpret_cast<int*>(p.ds_ws + ds_region_bytes(S, T, H) + lse2_region_bytes(S, T, H) + 1024) : nullptr;
     p.ds_nkb = (T + 127) / 128;
     p.ds_nt = (T + 63) / 64;
     p.stat_nt = (T + 63) / 64;

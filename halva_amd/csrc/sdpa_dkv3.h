@@ -25,8 +25,8 @@ constexpr int DKV3_TILE = 64 * 128 * 2;                      // one Q or dO tile
 constexpr int DKV3_DO = 4 * DKV3_TILE;                       // dO ring behind the Q ring
 constexpr int DKV3_LSE = 8 * DKV3_TILE;                      // [4][64] lse2, then [4][64] -delta
 constexpr int DKV3_ND = DKV3_LSE + 4 * 64 * 4;              // (the plain-HIP twin's own layout; the generated loop: four 1-KiB slots [lse2 x 64][-delta x 64][unused])
-constexpr int DKV3_SCHED = DKV3_LSE + 4096;                  // [2][8] ints: the persistent workgroup's item mail box
-constexpr int DKV3_STAGE = DKV3_SCHED + 128;                 // [4 waves][4 KiB]: a wave's staging area for its dK / dV rows (dkv3_store_rows_lds)
+constexpr int DKV3_SCHED = DKV3_LSE + 4096;                  // [2][64] ints: the persistent workgroup's item mail box (two item records, sdpa_dkv3_items.h; gen_dkv3_loop.py:MAIL_LDS)
+constexpr int DKV3_STAGE = DKV3_SCHED + 512;                 // [4 waves][4 KiB]: a wave's staging area for its dK / dV rows (dkv3_store_rows_lds)
 constexpr int DKV3_LDS = DKV3_STAGE + 4 * 4096;
 #ifndef DKV3_ROWS_VIA_LDS
 #define DKV3_ROWS_VIA_LDS 1      // 0: the dK / dV rows stored straight from the accumulator layout (store_rows_T), rounds 2-3
@@ -111,7 +111,7 @@ __device__ __forceinline__ unsigned dkv3_piece_voff(int64_t ld, int wave, int la
 // ROPE (round 5, the dK rows of halva_sdpa_branch_bwd_rope): the inverse rotation applied on the way (store_rows_T_rope's arithmetic: row rounded to
 // bf16, rotated with the bf16 table entries of the KEY's position, rounded again); elements d and d + 64 are the same register of tiles dt and dt + 2.
 // rope_cos / rope_sin: the wave's 4-KiB blocks of table rows in LDS (dkv3_rope_request_lds below), landed.
-template <bool ROPE>
+template <bool ROPE, bool MUL>
 __device__ __forceinline__ void dkv3_store_rows_lds(char* smem, int wave, bf16_t* row0, int64_t ld, const f32x16 (&acc)[4], float mul, int rows_ok, int lane,
                                                     const char* rope_cos, const char* rope_sin) {
     typedef __attribute__((address_space(3))) char lchar;
@@ -156,8 +156,8 @@ __device__ __forceinline__ void dkv3_store_rows_lds(char* smem, int wave, bf16_t
                     w[0] = pack_bf16x2(rot[dt][2 * g][0], rot[dt][2 * g][1]);
                     w[1] = pack_bf16x2(rot[dt][2 * g + 1][0], rot[dt][2 * g + 1][1]);
                 } else {
-                    w[0] = pack_bf16x2(acc[dt][4 * g + 0] * mul, acc[dt][4 * g + 1] * mul);
-                    w[1] = pack_bf16x2(acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
+                    w[0] = MUL ? pack_bf16x2(acc[dt][4 * g + 0] * mul, acc[dt][4 * g + 1] * mul) : pack_bf16x2(acc[dt][4 * g + 0], acc[dt][4 * g + 1]);
+                    w[1] = MUL ? pack_bf16x2(acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul) : pack_bf16x2(acc[dt][4 * g + 2], acc[dt][4 * g + 3]);
                 }
                 *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(wr + (((4 * dtl + g) << 4) ^ wmask)) = w;
             }
@@ -304,145 +304,71 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_block_hip(const SdpaParams& p, cha
     }
 }
 
-// What an item (sequence, head, key block) looks like to every wave of the workgroup: all of it wave-uniform.
-struct Dkv3Geom {
-    int valid;                          // 0: the queues are empty
-    int s, hd, kb, start, len;
-    Branch br;
-    int kblk_min, q_begin, ntiles;      // first key of the block in sequence coordinates; first query row that sees it; its 64-row steps
-    int last_partial, lr;               // the last step's tile stops inside the sequence: lr of its 64 rows exist
-    template <bool CAUSAL>
-    __device__ __forceinline__ void set(int valid_, int s_, int hd_, int kb_, int start_, int len_, int a, int b) {
-        constexpr int BQ = 64;
-        valid = valid_, s = s_, hd = hd_, kb = kb_;
-        start = start_, len = len_, br.a = a, br.b = b;
-        kblk_min = kb * 128 - start;
-        q_begin = CAUSAL ? max(0, kblk_min) / BQ * BQ : 0;
-        const bool block_has_keys = (kblk_min < len) && (kblk_min + 128 > 0);
-        const int q_stop = (kblk_min >= br.a && kblk_min + 127 < br.b) ? min(len, br.b) : len;
-        ntiles = (valid && block_has_keys && q_stop > q_begin) ? (q_stop - q_begin + BQ - 1) / BQ : 0;
-        const int last_rows = len - (q_begin + (ntiles - 1) * BQ);      // >= 64: whole (or the block's rows stop at br.b)
-        last_partial = last_rows < BQ;
-        lr = last_partial ? last_rows : BQ;
-        // (whatever of the above ran on the vector unit: without this everything derived from it stays in vector registers and the loops over
-        // the block's steps are compiled as divergent ones, the accumulators copied out of and into their registers around the asm block)
-        kblk_min = (int)dkv3_uni((unsigned)kblk_min);
-        q_begin = (int)dkv3_uni((unsigned)q_begin), ntiles = (int)dkv3_uni((unsigned)ntiles), last_partial = (int)dkv3_uni((unsigned)last_partial), lr = (int)dkv3_uni((unsigned)lr);
-    }
-    // the block's first three tiles are whole ones: the previous item's asm block may request them on its way out
-    __device__ __forceinline__ int prefetchable() const { return (ntiles > 0 && !(last_partial && ntiles <= 3)) ? min(3, ntiles) : 0; }
-};
-
 // The item loop of the generated-asm build.  Per item: [the asm block: every step of the key block; on its way out it requests the NEXT
 // item's first tiles] -> the next item's K / V fragments are asked for -> this item's dK / dV rows are converted and stored while those
-// loads and requests fly -> the fragments move into their accumulator registers -> next item.  (Before this pipelining an item paid
-// ~16 000 cycles around its steps - K / V fragments 2 200, the first tiles 4 000, address arithmetic 2 500, the stores and their
-// acknowledgements 4 700, the scheduler 2 500 - with nothing else resident on the CU to fill them: a fifth of the kernel.)
+// loads and requests fly -> next item.  (Before this pipelining an item paid ~16 000 cycles around its steps - K / V fragments 2 200, the
+// first tiles 4 000, address arithmetic 2 500, the stores and their acknowledgements 4 700, the scheduler 2 500 - with nothing else resident
+// on the CU to fill them: a fifth of the kernel.)
+// Round 6: what is uniform about an item arrives as its RECORD (sdpa_dkv3_items.h: written by the delta pass of the same call), held by every
+// wave in ONE vector register (lane l = dword l).  The scheduler is: thread 0 turns the home queue's answer into a record index (one compare and
+// one addition while the home queue lasts); wave 0's lanes 0..15 fetch that record INSIDE the block's first call (gen_dkv3_loop.py: beside the
+// counter's draw, back under the wait for the K / V fragments) and leave it in the LDS mail box; behind the round's barrier every wave reads its
+// dword of it.  Measured before (profiles/r06_dkv3_anatomy.log, 16 x 2048): 6 616 cycles of compiler code in front of every block (scheduler
+// 2 180, run lengths / addresses 1 935, K / V fetch 2 441) + 643 to collect the next geometry behind it.
+#define DKV3_F(rec, field) __builtin_amdgcn_readlane((rec), DKV3_REC_##field)
 template <bool CAUSAL>
 __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* smem, int wave, int lane_in) {
-    constexpr int D = 128, KS = 8, BQ = 64;
-    // ---- the scheduler: thread 0 draws items one round ahead and leaves them, with their sequence's geometry, in a two-slot mail box
+    constexpr int D = 128, BQ = 64;
     // (an LDS-typed pointer: through a generic one the accesses are FLAT instructions, which wait on the vector-memory counter as well - i.e.
     // for the acknowledgements of the rows just stored and the next item's tiles, all of which this loop is arranged not to wait for)
     typedef __attribute__((address_space(3))) volatile int LdsInt;
-    LdsInt* mail = (LdsInt*)(__attribute__((address_space(3))) char*)(smem + DKV3_SCHED);      // [2][8]: Posting
-    const int home = blockIdx.x & 7, order = p.sched_order;
-    int nkb = p.nblk, G = p.npairs;      // (not const: laundered once per round, see below)
-    auto queue_len = [&](int x) { return x < G ? ((G - x + 7) >> 3) * nkb : 0; };
-    // floor(n / d) for 0 <= n < 2^23 (the launcher checks), d >= 1: one multiplication by the reciprocal and one correction step
-    auto fdiv = [](int n, int d) {
-        int q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));      // (1 ulp: the quotient is off by one at most)
-        const int r = n - q * d;
-        return r < 0 ? q - 1 : (r >= d ? q + 1 : q);
-    };
-    struct Posting {
-        int valid, s, hd, kb, start, len, a, b;
-    };
-    auto item_of = [&](int x, int j) {      // item j of queue x -> (pair, key block)
-        const int ng = (G - x + 7) >> 3;
-        int gi, kb;
-        if (order == 1) {      // key-block major over the whole queue (measured: loses the L2's reuse of Q / dO, +30 % per step)
-            kb = fdiv(j, ng), gi = j - kb * ng;
-        } else if (order == 2) {      // the long half of every pair, pair by pair; then the short halves key-block major: what is left for the end is short
-            const int hl = (nkb + 1) >> 1, nl = ng * hl;
-            if (j < nl) {
-                gi = fdiv(j, hl), kb = j - gi * hl;
-            } else {
-                const int q = fdiv(j - nl, ng);
-                kb = hl + q, gi = j - nl - q * ng;
-            }
-        } else {
-            gi = fdiv(j, nkb), kb = j - gi * nkb;
-        }
-        const int g = x + 8 * gi, sq = fdiv(g, p.H);
-        return Posting{1, sq, g - sq * p.H, kb, 0, 0, 0, 0};
-    };
-    auto resolve = [&](int j) {      // j: what the home queue's counter returned
-        if (j < queue_len(home)) return item_of(home, j);
+    LdsInt* mail = (LdsInt*)(__attribute__((address_space(3))) char*)(smem + DKV3_SCHED);      // [2][64]: two item records
+    const int home = blockIdx.x & 7;
+    const int nkb = p.nblk, G = p.npairs, total = G * nkb;      // record `total`: the all-zero "queues are empty" record
+    const int home_len = dkv3_queue_len(home, G, nkb), home_base = dkv3_queue_base(home, G, nkb);
+    auto resolve = [&](int j) {      // thread 0: what the home queue's counter returned -> record index
+        if (j < home_len) return home_base + j;
+#pragma unroll 1
         for (int k = 1; k < 8; ++k) {      // the home queue is empty: the others, nearest first
-            const int x = (home + k) & 7, n = queue_len(x);
+            const int x = (home + k) & 7, n = dkv3_queue_len(x, G, nkb);
             if (n == 0) continue;
             const int jj = atomicAdd(p.sched + 32 * x, 1);
-            if (jj < n) return item_of(x, jj);
+            if (jj < n) return dkv3_queue_base(x, G, nkb) + jj;
         }
-        return Posting{0, 0, 0, 0, 0, 0, 0, 0};
+        return total;
     };
-    // the item's sequence, by SCALAR loads: they return through lgkmcnt; as vector loads the compiler would wait for them with vmcnt(0) (it
-    // knows nothing of what the asm blocks have in flight), i.e. for everything
-    Posting seen{0, -1, 0, 0, 0, 0, 0, 0};      // thread 0: the last sequence looked up (a workgroup's consecutive items mostly share it)
-    auto look_up = [&](Posting w) {      // thread 0 only
-        if (w.s == seen.s) {
-            w.start = seen.start, w.len = seen.len, w.a = seen.a, w.b = seen.b;
-            return w;
+    // a record into a mail-box slot by compiler code (start-up, and the rare item without steps: nothing is in flight that a vmcnt(0) would wait for
+    // in vain); wave 0 only
+    auto fetch_record = [&](int idx, int slot) {
+        idx = __builtin_amdgcn_readfirstlane(idx);
+        if (lane_in < 16) {
+            typedef int i4 __attribute__((ext_vector_type(4)));
+            const i4 v = *reinterpret_cast<const i4*>(p.items + (int64_t)idx * DKV3_REC_DWORDS + 4 * lane_in);
+            *reinterpret_cast<__attribute__((address_space(3))) i4*>((__attribute__((address_space(3))) char*)(smem + DKV3_SCHED) + 256 * slot + 16 * lane_in) = v;
         }
-        const int sq = (int)dkv3_uni((unsigned)w.s);
-        w.start = 0, w.len = p.T, w.a = 0x7fffffff, w.b = 0x7fffffff;
-        if (p.seq_start && p.seq_len && p.br_a && p.br_b) {      // (the packed launch of the training step: four loads, one wait)
-            asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\ts_load_dword %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&s"(w.start), "=&s"(w.len), "=&s"(w.a), "=&s"(w.b)
-                         : "s"(dkv3_uni64(p.seq_start + sq)), "s"(dkv3_uni64(p.seq_len + sq)), "s"(dkv3_uni64(p.br_a + sq)), "s"(dkv3_uni64(p.br_b + sq))
-                         : "memory");
-        } else {
-            auto sload = [&](const int32_t* base, int dflt) {
-                if (base == nullptr) return dflt;
-                int v;
-                asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(dkv3_uni64(base + sq)) : "memory");
-                return v;
-            };
-            w.start = sload(p.seq_start, 0), w.len = sload(p.seq_len, p.T), w.a = sload(p.br_a, 0x7fffffff), w.b = sload(p.br_b, 0x7fffffff);
-        }
-        seen = w;
-        return w;
-    };
-    auto post = [&](int slot, const Posting& w) {
-        mail[8 * slot + 0] = w.valid, mail[8 * slot + 1] = w.s, mail[8 * slot + 2] = w.hd, mail[8 * slot + 3] = w.kb;
-        mail[8 * slot + 4] = w.start, mail[8 * slot + 5] = w.len, mail[8 * slot + 6] = w.a, mail[8 * slot + 7] = w.b;
-    };
-    auto collect = [&](int slot, Dkv3Geom& g) {
-        int w[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = (int)dkv3_uni((unsigned)mail[8 * slot + i]);
-        g.set<CAUSAL>(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
     };
     int drawn = 0;      // thread 0: the home counter's answer for the item after next
-    if (threadIdx.x == 0) {
-        post(0, look_up(resolve(atomicAdd(p.sched + 32 * home, 1))));
-        post(1, look_up(resolve(atomicAdd(p.sched + 32 * home, 1))));
-        drawn = atomicAdd(p.sched + 32 * home, 1);
+    if (wave == 0) {
+        int i0 = 0, i1 = 0;
+        if (threadIdx.x == 0) {
+            i0 = resolve(atomicAdd(p.sched + 32 * home, 1));
+            i1 = resolve(atomicAdd(p.sched + 32 * home, 1));
+            drawn = atomicAdd(p.sched + 32 * home, 1);
+        }
+        fetch_record(i0, 0);
+        fetch_record(i1, 1);
     }
     __syncthreads();
-    Dkv3Geom cur, nxt;
-    collect(0, cur);
-    collect(1, nxt);
-    // every wave has READ both slots before thread 0 overwrites slot 0 in round 0 (later rounds: the end-of-round barrier separates a
-    // slot's last read from its next write; here nothing did - a delayed wave could have taken the third item's geometry for its first)
+    int rec = mail[lane_in], nrec = mail[64 + lane_in];
+    // every wave has READ both slots before wave 0 overwrites slot 0 in round 0 (later rounds: the end-of-round barrier separates a
+    // slot's last read from its next write; here nothing did - a delayed wave could have taken the third item's record for its first)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     const unsigned q_piece = dkv3_uni((unsigned)(16 * p.ld_qkv * 2)), do_piece = dkv3_uni((unsigned)(16 * p.ld_do * 2));
     const unsigned wave_u = dkv3_uni((unsigned)wave);
     const float sc = p.scale * kLog2e;
-    const bf16_t* qp0 = p.q;
-    const bf16_t* dop0 = p.d_o;
+    const unsigned ld2 = dkv3_uni((unsigned)(p.ld_qkv * 2));      // bytes between two rows of q / k / v (the launcher keeps it below 2^31)
+    const int64_t v_minus_k = (const char*)p.v - (const char*)p.k, dv_minus_dk = (const char*)p.dv - (const char*)p.dk;
 
     bool prefetched = false;      // cur's first tiles were requested by the previous item's asm block (its last three steps) ...
     int ring_base = 0;            // ... into the ring slots ring_base, ring_base + 1, ...
@@ -452,33 +378,21 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
     unsigned long long acc_pre_ = 0, acc_asm_ = 0, acc_post_ = 0, n_items_ = 0, t0_, t1_, t2_, t3_, tk_ = 0, ts_ = 0, acc_k_ = 0, acc_s_ = 0, tp_ = 0, tst_ = 0, tb_ = 0, acc_p_ = 0, acc_st_ = 0, acc_b_ = 0;
 #endif
 #pragma unroll 1
-    for (int round = 0; cur.valid; ++round) {
+    for (int round = 0; DKV3_F(rec, VALID); ++round) {
 #ifdef HALVA_STAMP
         DKV3_NOW(t0_);
         t1_ = t2_ = t0_;
 #endif
-        asm volatile("" : "+s"(nkb), "+s"(G));      // (else the reciprocals of the scheduler's divisions are hoisted out of the loop, spilled, and reloaded behind the requests in flight)
         // the lane parts of the generated loop's LDS / global addresses are the same for every item, and are formed per item all the same:
         // kept across the asm block (which leaves the compiler 97 vector registers) they were spilled to scratch, and a scratch reload waits
         // for every tile request in flight (vmcnt counts in order)
         int lane = lane_in;
         asm volatile("" : "+v"(lane));
         const int h = lane >> 5;
-        const unsigned rowrel = 2048 * ((lane & 31) >> 3) + 64 * (lane & 7) + 16 * (h ^ (((lane & 31) >> 2) & 3));
-        const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3, h2 = g16 >> 1;
-        const unsigned colrel = 64 * (4 * h2 + q4) + 16 * ((2 * (g16 & 1) + (pp >> 1)) ^ h2) + 8 * (pp & 1);
-        const unsigned statrel = 16 * h;
-        const unsigned voff_q = dkv3_piece_voff(p.ld_qkv, wave, lane, 0, 64), voff_do = dkv3_piece_voff(p.ld_do, wave, lane, 0, 64);
-        const int s = cur.s, hd = cur.hd, kb = cur.kb, len = cur.len, ntiles = cur.ntiles, q_begin = cur.q_begin, kblk_min = cur.kblk_min;
-        const Branch br = cur.br;
-        const int64_t seq_row0 = (int64_t)s * p.T;
-        const int gk = kb * 128 + 32 * wave + (lane & 31);
-        const int kl = gk - cur.start;
-        const bool k_in_T = gk < p.T;
-        const bool k_valid = k_in_T && kl >= 0 && kl < len;
-        const int npro_next = nxt.valid ? nxt.prefetchable() : 0;
+        const int ntiles = DKV3_F(rec, NTILES), kblk_min = DKV3_F(rec, KBLK_MIN), len = DKV3_F(rec, LEN);
+        const int kl = kblk_min + 32 * wave + (lane & 31);      // this lane's key in sequence coordinates
+        const bool k_valid = kl >= 0 && kl < len && DKV3_F(rec, KB) * 128 + 32 * wave + (lane & 31) < p.T;
         bool requested_next = false;
-        const bool next_runs = nxt.valid && nxt.ntiles > 0;
         if (ntiles > 0) {
             // this item's K / V fragments, asked for FIRST and by hand, straight into the registers the block reads them from (a key outside
             // the sequence reads the nearest one inside: its lane is masked).  They land during the address arithmetic below; nobody waits
@@ -486,9 +400,9 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
             // (it cannot count past an asm block): behind the stores of the previous item's rows, i.e. a wait for their acknowledgements.
             u32x4 kq[8], vq[8];
             {
-                const int kgk = cur.start + min(max(kl, 0), len - 1);
-                const bf16_t* k_ptr = p.k + (seq_row0 + kgk) * p.ld_qkv + hd * D + 8 * h;
-                const bf16_t* v_ptr = p.v + (seq_row0 + kgk) * p.ld_qkv + hd * D + 8 * h;
+                const unsigned long long k0 = ((unsigned long long)(unsigned)DKV3_F(rec, K_HI) << 32) | (unsigned)DKV3_F(rec, K_LO);
+                const char* k_ptr = (const char*)(size_t)k0 + (unsigned long long)(unsigned)min(max(kl, 0), len - 1) * ld2 + 16 * h;
+                const char* v_ptr = k_ptr + v_minus_k;
                 asm volatile(
                     "global_load_dwordx4 %0, %16, off\n\tglobal_load_dwordx4 %1, %16, off offset:32\n\tglobal_load_dwordx4 %2, %16, off offset:64\n\t"
                     "global_load_dwordx4 %3, %16, off offset:96\n\tglobal_load_dwordx4 %4, %16, off offset:128\n\tglobal_load_dwordx4 %5, %16, off offset:160\n\t"
@@ -505,108 +419,96 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
 #ifdef HALVA_STAMP
             DKV3_NOW(tk_);
 #endif
-            const bool key_hidden = kl >= br.a && kl < br.b;
-            const bool block_all_keys_valid = kblk_min >= 0 && kblk_min + 128 <= len;      // workgroup-uniform: no padded key in the block
-#ifdef DKV3_DIAG_SAME_HEAD      // (timing experiment, results wrong: every item reads the Q / dO tiles of sequence 0, head 0 - 1 MiB, resident in every L2:
-                                // what would PERFECT reuse of the tiles among an XCD's workgroups buy?)
-            const bf16_t* qp = qp0;
-            const bf16_t* dop = dop0;
-            const int64_t qrow0 = cur.start;
-#else
-            const bf16_t* qp = qp0 + hd * D;
-            const bf16_t* dop = dop0 + hd * D;
-            const int64_t qrow0 = seq_row0 + cur.start;
-#endif
-            // the statistics of this (sequence, head), 512 bytes per 64-row step in sequence coordinates (sdpa.hip:sdpa_bwd_delta_kernel), as a buffer
-            // descriptor: a step past the sequence brings zeros; lanes 32..63 of a request lie outside it on purpose (they fill the unused half of the slot)
-            const unsigned long long st_base = (unsigned long long)(size_t)(p.lse2 + ((int64_t)s * p.H + hd) * p.stat_nt * 128);
-            const unsigned st_rec = (unsigned)(((len + BQ - 1) / BQ) * 512);
+            const unsigned rowrel = 2048 * ((lane & 31) >> 3) + 64 * (lane & 7) + 16 * (h ^ (((lane & 31) >> 2) & 3));
+            const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3, h2 = g16 >> 1;
+            const unsigned colrel = 64 * (4 * h2 + q4) + 16 * ((2 * (g16 & 1) + (pp >> 1)) ^ h2) + 8 * (pp & 1);
+            const unsigned statrel = 16 * h;
+            const unsigned voff_q = dkv3_piece_voff(p.ld_qkv, wave, lane, 0, 64), voff_do = dkv3_piece_voff(p.ld_do, wave, lane, 0, 64);
+            // lanes 32..63 of a statistics request lie outside the descriptor on purpose (they fill the unused half of the slot)
             const unsigned stat_voff = lane < 32 ? 16u * lane : 0x7ffffff0u;
-            char* ds_block = p.ds_ws + ((((int64_t)s * p.H + hd) * p.ds_nkb + kb) * p.ds_nt + q_begin / BQ) * 16384 + wave * 4096;
-            // the sequence's Q / dO rows of this head as buffer descriptors: base row, bytes up to the end of the last row
-            const unsigned long long q_base = (unsigned long long)(size_t)(qp + qrow0 * p.ld_qkv), do_base = (unsigned long long)(size_t)(dop + qrow0 * p.ld_do);
-            const unsigned q_rec = len > 0 ? (unsigned)((int64_t)(len - 1) * p.ld_qkv * 2 + D * 2) : 0u;
-            const unsigned do_rec = len > 0 ? (unsigned)((int64_t)(len - 1) * p.ld_do * 2 + D * 2) : 0u;
-            // the next item's first tiles (requested by this item's last asm call)
-#ifdef DKV3_DIAG_SAME_HEAD
-            const int64_t nrow0 = nxt.start;
-            const unsigned long long nq_ptr = (unsigned long long)(size_t)(qp0 + nrow0 * p.ld_qkv), ndo_ptr = (unsigned long long)(size_t)(dop0 + nrow0 * p.ld_do);
-#else
-            const int64_t nrow0 = (int64_t)nxt.s * p.T + nxt.start;
-            const unsigned long long nq_ptr = (unsigned long long)(size_t)(qp0 + nxt.hd * D + nrow0 * p.ld_qkv), ndo_ptr = (unsigned long long)(size_t)(dop0 + nxt.hd * D + nrow0 * p.ld_do);
-#endif
-            const unsigned nqrec = nxt.len > 0 ? (unsigned)((int64_t)(nxt.len - 1) * p.ld_qkv * 2 + D * 2) : 0u;
-            const unsigned ndorec = nxt.len > 0 ? (unsigned)((int64_t)(nxt.len - 1) * p.ld_do * 2 + D * 2) : 0u;
-            const unsigned nqsoff = (unsigned)((int64_t)nxt.q_begin * p.ld_qkv * 2), ndosoff = (unsigned)((int64_t)nxt.q_begin * p.ld_do * 2);
-            const unsigned long long nst_base = (unsigned long long)(size_t)(p.lse2 + ((int64_t)nxt.s * p.H + nxt.hd) * p.stat_nt * 128);
-            const unsigned nst_rec = (unsigned)(((nxt.len + BQ - 1) / BQ) * 512), nst_soff = (unsigned)(nxt.q_begin / BQ * 512);
+            const int q_begin = DKV3_F(rec, Q_BEGIN);
+            const Branch br{DKV3_F(rec, BR_A), DKV3_F(rec, BR_B)};
+            const bool key_hidden = kl >= br.a && kl < br.b;
+            const unsigned long long ds0 = (((unsigned long long)(unsigned)DKV3_F(rec, DS_HI) << 32) | (unsigned)DKV3_F(rec, DS_LO)) + 4096u * wave_u;
+            const int npro_next = DKV3_F(nrec, PREFETCHABLE);      // (0 for the all-zero record)
             // (fixed accumulator registers, the same in every asm statement that touches them: no copies; the block zeroes them on its first call)
             f32x16 accV[4], accK[4];      // dV^T, dK^T (local to the item: carried from round to round they travelled through vector registers)
 #ifdef HALVA_STAMP
             DKV3_NOW(ts_);
 #endif
-            // thread 0: the item after next (the counter's answer came out of the previous item's asm block) goes, with its sequence, into the slot
-            // `cur` was read from
-            if (threadIdx.x == 0) post(round & 1, look_up(resolve(drawn)));
+            // thread 0: the item after next (the counter's answer came out of the previous item's asm block) - its record's address for the
+            // block's first call, whose wave-0 lanes 0..15 fetch it (16 bytes each) into the mail-box slot `cur` was read from
+            const int nn_idx = threadIdx.x == 0 ? resolve(drawn) : 0;
+            const int* rec_ptr = p.items + (int64_t)__builtin_amdgcn_readfirstlane(nn_idx) * DKV3_REC_DWORDS + 4 * (lane & 15);
 #ifdef HALVA_STAMP
             DKV3_NOW(tp_);
 #endif
             int* home_counter = p.sched + 32 * home;
             int drawn_out;      // the next answer of the home queue's counter: asked for by the block's first call (see gen_dkv3_loop.py)
             int t = 0;
+#define DKV3_FIRST 1
 #define DKV3_ACC_MOD "="
 #include "sdpa_dkv3_call.h"
 #undef DKV3_ACC_MOD
+#undef DKV3_FIRST
             if (threadIdx.x == 0) drawn = drawn_out;
 #pragma unroll 1
             while (t < ntiles) {
                 int drawn_out;      // (not a first call: nothing is drawn)
+#define DKV3_FIRST 0
 #define DKV3_ACC_MOD "+"
 #include "sdpa_dkv3_call.h"
 #undef DKV3_ACC_MOD
+#undef DKV3_FIRST
             }
             // (straight behind the loop, in the same block: carried to a common tail the accumulators travelled through vector registers)
-            int gk_st = gk;      // (the row pointers are formed HERE: formed before the asm block they were spilled across it, and their reload waited for the requests it had just made)
-            asm volatile("" : "+v"(gk_st));
-            bf16_t* dk_row = p.dk + (seq_row0 + gk_st) * p.ld_qkv + hd * D;
-            bf16_t* dv_row = p.dv + (seq_row0 + gk_st) * p.ld_qkv + hd * D;
             if (DKV3_ROWS_VIA_LDS) {      // (rows of the wave in the tensor: uniform)
-                const int wrow0 = kb * 128 + 32 * wave;
-                const int rows_ok = min(32, max(0, p.T - wrow0));
-                bf16_t* w0 = p.dk + (seq_row0 + wrow0) * p.ld_qkv + hd * D;
+                const int rows_ok = wave_u == 0 ? DKV3_F(rec, ROWS_OK0) : wave_u == 1 ? DKV3_F(rec, ROWS_OK1) : wave_u == 2 ? DKV3_F(rec, ROWS_OK2) : DKV3_F(rec, ROWS_OK3);
+                const unsigned long long dk0 = ((unsigned long long)(unsigned)DKV3_F(rec, DK_HI) << 32) | (unsigned)DKV3_F(rec, DK_LO);
+                bf16_t* w0 = (bf16_t*)(size_t)(dk0 + (unsigned long long)(32u * wave_u) * ld2);
                 // the ring slot the item's last tile has left: free until the next item's first step (its prefetched tiles sit in the other three)
                 const int free_slot = (ring_base + ntiles - 1) & 3;
                 char* rope_c = smem + free_slot * DKV3_TILE + wave * 4096;
                 char* rope_s = smem + DKV3_DO + free_slot * DKV3_TILE + wave * 4096;
-                if (p.rope_cos)      // (uniform) the table rows of this wave's keys, asked for now, needed behind the dV rows
-                    dkv3_rope_request_lds(rope_c, rope_s, p.rope_cos, p.rope_sin, rope_position(min(wrow0, p.T - 1), br), p.rope_max_pos, lane);
-                dkv3_store_rows_lds<false>(smem, wave, w0 + (p.dv - p.dk), p.ld_qkv, accV, k_valid ? 1.f : 0.f, rows_ok, lane, nullptr, nullptr);
-                if (p.rope_cos) {
-                    // the dV rows' stores are younger than the table requests: 8 of them when the wave's 32 rows all exist; a partial last block issues
-                    // fewer (a store whose rows are all past the tensor may be branched over) - then wait for everything
-                    if (rows_ok == 32) dkv3_rope_landed<8>();
-                    else dkv3_rope_landed<0>();
-                    dkv3_store_rows_lds<true>(smem, wave, w0, p.ld_qkv, accK, k_valid ? p.scale : 0.f, rows_ok, lane, rope_c, rope_s);
-                } else {
-                    dkv3_store_rows_lds<false>(smem, wave, w0, p.ld_qkv, accK, k_valid ? p.scale : 0.f, rows_ok, lane, nullptr, nullptr);
+                if (p.rope_cos) {      // (uniform) the table rows of this wave's keys, asked for now, needed behind the dV rows
+                    const int pos0 = wave_u == 0 ? DKV3_F(rec, ROPE_POS0) : wave_u == 1 ? DKV3_F(rec, ROPE_POS1) : wave_u == 2 ? DKV3_F(rec, ROPE_POS2) : DKV3_F(rec, ROPE_POS3);
+                    dkv3_rope_request_lds(rope_c, rope_s, p.rope_cos, p.rope_sin, pos0, p.rope_max_pos, lane);
                 }
-            } else if (k_in_T) {
-                store_rows_T<D>(dv_row, accV, k_valid ? 1.f : 0.f, true, lane);
-                store_rows_T<D>(dk_row, accK, k_valid ? p.scale : 0.f, true, lane);
+                // (dV of a key outside the sequence: every step of such a key is a masked one and its P is exactly 0, so the accumulator is
+                // 0 already - the multiplication by 1 / 0 of rounds 2-5 changed nothing and cost 64 instructions per item)
+                dkv3_store_rows_lds<false, false>(smem, wave, (bf16_t*)((char*)w0 + dv_minus_dk), p.ld_qkv, accV, 1.f, rows_ok, lane, nullptr, nullptr);
+                if (p.rope_cos) {
+                    // the dV rows' stores are younger than the table requests; how many the compiler issues is its own business (it may merge or
+                    // branch over them): wait for everything (profiles/r05_rope_cost.log: no measurable difference to a counted wait)
+                    dkv3_rope_landed<0>();
+                    dkv3_store_rows_lds<true, true>(smem, wave, w0, p.ld_qkv, accK, p.scale, rows_ok, lane, rope_c, rope_s);
+                } else {
+                    dkv3_store_rows_lds<false, true>(smem, wave, w0, p.ld_qkv, accK, p.scale, rows_ok, lane, nullptr, nullptr);
+                }
+            } else {
+                const int gk = DKV3_F(rec, KB) * 128 + 32 * wave + (lane & 31);
+                bf16_t* dk_row = p.dk + ((int64_t)DKV3_F(rec, S) * p.T + gk) * p.ld_qkv + DKV3_F(rec, HD) * D;
+                if (gk < p.T) {
+                    store_rows_T<D>((bf16_t*)((char*)dk_row + dv_minus_dk), accV, k_valid ? 1.f : 0.f, true, lane);
+                    store_rows_T<D>(dk_row, accK, k_valid ? p.scale : 0.f, true, lane);
+                }
             }
             ring_base = (ring_base + ntiles) & 3;      // (the next item's prefetched tiles continue the slot rotation)
         } else {
-            if (threadIdx.x == 0) {
-                post(round & 1, look_up(resolve(drawn)));
-                drawn = atomicAdd(p.sched + 32 * home, 1);
+            // an item without steps (a key block past its sequence, or wholly hidden): nothing is in flight, the scheduler's part in compiler code
+            if (wave == 0) {
+                int nn_idx = 0;
+                if (threadIdx.x == 0) {
+                    nn_idx = resolve(drawn);
+                    drawn = atomicAdd(p.sched + 32 * home, 1);
+                }
+                fetch_record(nn_idx, round & 1);
             }
-            int gk_st = gk;      // (the row pointers are formed HERE: formed before the asm block they were spilled across it, and their reload waited for the requests it had just made)
-            asm volatile("" : "+v"(gk_st));
-            bf16_t* dk_row = p.dk + (seq_row0 + gk_st) * p.ld_qkv + hd * D;
-            bf16_t* dv_row = p.dv + (seq_row0 + gk_st) * p.ld_qkv + hd * D;
-            if (k_in_T) {
+            const int gk = DKV3_F(rec, KB) * 128 + 32 * wave + (lane & 31);
+            bf16_t* dk_row = p.dk + ((int64_t)DKV3_F(rec, S) * p.T + gk) * p.ld_qkv + DKV3_F(rec, HD) * D;
+            if (gk < p.T) {
                 store_rows_zero<D>(dk_row, lane);
-                store_rows_zero<D>(dv_row, lane);
+                store_rows_zero<D>((bf16_t*)((char*)dk_row + dv_minus_dk), lane);
             }
         }
 #ifdef HALVA_STAMP
@@ -619,9 +521,9 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
 #ifdef HALVA_STAMP
         DKV3_NOW(tb_);
 #endif
-        cur = nxt;
+        rec = nrec;
         prefetched = requested_next;
-        collect(round & 1, nxt);
+        nrec = mail[64 * (round & 1) + lane_in];
 #ifdef HALVA_STAMP
         DKV3_NOW(t3_);
         acc_pre_ += t1_ - t0_, acc_asm_ += t2_ - t1_, acc_post_ += t3_ - t2_, ++n_items_;

@@ -1,44 +1,39 @@
 // One call of the generated block (sdpa_dkv3_loop.inc) for the steps t .. t_side of the current item - included TWICE by sdpa_bwd_dkv3_items
-// (sdpa_dkv3.h): once for the item's first call, where the accumulators are outputs only (DKV3_ACC_MOD "=": the block zeroes them itself),
-// and once inside the loop over the rare further calls (a key block cut by a branch point), where they are read and written ("+").  With ONE
-// site inside a loop the accumulators became a loop-carried value that the compiler kept in vector registers: 128 copies out of and 128
-// into the accumulator file around every call.
+// (sdpa_dkv3.h): once for the item's first call (DKV3_FIRST 1), where the accumulators are outputs only (DKV3_ACC_MOD "=": the block zeroes them
+// itself) and the call's run lengths come ready-made from the item's record (sdpa_dkv3_items.h), and once inside the loop over the rare further
+// calls (a key block cut by a branch point), where they are read and written ("+") and the run lengths are worked out here.  With ONE site inside a
+// loop the accumulators became a loop-carried value that the compiler kept in vector registers: 128 copies out of and 128 into the accumulator
+// file around every call.
 {
             const int qt0 = q_begin + t * BQ;
+#if DKV3_FIRST
+            const bool q_in_b = DKV3_F(rec, Q_IN_B0) != 0;
+            const int t_side = DKV3_F(rec, T_SIDE), ndma = DKV3_F(rec, NDMA);
+            const unsigned n02_u = (unsigned)DKV3_F(rec, N02), n1_u = (unsigned)DKV3_F(rec, N1);
+            // the next tile to request: tile 3 - or tile 0 on a cold first call, which requests tiles 0..2 up front
+            const bool cold = !prefetched;
+            const unsigned q_soff = (unsigned)(cold ? DKV3_F(rec, Q_SOFF0) : DKV3_F(rec, Q_SOFF3)), do_soff = (unsigned)(cold ? DKV3_F(rec, DO_SOFF0) : DKV3_F(rec, DO_SOFF3));
+            const unsigned st_soff = (unsigned)(cold ? DKV3_F(rec, ST_SOFF0) : DKV3_F(rec, ST_SOFF3));
+            // the call's control word: first call of the block | tiles it requests itself | which of those is the partial last tile
+            // | the run's last request is the partial last tile | ring slot of the first step's tile | mail-box slot   (gen_dkv3_loop.py: CTL_*)
+            const unsigned ctl_u = dkv3_uni((unsigned)DKV3_F(rec, CTL0) | ((cold ? (unsigned)min(3, ntiles) : 0u) << 1) | ((unsigned)(ring_base & 3) << 9) |
+                                            ((unsigned)(round & 1) << 11));
+            const unsigned long long ds_ptr = ds0;
+#else
             const bool q_in_b = qt0 >= br.b;                     // br.b and qt0 are multiples of 64: uniform over the step
             // ONE asm block for the steps up to the branch point (or the end): masked steps (the diagonal), interior steps, masked steps (the tail)
-            const int t_side = q_in_b ? ntiles : min(ntiles, (int)(((int64_t)br.b - q_begin + BQ - 1) / BQ));      // first step at or behind br.b
-            int n0, n1, n2;
-#ifdef HALVA_DKV3_ALL_MASKED      // diagnostic: every step through the masked phase (same results: an interior step's masks pass everything)
-            n0 = t_side - t, n1 = 0, n2 = 0;
-#else
-            {      // interior(t') on this side of br.b = side_ok && t_diag <= t' < t_full: three runs, no scan
-                const bool side_ok = block_all_keys_valid && !(q_in_b && kblk_min < br.b && kblk_min + 127 >= br.a);
-                const int t_diag = CAUSAL ? max(0, (kblk_min + 127 - q_begin + BQ - 1) / BQ) : 0;      // first t' with qt0 >= kblk_min + 127
-                const int t_full = max(0, (len - q_begin) / BQ);                                          // first t' with qt0 + 64 > len
-                const int lo = min(t_side, max(t, t_diag)), hi = min(t_side, max(lo, t_full));
-                n0 = side_ok ? lo - t : t_side - t;
-                n1 = side_ok ? hi - lo : 0;
-                n2 = t_side - t - n0 - n1;
-            }
-#endif
-            const int n = t_side - t;
-            const int ndma = min(n, max(0, ntiles - 3 - t));      // steps t' of the call with a tile t'+3 to request
-            const bool part = cur.last_partial && ndma > 0 && (t + ndma - 1 + 3 == ntiles - 1);
-            const bool lane_off = !k_valid || (q_in_b && key_hidden);
-            const unsigned lo0 = (unsigned)(kl - qt0 - 4 * h), range = lane_off ? 0u : (unsigned)(len - kl);
-            const unsigned long long ds_ptr = (unsigned long long)(size_t)(ds_block + (int64_t)t * 16384);
-            // the next tile to request: tile t+3 - or tile 0 on a cold first call, which requests tiles 0..2 up front
-            const bool cold = t == 0 && !prefetched;
-            const int tq = cold ? 0 : t + 3;
+            const Dkv3Call cp = dkv3_call_params<CAUSAL>(t, q_begin, kblk_min, len, ntiles, DKV3_F(rec, LAST_PARTIAL), br);
+            const int t_side = cp.t_side, ndma = cp.ndma;
+            const unsigned n02_u = dkv3_uni((unsigned)cp.n0 | ((unsigned)cp.n2 << 16)), n1_u = dkv3_uni((unsigned)cp.n1);      // (the launcher keeps T < 2^22)
+            const int tq = t + 3;
             const unsigned q_soff = (unsigned)((q_begin + (int64_t)tq * BQ) * p.ld_qkv * 2), do_soff = (unsigned)((q_begin + (int64_t)tq * BQ) * p.ld_do * 2);
             const unsigned st_soff = (unsigned)((q_begin / BQ + tq) * 512);      // the first step whose statistics this call requests (512 bytes per step)
-            // the call's control word: first call of the block | tiles it requests itself | which of those is the partial last tile
-            // | the run's last request is the partial last tile | ring slot of the first step's tile   (gen_dkv3_loop.py: CTL_*)
-            const unsigned ctl_u = dkv3_uni((t == 0 ? 1u : 0u) | ((cold ? (unsigned)min(3, ntiles) : 0u) << 1) |
-                                            (((cur.last_partial && ntiles <= 3) ? (unsigned)(ntiles - 1) : 7u) << 3) | ((part ? 1u : 0u) << 8) |
-                                            ((unsigned)((ring_base + t) & 3) << 9));
-            const unsigned n02_u = dkv3_uni((unsigned)n0 | ((unsigned)n2 << 16)), n1_u = dkv3_uni((unsigned)n1);      // (the launcher keeps T < 2^22)
+            const unsigned ctl_u = dkv3_uni((7u << 3) | ((cp.part ? 1u : 0u) << 8) | ((unsigned)((ring_base + t) & 3) << 9));
+            const unsigned long long ds_ptr = ds0 + (unsigned long long)t * 16384;
+#endif
+            const int n = t_side - t;
+            const bool lane_off = !k_valid || (q_in_b && key_hidden);
+            const unsigned lo0 = (unsigned)(kl - qt0 - 4 * h), range = lane_off ? 0u : (unsigned)(len - kl);
             // the next item's first tiles ride on this call's last three steps (which have no tile of their own left to ask for) - when it has three
             const unsigned pf = (t_side == ntiles && n - ndma == 3) ? (unsigned)npro_next : 0u;
             requested_next = requested_next || pf != 0;
@@ -51,20 +46,17 @@
                 : [accV0] DKV3_ACC_MOD "{a[0:15]}"(accV[0]), [accV1] DKV3_ACC_MOD "{a[16:31]}"(accV[1]), [accV2] DKV3_ACC_MOD "{a[32:47]}"(accV[2]), [accV3] DKV3_ACC_MOD "{a[48:63]}"(accV[3]),
                   [accK0] DKV3_ACC_MOD "{a[64:79]}"(accK[0]), [accK1] DKV3_ACC_MOD "{a[80:95]}"(accK[1]), [accK2] DKV3_ACC_MOD "{a[96:111]}"(accK[2]), [accK3] DKV3_ACC_MOD "{a[112:127]}"(accK[3]),
                   [drawn] "=&v"(drawn_out)
-                : [sched_ptr] "v"(home_counter), [kq0] "{a[128:131]}"(kq[0]), [kq1] "{a[132:135]}"(kq[1]), [kq2] "{a[136:139]}"(kq[2]), [kq3] "{a[140:143]}"(kq[3]), [kq4] "{a[144:147]}"(kq[4]),
+                : [sched_ptr] "v"(home_counter), [rec_ptr] "v"(rec_ptr), [kq0] "{a[128:131]}"(kq[0]), [kq1] "{a[132:135]}"(kq[1]), [kq2] "{a[136:139]}"(kq[2]), [kq3] "{a[140:143]}"(kq[3]), [kq4] "{a[144:147]}"(kq[4]),
                   [kq5] "{a[148:151]}"(kq[5]), [kq6] "{a[152:155]}"(kq[6]), [kq7] "{a[156:159]}"(kq[7]), [vq0] "{a[160:163]}"(vq[0]), [vq1] "{a[164:167]}"(vq[1]),
                   [vq2] "{a[168:171]}"(vq[2]), [vq3] "{a[172:175]}"(vq[3]), [vq4] "{a[176:179]}"(vq[4]), [vq5] "{a[180:183]}"(vq[5]), [vq6] "{a[184:187]}"(vq[6]),
                   [vq7] "{a[188:191]}"(vq[7]), [rowrel] "v"(rowrel), [colrel] "v"(colrel), [statrel] "v"(statrel), [voff_q] "v"(voff_q), [voff_do] "v"(voff_do),
                   [sc] "s"(sc), [n02] "s"(n02_u), [n1] "s"(n1_u), [ndma] "s"(ndma_u), [wave] "s"(wave_u), [q_piece] "s"(q_piece), [do_piece] "s"(do_piece),
                   [lo0] "v"(lo0), [range] "v"(range), [stat_voff] "v"(stat_voff),
                   [ctl] "s"(ctl_u),
-                  // uniform 64-bit addresses as two vector registers each (the block reads them with v_readfirstlane: scalar operands are scarce)
-                  [q_lo] "v"((unsigned)q_base), [q_hi] "v"((unsigned)(q_base >> 32)), [do_lo] "v"((unsigned)do_base), [do_hi] "v"((unsigned)(do_base >> 32)),
-                  [q_rec] "v"(q_rec), [do_rec] "v"(do_rec), [q_soff] "v"(q_soff), [do_soff] "v"(do_soff), [nqrec] "v"(nqrec), [ndorec] "v"(ndorec), [nqsoff] "v"(nqsoff), [ndosoff] "v"(ndosoff),
-                  [st_lo] "v"((unsigned)st_base), [st_hi] "v"((unsigned)(st_base >> 32)), [st_rec] "v"(st_rec), [st_soff] "v"(st_soff),
-                  [ds_lo] "v"((unsigned)ds_ptr), [ds_hi] "v"((unsigned)(ds_ptr >> 32)), [nq_lo] "v"((unsigned)nq_ptr), [nq_hi] "v"((unsigned)(nq_ptr >> 32)),
-                  [ndo_lo] "v"((unsigned)ndo_ptr), [ndo_hi] "v"((unsigned)(ndo_ptr >> 32)),
-                  [nst_lo] "v"((unsigned)nst_base), [nst_hi] "v"((unsigned)(nst_base >> 32)), [nst_rec] "v"(nst_rec), [nst_soff] "v"(nst_soff)
+                  // the item's record and the next item's (lane l = dword l): the block picks the descriptor bases / extents with v_readlane_b32
+                  [rec] "v"(rec), [nrec] "v"(nrec),
+                  // what changes from call to call, as uniform values in vector registers (the block reads them with v_readfirstlane: scalar operands are scarce)
+                  [q_soff] "v"(q_soff), [do_soff] "v"(do_soff), [st_soff] "v"(st_soff), [ds_lo] "v"((unsigned)ds_ptr), [ds_hi] "v"((unsigned)(ds_ptr >> 32))
                 :
 #include "sdpa_dkv3_loop_clobbers.inc"
             );

@@ -213,3 +213,132 @@ def test_forced_one_rank_communicator_issues_the_collectives():
     p.start()
     p.join(120)
     assert p.exitcode == 0 and q.get(timeout=5) == "ok"
+
+
+def _worker_n(rank, world, port, accum, out):
+    """The same plumbing at an arbitrary world size (round 6: every multi-process test stopped at world = 2, so port handling, the
+    sampler's `world x accum` dealing and the bucket hand-over had never run with 8 processes - reference src/hallava_7b.sh:21-22,30,
+    llava/train/halva_trainer.py:261-274)."""
+    import random
+    import time
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from halva_amd import dp
+    ctx = dp.DistContext.from_env("gloo")
+    assert (ctx.rank, ctx.world) == (rank, world) and ctx.active
+    mean_rank1 = (world + 1) / 2.0                      # mean over the ranks of (rank + 1)
+    # 1. the after-the-fact bucketed mean, with a bucket boundary inside the buffer
+    dp.BUCKET_ELEMS = 1000
+    flat = torch.arange(2500, dtype=torch.float32) * (rank + 1)
+    dp.allreduce_mean_(flat, ctx)
+    assert torch.allclose(flat, torch.arange(2500, dtype=torch.float32) * mean_rank1)
+    # 2. N ranks x 1 micro-batch == one process accumulating N micro-batches (pairs are independent)
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(2 * world, 16, generator=g)
+    w = torch.randn(16, generator=g)
+    mine = dp.shard_batches(world, ctx)
+    assert mine == [rank]
+    ww = w.clone().requires_grad_(True)
+    torch.nn.functional.softplus(X[2 * rank:2 * rank + 2] @ ww).mean().backward()
+    grad = ww.grad.clone()
+    dp.allreduce_mean_(grad, ctx)
+    ww = w.clone().requires_grad_(True)
+    torch.nn.functional.softplus(X @ ww).mean().backward()
+    assert torch.allclose(grad, ww.grad, atol=1e-6)
+    assert abs(dp.mean_scalar(float(rank), ctx) - (world - 1) / 2.0) < 1e-12 and dp.max_scalar(float(rank), ctx) == world - 1.0
+    # 3. GradReducer: every rank reports its layers at its OWN pace and granularity (the ranks' backwards are not in lock step: one
+    #    reports layer by layer, another skips hooks and reports several layers at once, a third only at finish()); the collectives
+    #    still pair bucket by bucket and the result is the plain mean
+    class _Flat:
+        names = ["model.layers.%d.w" % i for i in range(8)] + ["model.mm_projector.0.weight"]
+        offsets = list(range(0, 900, 100)) + [1000]
+        grad = None
+    rnd = random.Random(1000 + rank)
+    for trial in range(4):
+        _Flat.grad = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+        red = dp.GradReducer.for_flat(_Flat, ctx, min_bucket=(1, 150, 250, 10 ** 6)[trial])
+        assert red.late == (800, 1000) and red.buckets[-1][0] == 0 and red.buckets[0][1] == 800
+        red.begin()
+        reported = [i for i in range(7, -1, -1) if rnd.random() < (1.0, 0.6, 0.3, 0.0)[(rank + trial) % 4]]
+        for i in reported:
+            time.sleep(rnd.random() * 0.01)
+            red.layer_done(i)
+        _Flat.grad[800:] += 1.0                         # the projector's gradient: the last thing a backward produces
+        red.finish()
+        want = torch.arange(1000, dtype=torch.float32) * mean_rank1
+        want[800:] += 1.0
+        assert torch.allclose(_Flat.grad, want), trial
+    # 4. one rank (5 of 8; the last one in a smaller world) fails in the middle of its backward: drain(), collective MAX, everybody repeats
+    bad = 5 if world > 5 else world - 1
+    redf = dp.GradReducer.for_flat(_Flat, ctx, min_bucket=1)
+    for fail_after in (0, 3, 8, "before_begin"):
+        _Flat.grad = torch.full((1000,), rank + 1.0)
+        redf.g = _Flat.grad
+        failed = rank == bad
+        if not (failed and fail_after == "before_begin"):
+            redf.begin()
+            for k, layer in enumerate(range(7, -1, -1)):
+                if failed and fail_after == k:
+                    break
+                redf.layer_done(layer)
+        if failed:
+            redf.drain()
+        else:
+            redf.finish()
+        assert dp.max_scalar(1.0 if failed else 0.0, ctx) == 1.0
+        _Flat.grad.fill_(rank + 1.0)
+        redf.begin()
+        for layer in range(7, -1, -1):
+            redf.layer_done(layer)
+        redf.finish()
+        assert torch.allclose(_Flat.grad, torch.full((1000,), mean_rank1)), fail_after
+    b = torch.full((5,), float(rank + 7))
+    dp.broadcast_(b, ctx)
+    assert torch.equal(b, torch.full((5,), 7.0))
+    # 5. the trainer's loader: the sampler groups `world x accum` micro-batches by length (reference halva_trainer.py:261-274) and rank r
+    #    takes every world-th batch: disjoint, complete, every rank the same number of micro-batches, a multiple of accum
+    from llava.train.halva_trainer import HalvaTrainer
+    n_samples = 2 * world * accum * 3                   # three optimizer steps of 2-pair micro-batches
+
+    class DS(torch.utils.data.Dataset):
+        modality_lengths = [5 + (7 * i) % 41 for i in range(n_samples)]
+
+        def __len__(self):
+            return n_samples
+
+        def __getitem__(self, i):
+            return i
+    t = HalvaTrainer.__new__(HalvaTrainer)
+    t.dist, t.train_dataset, t.data_collator = ctx, DS(), (lambda x: x)
+    t.args = type("A", (), dict(per_device_train_batch_size=2, gradient_accumulation_steps=accum, group_by_modality_length=True,
+                                 dataloader_num_workers=0, dataloader_drop_last=False, seed=42))()
+    torch.manual_seed(7)
+    batches = [list(b) for b in t.get_train_dataloader()]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, batches)
+    if rank == 0:
+        flat_ids = [i for r in gathered for b in r for i in b]
+        assert sorted(flat_ids) == list(range(n_samples)), "dealing is not disjoint + complete"
+        assert len({len(r) for r in gathered}) == 1 and len(gathered[0]) == 3 * accum
+        assert all(len(b) == 2 for r in gathered for b in r)
+        out.put("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,accum", [(8, 4), (4, 1)])
+def test_eight_rank_gloo(world, accum):
+    """world 8 (x accumulation 4: the recipe's `world x accum` sampler dealing) and world 4 on CPU over gloo: plumbing only - no
+    scaling curve can come of it."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_n, args=(r, world, port, accum, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) == "ok"
