@@ -464,7 +464,15 @@ def main():
     names.update({8 + i: "kq%d" % i for i in range(8)}); names.update({16 + i: "vq%d" % i for i in range(8)})
     import re
     def named(l):      # the asm statement's operands are NAMED (sdpa_dkv3.h): the numbers above are this script's shorthand
-        return re.sub(r"%(\d+)", lambda m: "%%[%s]" % names[int(m.group(1))], l)
+        # (round 6: the K / V fragments are no operands any more but the literal registers a128-a191: the clobber list names them, which keeps the
+        # compiler's own spills out of them, and tools/check_dkv3_isa.py holds it to that.  It lets an experiment load them across the item loop's back
+        # edge - experiments/dkv3_item_boundary - where, as loop-carried operands, the compiler moved them through vector registers)
+        def one(m):
+            n = int(m.group(1))
+            if 8 <= n < 24:
+                return "a[%d:%d]" % (128 + 4 * (n - 8), 131 + 4 * (n - 8))
+            return "%%[%s]" % names[n]
+        return re.sub(r"%(\d+)", one, l)
     lines = [named(l) for l in lines]
     expanded = []
     for l in lines:
@@ -486,7 +494,8 @@ def main():
             f.write('"%s\\n\\t"\n' % l)
     with open(os.environ.get("DKV3_OUT", "sdpa_dkv3_loop.inc").replace(".inc", "_clobbers.inc"), "w") as f:
         f.write("// generated by gen_dkv3_loop.py - do not edit\n")
-        f.write(", ".join('"v%d"' % i for i in range(64, 223)) + ",\n" + ", ".join('"s%d"' % i for i in range(70, 100)) + ', "vcc", "scc", "memory"\n')
+        f.write(", ".join('"v%d"' % i for i in range(64, 223)) + ",\n" + ", ".join('"a%d"' % i for i in range(128, 192)) + ",\n" +
+                ", ".join('"s%d"' % i for i in range(70, 100)) + ', "vcc", "scc", "memory"\n')
     with open(os.environ.get("DKV3_OUT", "sdpa_dkv3_loop.inc").replace(".inc", "_rec.inc"), "w") as f:
         f.write("// generated by gen_dkv3_loop.py - do not edit: dword index of every field of an item record (gen_dkv3_loop.py:REC_FIELDS)\n")
         f.write("enum Dkv3Rec : int {\n" + "".join("    DKV3_REC_%s = %d,\n" % (n.upper(), i) for n, i in REC.items()) + "    DKV3_REC_DWORDS = 64\n};\n")

@@ -372,7 +372,6 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
 
     bool prefetched = false;      // cur's first tiles were requested by the previous item's asm block (its last three steps) ...
     int ring_base = 0;            // ... into the ring slots ring_base, ring_base + 1, ...
-
 #ifdef HALVA_STAMP
 #define DKV3_NOW(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory")
     unsigned long long acc_pre_ = 0, acc_asm_ = 0, acc_post_ = 0, n_items_ = 0, t0_, t1_, t2_, t3_, tk_ = 0, ts_ = 0, acc_k_ = 0, acc_s_ = 0, tp_ = 0, tst_ = 0, tb_ = 0, acc_p_ = 0, acc_st_ = 0, acc_b_ = 0;
@@ -394,25 +393,27 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
         const bool k_valid = kl >= 0 && kl < len && DKV3_F(rec, KB) * 128 + 32 * wave + (lane & 31) < p.T;
         bool requested_next = false;
         if (ntiles > 0) {
-            // this item's K / V fragments, asked for FIRST and by hand, straight into the registers the block reads them from (a key outside
-            // the sequence reads the nearest one inside: its lane is masked).  They land during the address arithmetic below; nobody waits
-            // for them before the block's own s_waitcnt vmcnt(0).  Loaded by the compiler they cost a vmcnt(0) wherever it chose to move them
-            // (it cannot count past an asm block): behind the stores of the previous item's rows, i.e. a wait for their acknowledgements.
-            u32x4 kq[8], vq[8];
+            // this item's K / V fragments, asked for FIRST and by hand, straight into the registers the block reads them from - a128-a191, literal
+            // registers here and in the block, not values the compiler knows about (a key outside the sequence reads the nearest one inside: its lane
+            // is masked).  Nobody waits for them before the block's own s_waitcnt vmcnt(0).  Loaded by the compiler they cost a vmcnt(0) wherever it
+            // chose to move them (it cannot count past an asm block).  What they cost: a fragment load is 64 separate 16-byte pieces (a lane = a key =
+            // a row of its own, 24 KiB apart) and holds the lone wave's issue for ~170 cycles - 2 750 per item wherever the sixteen stand - and
+            // what the code between here and the block does not cover of their ~4 000 cycles of latency is waited for inside the block's first call.
+            // Round 6 tried to get rid of both (experiments/dkv3_item_boundary: the loads in front of / between / behind the PREVIOUS item's store
+            // conversions; a second register set a192-a255 filled by the previous block's first call): the issue time cannot be hidden by a wave
+            // that is alone on its SIMD, and none of the five variants beat this one.
             {
                 const unsigned long long k0 = ((unsigned long long)(unsigned)DKV3_F(rec, K_HI) << 32) | (unsigned)DKV3_F(rec, K_LO);
                 const char* k_ptr = (const char*)(size_t)k0 + (unsigned long long)(unsigned)min(max(kl, 0), len - 1) * ld2 + 16 * h;
                 const char* v_ptr = k_ptr + v_minus_k;
                 asm volatile(
-                    "global_load_dwordx4 %0, %16, off\n\tglobal_load_dwordx4 %1, %16, off offset:32\n\tglobal_load_dwordx4 %2, %16, off offset:64\n\t"
-                    "global_load_dwordx4 %3, %16, off offset:96\n\tglobal_load_dwordx4 %4, %16, off offset:128\n\tglobal_load_dwordx4 %5, %16, off offset:160\n\t"
-                    "global_load_dwordx4 %6, %16, off offset:192\n\tglobal_load_dwordx4 %7, %16, off offset:224\n\t"
-                    "global_load_dwordx4 %8, %17, off\n\tglobal_load_dwordx4 %9, %17, off offset:32\n\tglobal_load_dwordx4 %10, %17, off offset:64\n\t"
-                    "global_load_dwordx4 %11, %17, off offset:96\n\tglobal_load_dwordx4 %12, %17, off offset:128\n\tglobal_load_dwordx4 %13, %17, off offset:160\n\t"
-                    "global_load_dwordx4 %14, %17, off offset:192\n\tglobal_load_dwordx4 %15, %17, off offset:224"
-                    : "={a[128:131]}"(kq[0]), "={a[132:135]}"(kq[1]), "={a[136:139]}"(kq[2]), "={a[140:143]}"(kq[3]), "={a[144:147]}"(kq[4]), "={a[148:151]}"(kq[5]),
-                      "={a[152:155]}"(kq[6]), "={a[156:159]}"(kq[7]), "={a[160:163]}"(vq[0]), "={a[164:167]}"(vq[1]), "={a[168:171]}"(vq[2]), "={a[172:175]}"(vq[3]),
-                      "={a[176:179]}"(vq[4]), "={a[180:183]}"(vq[5]), "={a[184:187]}"(vq[6]), "={a[188:191]}"(vq[7])
+                    "global_load_dwordx4 a[128:131], %0, off\n\tglobal_load_dwordx4 a[132:135], %0, off offset:32\n\tglobal_load_dwordx4 a[136:139], %0, off offset:64\n\t"
+                    "global_load_dwordx4 a[140:143], %0, off offset:96\n\tglobal_load_dwordx4 a[144:147], %0, off offset:128\n\tglobal_load_dwordx4 a[148:151], %0, off offset:160\n\t"
+                    "global_load_dwordx4 a[152:155], %0, off offset:192\n\tglobal_load_dwordx4 a[156:159], %0, off offset:224\n\t"
+                    "global_load_dwordx4 a[160:163], %1, off\n\tglobal_load_dwordx4 a[164:167], %1, off offset:32\n\tglobal_load_dwordx4 a[168:171], %1, off offset:64\n\t"
+                    "global_load_dwordx4 a[172:175], %1, off offset:96\n\tglobal_load_dwordx4 a[176:179], %1, off offset:128\n\tglobal_load_dwordx4 a[180:183], %1, off offset:160\n\t"
+                    "global_load_dwordx4 a[184:187], %1, off offset:192\n\tglobal_load_dwordx4 a[188:191], %1, off offset:224"
+                    :
                     : "v"(k_ptr), "v"(v_ptr)
                     : "memory");
             }
@@ -465,7 +466,9 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
             if (DKV3_ROWS_VIA_LDS) {      // (rows of the wave in the tensor: uniform)
                 const int rows_ok = wave_u == 0 ? DKV3_F(rec, ROWS_OK0) : wave_u == 1 ? DKV3_F(rec, ROWS_OK1) : wave_u == 2 ? DKV3_F(rec, ROWS_OK2) : DKV3_F(rec, ROWS_OK3);
                 const unsigned long long dk0 = ((unsigned long long)(unsigned)DKV3_F(rec, DK_HI) << 32) | (unsigned)DKV3_F(rec, DK_LO);
-                bf16_t* w0 = (bf16_t*)(size_t)(dk0 + (unsigned long long)(32u * wave_u) * ld2);
+                // (through a GLOBAL-typed pointer: an address built from integers is a generic one to the compiler, and generic stores are FLAT
+                // instructions - they count on the LDS counter too, every LDS read behind one waited for vmcnt(0): 7 000 cycles per item, measured)
+                bf16_t* w0 = (bf16_t*)(__attribute__((address_space(1))) bf16_t*)(size_t)(dk0 + (unsigned long long)(32u * wave_u) * ld2);
                 // the ring slot the item's last tile has left: free until the next item's first step (its prefetched tiles sit in the other three)
                 const int free_slot = (ring_base + ntiles - 1) & 3;
                 char* rope_c = smem + free_slot * DKV3_TILE + wave * 4096;

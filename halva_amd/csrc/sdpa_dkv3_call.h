@@ -46,10 +46,7 @@
                 : [accV0] DKV3_ACC_MOD "{a[0:15]}"(accV[0]), [accV1] DKV3_ACC_MOD "{a[16:31]}"(accV[1]), [accV2] DKV3_ACC_MOD "{a[32:47]}"(accV[2]), [accV3] DKV3_ACC_MOD "{a[48:63]}"(accV[3]),
                   [accK0] DKV3_ACC_MOD "{a[64:79]}"(accK[0]), [accK1] DKV3_ACC_MOD "{a[80:95]}"(accK[1]), [accK2] DKV3_ACC_MOD "{a[96:111]}"(accK[2]), [accK3] DKV3_ACC_MOD "{a[112:127]}"(accK[3]),
                   [drawn] "=&v"(drawn_out)
-                : [sched_ptr] "v"(home_counter), [rec_ptr] "v"(rec_ptr), [kq0] "{a[128:131]}"(kq[0]), [kq1] "{a[132:135]}"(kq[1]), [kq2] "{a[136:139]}"(kq[2]), [kq3] "{a[140:143]}"(kq[3]), [kq4] "{a[144:147]}"(kq[4]),
-                  [kq5] "{a[148:151]}"(kq[5]), [kq6] "{a[152:155]}"(kq[6]), [kq7] "{a[156:159]}"(kq[7]), [vq0] "{a[160:163]}"(vq[0]), [vq1] "{a[164:167]}"(vq[1]),
-                  [vq2] "{a[168:171]}"(vq[2]), [vq3] "{a[172:175]}"(vq[3]), [vq4] "{a[176:179]}"(vq[4]), [vq5] "{a[180:183]}"(vq[5]), [vq6] "{a[184:187]}"(vq[6]),
-                  [vq7] "{a[188:191]}"(vq[7]), [rowrel] "v"(rowrel), [colrel] "v"(colrel), [statrel] "v"(statrel), [voff_q] "v"(voff_q), [voff_do] "v"(voff_do),
+                : [sched_ptr] "v"(home_counter), [rec_ptr] "v"(rec_ptr), [rowrel] "v"(rowrel), [colrel] "v"(colrel), [statrel] "v"(statrel), [voff_q] "v"(voff_q), [voff_do] "v"(voff_do),
                   [sc] "s"(sc), [n02] "s"(n02_u), [n1] "s"(n1_u), [ndma] "s"(ndma_u), [wave] "s"(wave_u), [q_piece] "s"(q_piece), [do_piece] "s"(do_piece),
                   [lo0] "v"(lo0), [range] "v"(range), [stat_voff] "v"(stat_voff),
                   [ctl] "s"(ctl_u),
