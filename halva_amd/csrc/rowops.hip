@@ -223,10 +223,12 @@ __global__ __launch_bounds__(256) void splice_rows_kernel(const u32x4* __restric
 
 // One 16-byte chunk per thread, no grid-stride loop (round 5, experiments/rowops_stream: the swiglu_bwd pattern at the step's shape streams at
 // 5.3 TB/s that way against 5.0 with the grid capped at 8192 blocks, and at 5.8 with nontemporal accesses on top - stream_load / stream_store);
-// the kernels keep their loops for grids beyond 2^31 - 1 blocks.
+// the kernels keep their grid-stride loops for what lies beyond the largest launch: HIP rejects a grid whose gridDim.x * blockDim.x exceeds
+// 2^32 - 1 threads (hipErrorInvalidConfiguration), so the cap is (2^32 - 1) / block BLOCKS (a cap of 2^31 - 1 blocks would have
+// failed to launch where the 8 192-block grids of rounds 1-4 simply looped - unreachable at today's shapes, a 64-GiB tensor).
 inline int grid_for(int64_t total, int block) {
     int64_t g = (total + block - 1) / block;
-    const int64_t cap = 0x7fffffff;
+    const int64_t cap = 0xffffffffll / block;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 

@@ -1978,7 +1978,9 @@ int launch_bwd(const SdpaParams& p_in, int S, hipStream_t st, bool* fused_rope =
         // the inverse RoPE of dq / dk rides in the store epilogues of sdpa_bwd_dq2 and of sdpa_bwd_dkv3's generated build; any other kernel
         // combination leaves them un-rotated and halva_sdpa_branch_bwd_rope follows up with halva_rope_qk_branch (p_in.rope_cos stays set)
         const bool use_asm = env_flag_on("HALVA_DKV3_ASM");
-        if (!(dkv3 && use_asm && !slow && env_flag_on("HALVA_ROPE_FUSED_BWD"))) p.rope_cos = p.rope_sin = nullptr;
+        // (DKV3_ROWS_VIA_LDS: the dK rows are rotated by dkv3_store_rows_lds only - a -DDKV3_ROWS_VIA_LDS=0 build stores them un-rotated, so it
+        // must not report the rotation as done)
+        if (!(dkv3 && use_asm && !slow && DKV3_ROWS_VIA_LDS && env_flag_on("HALVA_ROPE_FUSED_BWD"))) p.rope_cos = p.rope_sin = nullptr;
         if (fused_rope) *fused_rope = p.rope_cos != nullptr;
         if (dkv3) {
             static_assert(CAUSAL || D != 128, "sdpa_bwd_dkv3's item records are written for the causal backward (dkv3_build_record<true>)");

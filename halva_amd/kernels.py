@@ -131,10 +131,17 @@ def rope_tables(head_dim, max_pos, base=10000.0, device="cuda", linear_factor=1.
     return freqs.cos().to(torch.bfloat16).contiguous(), freqs.sin().to(torch.bfloat16).contiguous()
 
 
-def _rope_inplace(qkv, cos, sin, T, H, D, inverse, pos=None):
-    """pos: optional int32 [rows] position of every row (branch-packed sequences); default = row index inside its sequence."""
+def _rope_inplace(qkv, cos, sin, T, H, D, inverse, branch=None):
+    """branch: optional (br_a, br_b[, ...]) int32 [S] device tensors of branch-packed rows [prefix | A | pad | B]: row t sits at position t, rows of
+    B (t >= br_b) at br_a + (t - br_b) - halva_rope_qk_branch, the SAME rule the attention backward's rotating epilogues apply
+    (halva_sdpa_branch_bwd_rope).  Round 6: the forward used to rotate with a caller-supplied position table while the backward
+    derived the positions from the branch points - a table that disagreed with them gave silently wrong dq / dk.  One source of truth now: the
+    branch points, in both directions; the table splice.pack_pairs still returns is what tests/test_pack_pairs_cpu.py holds to that rule."""
     rows = qkv.numel() // (3 * H * D)
-    call("halva_rope_qk", ptr(qkv), ptr(cos), ptr(sin), ptr(pos), rows, T, H, D, cos.shape[0], int(inverse), stream_ptr())
+    if branch is None:
+        call("halva_rope_qk", ptr(qkv), ptr(cos), ptr(sin), ptr(None), rows, T, H, D, cos.shape[0], int(inverse), stream_ptr())
+    else:
+        call("halva_rope_qk_branch", ptr(qkv), ptr(cos), ptr(sin), ptr(branch[0]), ptr(branch[1]), rows, T, H, D, cos.shape[0], int(inverse), stream_ptr())
 
 
 class _RopeQK(torch.autograd.Function):
@@ -143,9 +150,9 @@ class _RopeQK(torch.autograd.Function):
     buffer), so this node's backward is the identity."""
 
     @staticmethod
-    def forward(ctx, qkv, cos, sin, H, D, pos=None):
+    def forward(ctx, qkv, cos, sin, H, D, branch=None):
         _chk(qkv, torch.bfloat16, "qkv")
-        _rope_inplace(qkv, cos, sin, qkv.shape[1], H, D, False, pos)
+        _rope_inplace(qkv, cos, sin, qkv.shape[1], H, D, False, branch)
         ctx.mark_dirty(qkv)
         return qkv
 
@@ -181,14 +188,14 @@ class _SdpaCausal(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qkv, seq_start, seq_len, H, D, cos, sin, out_width=None, branch=None):
-        """branch: optional (br_a, br_b, pos) int32 device tensors - packed [prefix | A | B] rows whose B part must not see A
-        (halva_sdpa_branch_fwd) and whose RoPE positions are given explicitly."""
+        """branch: optional (br_a, br_b[, pos]) int32 device tensors - packed [prefix | A | B] rows whose B part must not see A
+        (halva_sdpa_branch_fwd); their RoPE positions follow from the branch points (_rope_inplace); a third entry is ignored."""
         _chk(qkv, torch.bfloat16, "qkv")
         S, T = qkv.shape[0], qkv.shape[1]
         width = out_width or H * D
         out = torch.empty(S, T, width, dtype=torch.bfloat16, device=qkv.device)
         lse = torch.empty(S, H, T, dtype=torch.float32, device=qkv.device)
-        br_a, br_b, pos = branch if branch is not None else (None, None, None)
+        br_a, br_b = (branch[0], branch[1]) if branch is not None else (None, None)
         probe = sdpa_fwd_probe
         if probe is not None:          # bench.py: HIP events around the launch, on the stream it goes to
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -215,7 +222,7 @@ class _SdpaCausal(torch.autograd.Function):
         dout = _chk(dout.contiguous(), torch.bfloat16, "dout")
         dqkv = torch.empty_like(qkv)
         delta = torch.empty(S, H, T, dtype=torch.float32, device=qkv.device)
-        br_a, br_b, pos = ctx.branch if ctx.branch is not None else (None, None, None)
+        br_a, br_b = (ctx.branch[0], ctx.branch[1]) if ctx.branch is not None else (None, None)
         probe = sdpa_bwd_probe
         if probe is not None:          # bench.py: HIP events around the launch, on the stream it goes to
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -235,7 +242,7 @@ class _SdpaCausal(torch.autograd.Function):
 
 def attention(qkv, cos, sin, seq_start, seq_len, H, D, out_width=None, branch=None):
     """RoPE (in place) + causal attention on a packed [S, T, 3*H*D] projection output."""
-    qkv = _RopeQK.apply(qkv, cos, sin, H, D, None if branch is None else branch[2])
+    qkv = _RopeQK.apply(qkv, cos, sin, H, D, branch)      # (positions from the branch points, as in the backward; branch[2], a position table, is not read)
     return _SdpaCausal.apply(qkv, seq_start, seq_len, H, D, cos, sin, out_width, branch)
 
 

@@ -301,36 +301,46 @@ class HalvaTrainer:
         fp32 master weights, AdamW moments, step / epoch / micro-batch position (an epoch's batch order follows from seed + epoch)."""
         a = self.args
         folder = os.path.join(a.output_dir, "%s-%d" % (self.CKPT_PREFIX, self.state.global_step))
+        save_error = None
         if self.dist.rank == 0:
-            os.makedirs(folder, exist_ok=True)
-            self.model.config.save_pretrained(folder)
-            if getattr(a, "tune_mm_mlp_adapter", False):
-                proj, _ = dpa._projector_of(self.model)
-                torch.save({"model.mm_projector." + k: v.detach().cpu() for k, v in proj.state_dict().items()},
-                           os.path.join(folder, "mm_projector.bin"))
-            else:
-                self._save_adapter(folder)
-            torch.save({"master": self._flat.master.detach().cpu(), "names": list(self._flat.names),
-                        "optimizer": self.optimizer.state_dict(), "global_step": self.state.global_step,
-                        "epoch_index": self._pos["epoch"], "micro_in_epoch": self._pos["micro"],
-                        "micro_total": self._pos["total"], "pending_micro": self._pos.get("pending", 0),
-                        "epoch_rng_state": self._pos["rng"], "log_history": self.state.log_history,
-                        "world": self.dist.world},
-                       os.path.join(folder, "halva_state.pt"))
-            with open(os.path.join(folder, "trainer_state.json"), "w") as f:
-                json.dump({"global_step": self.state.global_step, "epoch": self.state.epoch, "log_history": self.state.log_history}, f,
-                          indent=1)
-            limit = getattr(a, "save_total_limit", None)
-            if limit is not None and limit > 0:                   # HF _rotate_checkpoints: keep the newest `limit`
-                for old in self._checkpoint_dirs()[:-limit]:
-                    import shutil
-                    shutil.rmtree(old, ignore_errors=True)
+            try:
+                os.makedirs(folder, exist_ok=True)
+                self.model.config.save_pretrained(folder)
+                if getattr(a, "tune_mm_mlp_adapter", False):
+                    proj, _ = dpa._projector_of(self.model)
+                    torch.save({"model.mm_projector." + k: v.detach().cpu() for k, v in proj.state_dict().items()},
+                               os.path.join(folder, "mm_projector.bin"))
+                else:
+                    self._save_adapter(folder)
+                torch.save({"master": self._flat.master.detach().cpu(), "names": list(self._flat.names),
+                            "optimizer": self.optimizer.state_dict(), "global_step": self.state.global_step,
+                            "epoch_index": self._pos["epoch"], "micro_in_epoch": self._pos["micro"],
+                            "micro_total": self._pos["total"], "pending_micro": self._pos.get("pending", 0),
+                            "epoch_rng_state": self._pos["rng"], "log_history": self.state.log_history,
+                            "world": self.dist.world},
+                           os.path.join(folder, "halva_state.pt"))
+                with open(os.path.join(folder, "trainer_state.json"), "w") as f:
+                    json.dump({"global_step": self.state.global_step, "epoch": self.state.epoch, "log_history": self.state.log_history}, f,
+                              indent=1)
+                limit = getattr(a, "save_total_limit", None)
+                if limit is not None and limit > 0:                   # HF _rotate_checkpoints: keep the newest `limit`
+                    for old in self._checkpoint_dirs()[:-limit]:
+                        import shutil
+                        shutil.rmtree(old, ignore_errors=True)
+            except Exception as e:      # (the other ranks are waiting at the barrier below: tell them instead of leaving them there)
+                save_error = e
+
         # rank 0's folder (with halva_state.pt) exists before any other rank looks for it - and every rank must SEE it: the per-rank files below
         # are only of use beside rank 0's state, so output_dir has to be on a filesystem all ranks share.  A rank that does not see the folder
         # (node-local output_dir on a multi-node run) used to write its accumulator into a private folder without halva_state.pt, which the
         # resumed run then could not load, or loaded from a stale one (round-4 advice); now every rank fails together, at save time.
-        dp.barrier(self.dist)
-        seen = os.path.exists(os.path.join(folder, "halva_state.pt"))
+        # Round 6 (ADVICE r05): (i) a failure of rank 0's save is a collective decision too - broadcast through the same MAX reduction, every rank
+        # raises; (ii) on NFS-like filesystems a rank can briefly miss a file another host has just written (attribute / negative-lookup caches):
+        # the existence check is retried for a few seconds, listing the parent directory in between (which refreshes those caches), before the
+        # folder is declared invisible.
+        if dp.max_scalar(1.0 if save_error is not None else 0.0, self.dist) > 0:
+            raise RuntimeError("rank 0 could not write checkpoint %s: %s" % (folder, save_error if save_error is not None else "(see rank 0)"))
+        seen = self._wait_until_visible(os.path.join(folder, "halva_state.pt"))
         if dp.max_scalar(0.0 if seen else 1.0, self.dist) > 0:
             raise RuntimeError("checkpoint folder %s written by rank 0 is not visible to every rank (this rank %d: %s): --output_dir must be on "
                                "a filesystem shared by all ranks" % (folder, self.dist.rank, "visible" if seen else "NOT visible"))
@@ -345,6 +355,22 @@ class HalvaTrainer:
                        os.path.join(folder, "halva_pending_grad_rank%d.pt" % self.dist.rank))
         dp.barrier(self.dist)
         return folder
+
+    @staticmethod
+    def _wait_until_visible(path, seconds=5.0):
+        """os.path.exists with retries: True as soon as `path` shows up, False after `seconds`."""
+        import time
+        deadline = time.time() + seconds
+        while True:
+            if os.path.exists(path):
+                return True
+            if time.time() >= deadline:
+                return False
+            try:
+                os.listdir(os.path.dirname(path) or ".")      # refreshes a network filesystem's directory / negative-lookup cache
+            except OSError:
+                pass
+            time.sleep(0.2)
 
     def _save_adapter(self, folder):
         """The trained tensors in the run's output naming (llava/train/train_halva.py:save_lora_outputs; VILA overrides)."""

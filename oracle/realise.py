@@ -17,7 +17,8 @@ import contextlib
 import torch
 import torch.nn.functional as F
 
-# the set used by the tests: name -> (permutation seed or None, chunks)
+# the set used by the tests: name -> (permutation seed or None, chunks).  FROZEN (round 6): a bound defined as "the largest of the set"
+# loosens whenever a realisation is added, so nothing is added or removed any more; tests/test_oracle_vs_golden.py pins the names.
 REALISATIONS = {
     "plain": (None, 1),
     "perm1": (1, 1),
@@ -32,6 +33,13 @@ REALISATIONS = {
     "perm8": (8, 1),
     "chunk3": (None, 3),
 }
+
+
+# The realisations the test BOUNDS are taken over (round 6): the permutation-only ones.  The chunked ones round split-K partial products
+# to bf16 and add them in bf16 - no GEMM the reference runs does that (cuBLAS, hipBLASLt and flash-attn accumulate in fp32 and round once) - so they
+# stay in the table as information, not as draws of the reference.  (On the smallest fixture the six permutations give the SAME numbers: with K = 64
+# and fp32 accumulation the order of a sum does not reach the bf16 result - the legitimate spread there is two draws wide, and that is the finding.)
+BOUND_SET = tuple(n for n, (_, chunks) in REALISATIONS.items() if chunks == 1)
 
 
 @contextlib.contextmanager

@@ -35,7 +35,9 @@ def run(out_path):
     opt = dpa.AdamWFlat(flat, lr=1e-3, weight_decay=0.0, mm_projector_lr=1e-3)
     eng = dpa.DPAEngine(pol, ref, float(z["alpha"]), pairs_per_group=1, ref_rows_per_group=1)
     reducer = dp.GradReducer.for_flat(flat, ctx, min_bucket=1)          # one bucket per decoder layer + the projector
-    batch = micro_batch(batch_of(z), [ctx.rank, ctx.rank + 1])
+    full = batch_of(z)
+    n = full["input_ids"].shape[0]
+    batch = micro_batch(full, [ctx.rank % n, (ctx.rank + 1) % n])      # (pairs rank, rank + 1 of the fixture batch, wrapping: 8 ranks on 4 pairs)
     flat.zero_grad()
     loss = float(eng.loss(batch, backward=True, reducer=reducer))
     early = reducer.issued_early

@@ -29,7 +29,8 @@ def plain(masked):
     return s[len("<MASK> "):] if s.startswith("<MASK> ") else s
 
 
-def build(root):
+def build(root, n_samples=None):
+    """n_samples: more than len(SAMPLES) repeats them under new ids / images (the 8-rank test needs 8 micro-batches per optimizer step)"""
     from PIL import Image
     from safetensors.torch import save_file
     z = load_npz("dpa_step_d64_init.npz")
@@ -51,13 +52,15 @@ def build(root):
               open(os.path.join(vt, "preprocessor_config.json"), "w"))
     rng = np.random.RandomState(0)
     rows, refs = [], []
-    for i, (tag, q, pos, neg) in enumerate(SAMPLES):
+    samples = SAMPLES if n_samples is None else [SAMPLES[i % len(SAMPLES)] for i in range(n_samples)]
+    for i, (tag, q, pos, neg) in enumerate(samples):
         name = "coco/im%d.png" % i
         Image.fromarray(rng.randint(0, 255, (24 + 3 * i, 30, 3), dtype=np.uint8)).save(os.path.join(img, name))
         rows.append({"id": i, "image": name, "tag": tag, "raw_answer": "yes" if "Yes" in pos else "no", "question": "<image>\n" + q,
                      "correct_answer": plain(pos), "correct_answer_masked": pos, "hallucinated_answer": plain(neg),
                      "hallucinated_answer_masked": neg})
-    for i, (q, a) in enumerate(REF):
+    ref_rows = REF if n_samples is None else [REF[i % len(REF)] for i in range(max(len(REF), n_samples + 2))]      # (the reference asserts len(ref) > len(data))
+    for i, (q, a) in enumerate(ref_rows):
         refs.append({"id": "r%d" % i, "image": "coco/im%d.png" % (i % len(SAMPLES)),
                      "conversations": [{"from": "human", "value": "<image>\n" + q}, {"from": "gpt", "value": a}]})
     json.dump(rows, open(os.path.join(data, "data.json"), "w"))

@@ -6,13 +6,17 @@ from golden_util import meta_of, tensors
 
 
 def build_product_models(z, device="cuda", lora=True):
-    from halva_amd.clip import CLIPVisionConfig, CLIPVisionTower, build_vision_projector
-    from halva_amd.llama import add_lora, load_hf_llama_weights
-    from halva_amd.llava_model import LlavaConfig, LlavaLlamaForCausalLM
     cfg_d, clip_d = meta_of(z, "llama_cfg"), meta_of(z, "clip_cfg")
     base, clipW, fac = tensors(z, "base."), tensors(z, "clip."), tensors(z, "lora.")
     r, alpha = int(z["lora_cfg"][0]), float(z["lora_cfg"][1])
-    max_len = int(z["max_len"])
+    return build_product_models_from(cfg_d, clip_d, base, clipW, fac, r, alpha, int(z["max_len"]), device, lora)
+
+
+def build_product_models_from(cfg_d, clip_d, base, clipW, fac, r, alpha, max_len, device="cuda", lora=True):
+    """(policy, reference, (r, alpha, factors)) from weight dicts in the fixtures' naming (HF names, fp32 tensors holding bf16 values)."""
+    from halva_amd.clip import CLIPVisionConfig, CLIPVisionTower, build_vision_projector
+    from halva_amd.llama import add_lora, load_hf_llama_weights
+    from halva_amd.llava_model import LlavaConfig, LlavaLlamaForCausalLM
 
     def make(with_lora):
         cfg = LlavaConfig(**cfg_d)

@@ -49,7 +49,7 @@ def _launch(world, out, backend, share_gpu):
     assert codes == [0] * world, codes
 
 
-def _single_process_reference():
+def _single_process_reference(world=2):
     from dp_worker import micro_batch
     from golden_util import load_npz
     from model_util import batch_of, build_product_models
@@ -62,15 +62,17 @@ def _single_process_reference():
     opt = dpa.AdamWFlat(flat, lr=1e-3, weight_decay=0.0, mm_projector_lr=1e-3)
     eng = dpa.DPAEngine(pol, ref, float(z["alpha"]), pairs_per_group=1, ref_rows_per_group=1)
     flat.zero_grad()
-    losses = [float(eng.loss(micro_batch(batch_of(z), [r, r + 1]), backward=True, scale=0.5)) for r in range(2)]
+    full = batch_of(z)
+    n = full["input_ids"].shape[0]
+    losses = [float(eng.loss(micro_batch(full, [r % n, (r + 1) % n]), backward=True, scale=1.0 / world)) for r in range(world)]
     grad = flat.grad.detach().cpu().clone()
     opt.step()
-    return grad, flat.master.detach().cpu(), sum(losses) / 2
+    return grad, flat.master.detach().cpu(), sum(losses) / world
 
 
-def _check(got, want):
+def _check(got, want, world=2):
     grad, master, loss = want
-    assert got["world"] == 2
+    assert got["world"] == world
     assert abs(got["loss"] - loss) < 1e-6
     # every per-micro-batch gradient is produced by the same deterministic kernels; (a + b) / 2 vs a/2 + b/2 in fp32
     scale = float(grad.abs().max())
@@ -85,6 +87,16 @@ def test_two_ranks_sharing_one_gpu_match_one_rank(tmp_path):
     out = str(tmp_path / "dp2.pt")
     _launch(2, out, "gloo", share_gpu=True)
     _check(torch.load(out, weights_only=False), _single_process_reference())
+
+
+def test_eight_ranks_sharing_one_gpu_match_one_rank(tmp_path):
+    """PLUMBING at the recipe's rank count (every multi-process test stopped at world = 2, so the first 8-GPU run would have
+    been the first 8-rank run of any kind; reference src/hallava_7b.sh:21-22,30).  Eight rank processes of the real engine on one GPU (gloo,
+    host-staged buckets), micro-batch r = pairs (r, r + 1) mod 4 of the fixture: flat fp32 gradient, mean loss and the weights after AdamW equal
+    one process accumulating the same eight micro-batches (scale 1/8).  No scaling curve can come of it."""
+    out = str(tmp_path / "dp8.pt")
+    _launch(8, out, "gloo", share_gpu=True)
+    _check(torch.load(out, weights_only=False), _single_process_reference(8), world=8)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL)")
@@ -148,6 +160,37 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_pairs"] == 4 and rec["value"] > 0
     assert rec["grad_allreduce"]["buckets_issued_inside_backward"] >= 1
+
+
+def test_bench_eight_ranks_and_a_collective_out_of_memory_fallback(tmp_path):
+    """`python bench.py --gpus 8 --global-pairs 8` (1 pair per rank, two layers, the ranks sharing the GPU of a 1-GPU box): one JSON line, n_gpus 8,
+    global 8 - the spawner's port handling, `--global-pairs` / 8, eight reducers.  Then 4 pairs per rank with rank 5 capped below what groups of 4
+    and of 2 need: all eight ranks must fall back together, twice.  Plumbing only: the ranks share one GPU, the line's value means nothing."""
+    import json
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 8:
+        env["HALVA_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--global-pairs", "8", "--steps", "1", "--warmup", "1", "--layers", "2",
+                        "--pairs-per-group", "1", "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["config"]["global_pairs"] == 8 and rec["config"]["pairs_per_gpu"] == 1 and rec["value"] > 0
+    assert rec["grad_allreduce"]["world"] == 8 and rec["grad_allreduce"]["buckets_issued_inside_backward"] >= 1
+    total = torch.cuda.get_device_properties(0).total_memory
+    # the 2-rank test's memory ladder (4 pairs per rank, two layers: groups of 4 pairs 11.2 / 12.2 GiB at the peak, of 2 pairs 8.5 / 9.9, of 1 pair
+    # 6.2 / 6.7): rank 5 alone capped at 7.6 GiB -> two collective fall-backs of all eight ranks
+    env["HALVA_BENCH_MEM_FRACTION"] = "5:%.5f" % (7.6 * 2 ** 30 / total)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--global-pairs", "32", "--steps", "1", "--warmup", "1", "--layers", "2",
+                        "--pairs-per-group", "4", "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["config"]["oom_fallbacks_in_warmup"] == 2 and rec["config"]["pairs_per_group"] == 1 and rec["n_gpus"] == 8, (rec["config"], r.stderr[-2000:])
 
 
 def test_bench_out_of_memory_on_one_rank_is_a_collective_decision(tmp_path):
@@ -225,3 +268,51 @@ def test_deepspeed_shim_two_ranks_train_like_one_rank_with_accumulation(tmp_path
     assert set(a2) == set(a1)
     for k in a1:
         assert float((a2[k].float() - a1[k].float()).norm()) <= 2e-2 * float(a1[k].float().norm()) + 1e-6, k
+
+
+def test_deepspeed_shim_eight_ranks_train_like_one_rank_with_accumulation(tmp_path):
+    """`deepspeed --num_gpus 8 train_halva.py` with the flag set of src/hallava_7b.sh:30-69 against ONE rank with --gradient_accumulation_steps 8:
+    the sampler is built for world x accumulation = 8 either way (llava/train/halva_trainer.py:261-274), so both consume the same 8 micro-batches
+    per optimizer step - same step count, losses, adapter.  Eight samples, one per rank and step; the ranks share the GPU of a 1-GPU box (gloo)."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import e2e_util
+    paths = e2e_util.build(str(tmp_path), n_samples=8)
+    runner = os.path.join(str(tmp_path), "run_train.py")
+    with open(runner, "w") as f:
+        f.write("import sys\nsys.path[:0] = [%r, %r, %r]\n"
+                "import e2e_util, pytest\nfrom _pytest.monkeypatch import MonkeyPatch\n"
+                "paths = dict(vocab_size=%d, data=%r, ref=%r, images=%r, vision=%r)\n"
+                "e2e_util.patch_tokenizer(MonkeyPatch(), paths['vocab_size'], warm_paths=paths)\n"
+                "import llava.train.train_halva as TH\nTH.train(sys.argv[1:])\n"
+                % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden"), paths["vocab_size"], paths["data"], paths["ref"],
+                   paths["images"], paths["vision"]))
+
+    def argv(out, accum):      # every flag of the reference's launch line (src/hallava_7b.sh:30-69) that the run's size allows
+        return ("--lora_enable True --lora_r 8 --lora_alpha 16 --mm_projector_lr 0 --deepspeed %s --loss_alpha 0.4 --model_name_or_path %s --version v1 "
+                "--data_path %s --ref_data_path %s --image_folder %s --vision_tower %s --mm_projector_type mlp2x_gelu "
+                "--mm_vision_select_layer -2 --mm_use_im_start_end False --mm_use_im_patch_token False --image_aspect_ratio pad "
+                "--group_by_modality_length True --bf16 True --output_dir %s --num_train_epochs 2 --per_device_train_batch_size 1 "
+                "--per_device_eval_batch_size 4 --gradient_accumulation_steps %d --evaluation_strategy no --save_strategy no --save_steps 50000 "
+                "--save_total_limit 1 --learning_rate 1e-3 --weight_decay 0. --warmup_ratio 0.03 --lr_scheduler_type cosine --logging_steps 1 "
+                "--tf32 True --model_max_length 64 --gradient_checkpointing True --dataloader_num_workers 0 --lazy_preprocess True "
+                "--report_to none --run_name dp8" % (os.path.join(ROOT, "src", "json", "zero3.json"), paths["ckpt"], paths["data"], paths["ref"],
+                                                     paths["images"], paths["vision"], out, accum)).split()
+    env = dict(os.environ, HALVA_SHARE_GPU="1" if torch.cuda.device_count() < 8 else "0", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out8, out1 = os.path.join(str(tmp_path), "dp8"), os.path.join(str(tmp_path), "dp1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "deepspeed"), "--num_gpus", "8", runner] + argv(out8, 1), env=env,
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "deepspeed"), "--num_gpus", "1", runner] + argv(out1, 8), env=env,
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    s8, s1 = (json.load(open(os.path.join(o, "trainer_state.json"))) for o in (out8, out1))
+    assert s8["global_step"] == s1["global_step"] == 2                       # 8 samples / (1 per rank x 8 ranks) x 2 epochs
+    l8, l1 = ([x["loss"] for x in st["log_history"] if "loss" in x] for st in (s8, s1))
+    assert max(abs(a - b) for a, b in zip(l8, l1)) < 2e-3, (l8, l1)         # mean over ranks == mean over the accumulated micro-batches
+    a8, a1 = (torch.load(os.path.join(o, "adapter_model.bin")) for o in (out8, out1))
+    assert set(a8) == set(a1)
+    for k in a1:
+        assert float((a8[k].float() - a1[k].float()).norm()) <= 2e-2 * float(a1[k].float().norm()) + 1e-6, k

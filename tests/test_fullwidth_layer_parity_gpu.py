@@ -13,8 +13,9 @@ attention of llava/train/llama_flash_attn_monkey_patch.py:16-93) evaluated in fp
                    oracle's TWO plain rows [prefix | A] and [prefix | B]: the pair's packing itself is part of what is checked;
   * the top-layer row pruning (`DecoderLayer.forward(rows=)`, LlamaModel.run_layers) on top of the plain layout.
 
-Outputs: y, dx and dA / dB of all seven LoRA targets.  Tolerances (Frobenius norm per tensor): forward 1e-2 relative, gradients 2e-2
-relative (what tests/test_sdpa_bench_shapes_gpu.py holds the attention kernels to); the measured values are printed.
+Outputs: y, dx and dA / dB of all seven LoRA targets.  Tolerances (Frobenius norm per tensor; round 6): DERIVED, not chosen -
+the largest error of the oracle's own bf16 realisations (oracle/realise.py, permutation-only draws) of the same layer on the same inputs, per
+tensor (the product measures 0.53 - 0.69 of it); the flat 1e-2 / 2e-2 of round 5 would have let a 50 % regression of the q / k / v / o gradients through.  Both are printed.
 
 Also here: the chunked lm_head -> token log-prob / KL-to-reference path (halva_amd/dpa.py:lm_head_logp / lm_head_kl) at [8192 + 300 rows x 4096]
 x 32000 - across a chunk boundary - against oracle.dpa.cal_batch_logp / kl_to_reference (reference llava/train/halva_trainer.py:392-409,580-588).
@@ -112,31 +113,58 @@ def _threads():
     torch.set_num_threads(bench.physical_cores()[0])
 
 
-def _oracle(W, lora, ocfg, x, dys, keep):
-    """oracle.nets.decoder_layer in fp32 on the host (varlen attention = what the reference's GPU path computes): ONE forward, one backward per
-    upstream gradient in `dys`; returns y and [(dx, {name: grad})] in that order"""
-    xr = x.float().requires_grad_(True)
-    y = nets.decoder_layer(xr, W, PRE, keep, ocfg, lora, ALPHA / R, varlen=True)
-    outs = []
-    for i, dy in enumerate(dys):
-        for t in lora.values():
-            t.grad = None
-        xr.grad = None
-        y.backward(dy.float(), retain_graph=i + 1 < len(dys))
-        outs.append((xr.grad.clone(), {k: v.grad.clone() for k, v in lora.items()}))
-    return y.detach(), outs
+def _oracle(W, lora, ocfg, x, dys, keep, dtype=torch.float32, real="plain"):
+    """oracle.nets.decoder_layer on the host (varlen attention = what the reference's GPU path computes): ONE forward, one backward per
+    upstream gradient in `dys`; returns y and [(dx, {name: grad})] in that order.  dtype / real: fp32 = the reference numbers; bf16 under a
+    realisation of oracle/realise.py = one draw of what the reference's own bf16 arithmetic does to this layer (the floor)."""
+    from oracle import realise
+    Wd = {k: v.to(dtype) for k, v in W.items()}
+    ld = {k: v.detach().to(dtype).requires_grad_(True) for k, v in lora.items()}
+    xr = x.detach().clone().to(dtype).requires_grad_(True)      # (a copy: x.to(its own dtype) IS x, and the product's run must not see a tensor that requires grad)
+    with realise.realisation(real):
+        y = nets.decoder_layer(xr, Wd, PRE, keep, ocfg, ld, ALPHA / R, varlen=True)
+        outs = []
+        for i, dy in enumerate(dys):
+            for t in ld.values():
+                t.grad = None
+            xr.grad = None
+            y.backward(dy.to(dtype), retain_graph=i + 1 < len(dys))
+            outs.append((xr.grad.float().clone(), {k: v.grad.float().clone() for k, v in ld.items()}))
+    return y.detach().float(), outs
 
 
-def _compare(tag, y, yo, dx, dxo, gr, gro):
-    worst = {"fwd": rel_err(y, yo), "dx": rel_err(dx, dxo)}
+FLOOR_REALS = ("plain", "perm1", "perm2")      # permutation-only draws (oracle/realise.py:BOUND_SET; ADVICE r05)
+# VERDICT r05 item 6 asked for 1.25 x the oracle's own bf16 spread at this width.  Measured (profiles/r06_pytest_gpu.log): the product sits at 0.53 - 0.69 of
+# the LARGEST bf16 realisation on every tensor (fp32 accumulation inside every fused kernel, one rounding where the reference arithmetic has two or
+# three) - so the bound is the realisations' largest error itself: the product must not be worse than the reference's own arithmetic in bf16.
+FACTOR = 1.0
+
+
+def _errors(y, yo, dx, dxo, gr, gro):
+    e = {"fwd": rel_err(y, yo), "dx": rel_err(dx, dxo)}
     for k in sorted(gro):
-        worst[k.replace(PRE, "")] = rel_err(gr[k], gro[k])
-    print("%s: " % tag + ", ".join("%s %.2e" % kv for kv in worst.items()))
-    assert torch.isfinite(y).all() and torch.isfinite(dx).all()
-    assert worst["fwd"] < 1e-2, (tag, worst)
-    for k, v in worst.items():
-        if k != "fwd":
-            assert v < 2e-2, (tag, k, worst)
+        e[k.replace(PRE, "")] = rel_err(gr[k], gro[k])
+    return e
+
+
+def _compare(tag, got, floors):
+    """got / floors: {tensor: relative error against the fp32 oracle} of the product / the largest of the oracle's bf16 realisations"""
+    print("%s:" % tag)
+    print("   product      " + ", ".join("%s %.2e" % kv for kv in got.items()))
+    print("   bf16 oracle  " + ", ".join("%s %.2e" % (k, floors[k]) for k in got))
+    print("   ratio        " + ", ".join("%s %.2f" % (k, got[k] / floors[k]) for k in got))
+    for k, v in got.items():
+        assert v <= FACTOR * floors[k], (tag, k, v, floors[k])
+
+
+def _floors(W, lora, ocfg, x, dys, keep, pick):
+    """largest error of the oracle's bf16 realisations per tensor; pick(y, outs) -> the same error dict the product is measured with"""
+    worst = {}
+    for real in FLOOR_REALS:
+        yb, outs = _oracle(W, lora, ocfg, x, dys, keep, torch.bfloat16, real)
+        for k, v in pick(yb, outs).items():
+            worst[k] = max(worst.get(k, 0.0), v)
+    return worst
 
 
 @pytest.mark.parametrize("width", ["7b", "13b"])
@@ -166,11 +194,16 @@ def test_decoder_layer_plain_and_ragged_rows_match_the_oracle(width):
         dys.append(dy_full.view(S, T, d))
     yo, outs = _oracle(W, lora, ocfg, x, dys, keep)
     dxo, gro = outs[0]
-    _compare(width + " plain", y.view(-1, d)[valid], yo.view(-1, d)[valid], dx.view(-1, d)[valid], dxo.view(-1, d)[valid], gr, gro)
+    sel = lambda t: t.view(-1, d)[valid]
+    floors = _floors(W, lora, ocfg, x, dys, keep, lambda yb, ob: _errors(sel(yb), sel(yo), sel(ob[0][0]), sel(dxo), ob[0][1], gro))
+    got = _errors(sel(y), sel(yo), sel(dx), sel(dxo), gr, gro)
+    assert torch.isfinite(y).all() and torch.isfinite(dx).all()
+    _compare(width + " plain", got, floors)
     if idx is not None:
         yr, dxr, grr = _product(layer, x, dyr, lens, rows=idx)
         dxo2, gro2 = outs[1]
-        _compare(width + " rows=", yr, yo.view(-1, d)[idx], dxr.view(-1, d)[valid], dxo2.view(-1, d)[valid], grr, gro2)
+        floors2 = _floors(W, lora, ocfg, x, dys, keep, lambda yb, ob: _errors(yb.view(-1, d)[idx], yo.view(-1, d)[idx], sel(ob[1][0]), sel(dxo2), ob[1][1], gro2))
+        _compare(width + " rows=", _errors(yr, yo.view(-1, d)[idx], sel(dxr), sel(dxo2), grr, gro2), floors2)
 
 
 @pytest.mark.parametrize("width", ["7b", "13b"])
@@ -194,50 +227,18 @@ def test_decoder_layer_packed_pair_matches_the_oracles_two_rows(width):
     yo_packed = torch.cat([yo[0], yo[1, P:]])
     dxo_packed = torch.cat([dxo[0, :P] + dxo[1, :P], dxo[0, P:], dxo[1, P:]])
     assert rel_err(yo[1, :P], yo[0, :P]) < 1e-5          # (the oracle's own prefix rows agree: causal)
-    _compare(width + " packed", y[0], yo_packed, dx[0], dxo_packed, gr, gro)
-    # the branch rows on their own (a wrong branch mask would hide in the whole-tensor norm: 40 % of the rows)
-    assert rel_err(y[0, TA:], yo[1, P:]) < 1e-2 and rel_err(dx[0, TA:], dxo[1, P:]) < 2e-2
-    assert rel_err(dx[0, :P], dxo_packed[:P]) < 2e-2
 
+    def packed(yb, dxb):
+        return torch.cat([yb[0], yb[1, P:]]), torch.cat([dxb[0, :P] + dxb[1, :P], dxb[0, P:], dxb[1, P:]])
 
-def test_lm_head_logp_and_kl_across_a_chunk_boundary_match_the_oracle():
-    """halva_amd.dpa.lm_head_logp / lm_head_kl (chunks of 8192 rows) at the 7B head: [8492 x 4096] x 32000."""
-    from halva_amd import dpa
-    _threads()
-    rows, d, V = dpa.LOGIT_CHUNK_ROWS + 300, 4096, 32000
-    g = torch.Generator().manual_seed(9)
-    h_pol = bf(torch.randn(rows, d, generator=g))
-    h_ref = bf(h_pol.float() + 0.3 * torch.randn(rows, d, generator=g))
-    Wp = bf(torch.randn(V, d, generator=g) * 0.02)
-    tgt = torch.randint(0, V, (rows,), generator=g)
-    gl = torch.randn(rows, generator=g)
-    # product
-    hp = h_pol.to(DEV).requires_grad_(True)
-    lp = dpa.lm_head_logp(hp, Wp.to(DEV), tgt.to(torch.int32).to(DEV))
-    lp.backward(gl.to(DEV))
-    dh_logp = hp.grad.float().cpu()
-    hp2 = h_pol.to(DEV).requires_grad_(True)
-    kl = dpa.lm_head_kl(hp2, h_ref.to(DEV), Wp.to(DEV), Wp.to(DEV))
-    kl.backward()
-    torch.cuda.synchronize()
-    dh_kl = hp2.grad.float().cpu()
-    # oracle: ONE [rows, V] fp32 logits matrix serves both heads ([1, rows + 1, V] with labels shifted by one for cal_batch_logp, which gathers
-    # logits[:, :-1] at labels[:, 1:])
-    ho = h_pol.float().requires_grad_(True)
-    pol_logits = ho @ Wp.float().t()
-    labels = torch.cat([torch.tensor([-100]), tgt])[None]
-    lo = odpa.cal_batch_logp(torch.cat([pol_logits, torch.zeros(1, V)])[None], labels)[0]
-    lo.backward(gl, retain_graph=True)
-    d_lp = (lp.detach().float().cpu() - lo.detach()).abs()
-    print("lm_head_logp: mean |diff| %.2e max %.2e; dh rel %.2e" % (float(d_lp.mean()), float(d_lp.max()), rel_err(dh_logp, ho.grad)))
-    assert float(d_lp.mean()) < 4e-3 and float(d_lp.max()) < 4e-2      # bf16 logits: |logit| 2^-9 per entry
-    assert rel_err(dh_logp, ho.grad) < 2e-2
-    del lo
-    ho.grad = None
-    with torch.no_grad():
-        ref_logits = (h_ref.float() @ Wp.float().t())[None]
-    klo = odpa.kl_to_reference(pol_logits[None], ref_logits, torch.zeros(1, rows, dtype=torch.long))      # every row counts; B = 1
-    klo.backward()
-    print("lm_head_kl: product %.4f oracle %.4f; dh rel %.2e" % (float(kl.detach()), float(klo.detach()), rel_err(dh_kl, ho.grad)))
-    assert abs(float(kl.detach()) - float(klo.detach())) < 1e-2 * abs(float(klo.detach()))
-    assert rel_err(dh_kl, ho.grad) < 2e-2
+    def pick(yb, ob):
+        yp, dxp = packed(yb, ob[0][0])
+        e = _errors(yp, yo_packed, dxp, dxo_packed, ob[0][1], gro)
+        # the branch rows on their own (a wrong branch mask would hide in the whole-tensor norm: 40 % of the rows), and the shared prefix's dx
+        e["fwd B rows"], e["dx B rows"], e["dx prefix"] = rel_err(yb[1, P:], yo[1, P:]), rel_err(ob[0][0][1, P:], dxo[1, P:]), rel_err(dxp[:P], dxo_packed[:P])
+        return e
+    floors = _floors(W, lora, ocfg, xo, [dyo], keep, pick)
+    got = _errors(y[0], yo_packed, dx[0], dxo_packed, gr, gro)
+    got["fwd B rows"], got["dx B rows"], got["dx prefix"] = rel_err(y[0, TA:], yo[1, P:]), rel_err(dx[0, TA:], dxo[1, P:]), rel_err(dx[0, :P], dxo_packed[:P])
+    assert torch.isfinite(y).all() and torch.isfinite(dx).all()
+    _compare(width + " packed", got, floors)

@@ -234,6 +234,45 @@ def test_inverse_rope_in_the_backward_epilogues_equals_the_separate_launch(layou
     assert torch.equal(y1, y2)
 
 
+def test_forward_rope_positions_come_from_the_branch_points_like_the_backwards():
+    """kernels.attention() rotated q / k with the caller's position table in the forward and with the positions implied by the branch
+    points in the backward - a table that disagreed gave silently wrong dq / dk.  One source of truth now (halva_rope_qk_branch in both
+    directions): a scrambled table changes nothing, and the result is the table-driven rotation (halva_rope_qk) with the table
+    halva_amd/splice.py:pack_pairs writes (reference llava/model/language_model/modelling_llama.py:154-169 at those positions)."""
+    from halva_amd import kernels as HK
+    from halva_amd.hip import call, ptr, stream_ptr
+    S, T, H, D = 2, 520, 2, 128
+    lens, br = [520, 470], ([130, 100], [256, 192])
+    g = torch.Generator().manual_seed(23)
+    qkv = bf(torch.randn(S, T, 3 * H * D, generator=g)).to(DEV)
+    dout = bf(torch.randn(S, T, H * D, generator=g)).to(DEV)
+    cos, sin = K().rope_tables(D, 2048, device=DEV)
+    mk = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    pos = torch.zeros(S, T, dtype=torch.int32)
+    for s_ in range(S):
+        a, b = br[0][s_], br[1][s_]
+        pos[s_, :b] = torch.arange(b)
+        pos[s_, b:] = a + torch.arange(T - b)
+
+    def run(table):
+        qg = qkv.clone().requires_grad_(True)
+        out = HK.attention(qg * 1, cos, sin, mk([0, 0]), mk(lens), H, D, None, (mk(br[0]), mk(br[1]), table))
+        out.backward(dout)
+        torch.cuda.synchronize()
+        return out.detach().clone(), qg.grad.clone()
+    good = run(pos.view(-1).to(DEV))
+    scrambled = run(torch.randint(0, 2048, (S * T,), dtype=torch.int32, generator=g).to(DEV))
+    assert torch.equal(good[0], scrambled[0]) and torch.equal(good[1], scrambled[1])
+    # against the table-driven rotation + the attention kernel on its own
+    rot = qkv.clone()
+    call("halva_rope_qk", ptr(rot), ptr(cos), ptr(sin), ptr(pos.view(-1).to(DEV)), S * T, T, H, D, cos.shape[0], 0, stream_ptr())
+    want = HK.sdpa_causal(rot, mk([0, 0]), mk(lens), H, D, mk(br[0]), mk(br[1]))
+    valid = torch.zeros(S, T, dtype=torch.bool)
+    for s_ in range(S):
+        valid[s_, :lens[s_]] = True
+    assert torch.equal(good[0][valid.to(DEV)], want[valid.to(DEV)])
+
+
 def test_swiglu():
     rows, Fd = 50, 11008
     g = torch.Generator().manual_seed(2)
