@@ -190,16 +190,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 // Same arithmetic and summation order inside a slab as gemm_kernel<true, true>: bitwise the same partials.
 // KT = 64: two stages, one tile in flight per workgroup while it multiplies.  KT = 32: FOUR stages of half the height - tile t + 3 is requested
 // when tile t has landed, so three tiles (48 KiB per workgroup) stay in flight all the time, at twice the barriers (HALVA_WGRAD_KT=32).
+// (the body of one workgroup = one [128 x 128] tile of one k-slab: bx / by / bz = the tile's column, row and slab - blockIdx of the single-problem launch,
+// decoded from a linear index by the batched one)
 template <int KT, int NT_MODE>      // NT_MODE bit 0: A streamed nontemporally, bit 1: B (see `request`)
-__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const GemmParams p) {
+__device__ __forceinline__ void wgrad_dma_body(const GemmParams& p, int bx, int by, int bz, char* smem) {
     constexpr int TILE = 128 * KT * 2, NST = 128 / KT, PPW = KT / 16;      // bytes of an operand tile; stages; 1-KiB pieces per wave and operand
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* a_lds = smem;                 // [NST][TILE]
     char* b_lds = smem + NST * TILE;    // [NST][TILE]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
-    const int64_t kb = (int64_t)blockIdx.z * p.ksplit;
+    const int m0 = by * 128, n0 = bx * 128;
+    const int64_t kb = (int64_t)bz * p.ksplit;
     const int K = (int)min((int64_t)p.ksplit, p.K - kb);
     const int nk = (K + KT - 1) / KT;
     f32x16 acc[2][2];
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const GemmParams p) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the requests past the slab's end)
-    float* cz = (float*)p.C + (int64_t)blockIdx.z * p.M * p.ldc;
+    float* cz = (float*)p.C + (int64_t)bz * p.M * p.ldc;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + 64 * wn + 32 * j + (lane & 31);
@@ -287,6 +288,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const GemmParams p) {
                 const int m = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
                 cz[(int64_t)m * p.ldc + n] = acc[i][j][r];
             }
+    }
+}
+template <int KT, int NT_MODE>
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wgrad_dma_body<KT, NT_MODE>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// Round 6: the weight gradients of ONE LoRA group - its A factor and its one to three B factors, two to four products that
+// become available together in the group's backward (halva_amd/llama.py:_LoraGroupLinear) - as ONE launch of the tile kernel and ONE of the reduction
+// instead of two launches per factor (1 408 -> 512 per bench step): every workgroup finds its problem from a prefix table in the kernel arguments and
+// runs the single-problem body on it, with the slab counts of the single-problem launcher - the partials, their order and the results are BITWISE those
+// of halva_wgrad_accumulate called once per factor (tests/test_hip_kernels.py).  What it saves is kernel boundaries (each one drains and refills the
+// chip), not work.
+constexpr int WGRAD_BATCH_MAX = 4;
+struct WgradBatch {
+    GemmParams p[WGRAD_BATCH_MAX];      // p[q].C: the partials of problem q in the workspace
+    float* C[WGRAD_BATCH_MAX];
+    float alpha[WGRAD_BATCH_MAX];
+    int64_t mn[WGRAD_BATCH_MAX];
+    int splits[WGRAD_BATCH_MAX], nt_mode[WGRAD_BATCH_MAX], gx[WGRAD_BATCH_MAX], gy[WGRAD_BATCH_MAX];
+    int first_block[WGRAD_BATCH_MAX + 1];       // prefix sums of gx * gy * splits
+    int first_rblock[WGRAD_BATCH_MAX + 1];      // prefix sums of the reduction's blocks (1 024 elements each)
+    int n;
+};
+__global__ __launch_bounds__(256, 2) void wgrad_dma_batch_kernel(const WgradBatch b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int q = 0;
+    while (q + 1 < b.n && (int)blockIdx.x >= b.first_block[q + 1]) ++q;      // (uniform: scalar loads from the kernel arguments)
+    const int i = (int)blockIdx.x - b.first_block[q], gx = b.gx[q], gy = b.gy[q];
+    const int bx = i % gx, by = (i / gx) % gy, bz = i / (gx * gy);
+    const GemmParams& p = b.p[q];
+    switch (b.nt_mode[q]) {
+    case 0: wgrad_dma_body<64, 0>(p, bx, by, bz, smem); break;
+    case 1: wgrad_dma_body<64, 1>(p, bx, by, bz, smem); break;
+    case 2: wgrad_dma_body<64, 2>(p, bx, by, bz, smem); break;
+    default: wgrad_dma_body<64, 3>(p, bx, by, bz, smem); break;
     }
 }
 
@@ -340,6 +378,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *c = *c + s * alpha;
 }
 
+__global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const WgradBatch b) {
+    int q = 0;
+    while (q + 1 < b.n && (int)blockIdx.x >= b.first_rblock[q + 1]) ++q;
+    const int64_t i = ((int64_t)((int)blockIdx.x - b.first_rblock[q]) * 256 + threadIdx.x) * 4, mn = b.mn[q];
+    if (i >= mn) return;
+    const float* ws = (const float*)b.p[q].C;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < b.splits[q]; ++z) s += *reinterpret_cast<const f32x4*>(ws + z * mn + i);
+    f32x4* c = reinterpret_cast<f32x4*>(b.C[q] + i);
+    *c = *c + s * b.alpha[q];
+}
+
 template <bool TA, bool TB>
 int launch_gemm(const GemmParams& p, hipStream_t st) {
     const dim3 grid((p.N + 127) / 128, (p.M + 127) / 128, p.ksplit > 0 ? (p.K + p.ksplit - 1) / p.ksplit : 1), block(256);
@@ -381,6 +431,21 @@ extern "C" int halva_gemm_bf16(const void* A, const void* B, const void* bias, v
     return launch_gemm<true, true>(p, (hipStream_t)stream);
 }
 
+// the k-slabs of one weight-gradient product: as many as keep the whole grid resident at once (2 workgroups per CU x 256 CUs): a second, partial
+// round of workgroups costs more than the extra parallelism brings (measured at 256..1536 workgroups, tools/bench_wgrad.py)
+static void wgrad_slabs(int M, int N, int64_t rows, int64_t ws_floats, int& splits, int& ksplit) {
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    const int64_t mn = (int64_t)M * N;
+    splits = (int)max((int64_t)1, min((int64_t)min(64, 512 / tiles), ws_floats / mn));
+    ksplit = (int)(((rows + splits - 1) / splits + 63) / 64 * 64);
+    splits = (int)((rows + ksplit - 1) / ksplit);
+}
+static bool wgrad_dma_ok(int M, int N, int64_t lda, int64_t ldb, int ksplit) {      // HALVA_WGRAD_DMA=0: the register-staged gemm_kernel<true, true> of rounds 2-3 (also what odd shapes take)
+    const char* e_dma = getenv("HALVA_WGRAD_DMA");
+    const int64_t slab_bytes = (int64_t)ksplit * (lda > ldb ? lda : ldb) * 2;
+    return !(e_dma && e_dma[0] == '0') && M % 128 == 0 && N % 128 == 0 && slab_bytes < (1ll << 31);
+}
+
 extern "C" int halva_wgrad_accumulate(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int M, int N, int64_t rows,
                                       float alpha, float* ws, int64_t ws_floats, void* stream) {
     HALVA_CHECK_ARG(A && B && C && ws, "wgrad_accumulate: null pointer");
@@ -388,15 +453,11 @@ extern "C" int halva_wgrad_accumulate(const void* A, int64_t lda, const void* B,
     HALVA_CHECK_ARG(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N,
                     "wgrad_accumulate: M, lda, ldb must be multiples of 8 and the strides cover the columns");
     HALVA_CHECK_ARG((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)ws) & 15) == 0, "wgrad_accumulate: 16-byte aligned pointers");
-    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     const int64_t mn = (int64_t)M * N;
     HALVA_CHECK_ARG(ws_floats >= mn, "wgrad_accumulate: workspace of %lld floats, need at least M * N = %lld", (long long)ws_floats,
                     (long long)mn);
-    // as many k-slabs as keep the whole grid resident at once (2 workgroups per CU x 256 CUs): a second, partial round of
-    // workgroups costs more than the extra parallelism brings (measured at 256..1536 workgroups, tools/bench_wgrad.py)
-    int splits = (int)max((int64_t)1, min((int64_t)min(64, 512 / tiles), ws_floats / mn));
-    const int ksplit = (int)(((rows + splits - 1) / splits + 63) / 64 * 64);
-    splits = (int)((rows + ksplit - 1) / ksplit);
+    int splits, ksplit;
+    wgrad_slabs(M, N, rows, ws_floats, splits, ksplit);
     GemmParams p{};
     p.A = (const bf16_t*)A;
     p.B = (const bf16_t*)B;
@@ -409,10 +470,7 @@ extern "C" int halva_wgrad_accumulate(const void* A, int64_t lda, const void* B,
     p.K = (int)rows;
     p.out_f32 = 1;
     p.ksplit = ksplit;
-    // HALVA_WGRAD_DMA=0: the register-staged gemm_kernel<true, true> of rounds 2-3 (also what odd shapes take)
-    const char* e_dma = getenv("HALVA_WGRAD_DMA");
-    const int64_t slab_bytes = (int64_t)ksplit * (lda > ldb ? lda : ldb) * 2;
-    if (!(e_dma && e_dma[0] == '0') && M % 128 == 0 && N % 128 == 0 && slab_bytes < (1ll << 31)) {
+    if (wgrad_dma_ok(M, N, lda, ldb, ksplit)) {
         const dim3 grid(N / 128, M / 128, splits);
         const size_t lds = 4 * 128 * 64 * 2;
         const char* e_kt = getenv("HALVA_WGRAD_KT");
@@ -435,6 +493,55 @@ extern "C" int halva_wgrad_accumulate(const void* A, int64_t lda, const void* B,
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, C, mn, splits,
                        alpha);
     HALVA_CHECK_LAUNCH("splitk_reduce");
+    return HALVA_OK;
+}
+
+extern "C" int halva_wgrad_accumulate_batch(int n, const halva_wgrad_item* items, float* ws, int64_t ws_floats, void* stream) {
+    HALVA_CHECK_ARG(n > 0 && items && ws, "wgrad_accumulate_batch: no items / null pointer");
+    // one launch pair when every product takes the LDS-DMA tile kernel and all partials fit the workspace side by side - with the slab counts the
+    // single-problem call would choose for each, so that the results are bitwise the same; anything else: the single-problem calls, one by one
+    WgradBatch b{};
+    const char* e_kt = getenv("HALVA_WGRAD_KT");
+    bool batched = n <= WGRAD_BATCH_MAX && !(e_kt && atoi(e_kt) == 32) && (((uintptr_t)ws) & 15) == 0;
+    int64_t ws_at = 0;
+    for (int q = 0; q < n && batched; ++q) {
+        const halva_wgrad_item& it = items[q];
+        const int64_t mn = (int64_t)it.M * it.N;
+        if (!(it.A && it.B && it.C && it.M > 0 && it.N > 0 && it.rows > 0 && it.rows < (1ll << 31) && it.lda % 8 == 0 && it.ldb % 8 == 0 && it.lda >= it.M &&
+              it.ldb >= it.N && (((uintptr_t)it.A | (uintptr_t)it.B | (uintptr_t)it.C) & 15) == 0 && ws_floats >= mn)) {
+            batched = false;
+            break;
+        }
+        int splits, ksplit;
+        wgrad_slabs(it.M, it.N, it.rows, ws_floats, splits, ksplit);
+        if (!wgrad_dma_ok(it.M, it.N, it.lda, it.ldb, ksplit) || ws_at + (int64_t)splits * mn > ws_floats) {
+            batched = false;
+            break;
+        }
+        GemmParams& p = b.p[q];
+        p.A = (const bf16_t*)it.A, p.B = (const bf16_t*)it.B, p.C = ws + ws_at;
+        p.lda = it.lda, p.ldb = it.ldb, p.ldc = it.N, p.M = it.M, p.N = it.N, p.K = (int)it.rows, p.out_f32 = 1, p.ksplit = ksplit;
+        b.C[q] = it.C, b.alpha[q] = it.alpha, b.mn[q] = mn, b.splits[q] = splits, b.gx[q] = it.N / 128, b.gy[q] = it.M / 128;
+        b.nt_mode[q] = (b.gx[q] == 1 ? 1 : 0) | (b.gy[q] == 1 ? 2 : 0);
+        b.first_block[q + 1] = b.first_block[q] + b.gx[q] * b.gy[q] * splits;
+        b.first_rblock[q + 1] = b.first_rblock[q] + (int)((mn / 4 + 255) / 256);
+        ws_at += ((int64_t)splits * mn + 3) / 4 * 4;
+    }
+    if (!batched) {
+        for (int q = 0; q < n; ++q) {
+            const halva_wgrad_item& it = items[q];
+            const int rc = halva_wgrad_accumulate(it.A, it.lda, it.B, it.ldb, it.C, it.M, it.N, it.rows, it.alpha, ws, ws_floats, stream);
+            if (rc != HALVA_OK) return rc;
+        }
+        return HALVA_OK;
+    }
+    b.n = n;
+    const size_t lds = 4 * 128 * 64 * 2;
+    (void)hipFuncSetAttribute((const void*)wgrad_dma_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(wgrad_dma_batch_kernel, dim3((unsigned)b.first_block[n]), dim3(256), lds, (hipStream_t)stream, b);
+    HALVA_CHECK_LAUNCH("wgrad_dma_batch");
+    hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3((unsigned)b.first_rblock[n]), dim3(256), 0, (hipStream_t)stream, b);
+    HALVA_CHECK_LAUNCH("splitk_reduce_batch");
     return HALVA_OK;
 }
 

@@ -402,6 +402,9 @@ __device__ __forceinline__ void sdpa_bwd_dkv3_items(const SdpaParams& p, char* s
             // Round 6 tried to get rid of both (experiments/dkv3_item_boundary: the loads in front of / between / behind the PREVIOUS item's store
             // conversions; a second register set a192-a255 filled by the previous block's first call): the issue time cannot be hidden by a wave
             // that is alone on its SIMD, and none of the five variants beat this one.
+#ifdef DKV3_DIAG_NO_KV      // (timing experiment, results wrong: what would FREE K / V fragments buy? - the ceiling of any other way to deliver them)
+            if (round == 0)
+#endif
             {
                 const unsigned long long k0 = ((unsigned long long)(unsigned)DKV3_F(rec, K_HI) << 32) | (unsigned)DKV3_F(rec, K_LO);
                 const char* k_ptr = (const char*)(size_t)k0 + (unsigned long long)(unsigned)min(max(kl, 0), len - 1) * ld2 + 16 * h;

@@ -39,6 +39,7 @@ SIGNATURES = {
     "halva_sdpa_full_fwd": [_P, _P, _I, _I, _I, _I, _F, _P],
     "halva_gemm_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "halva_wgrad_accumulate": [_P, _L, _P, _L, _P, _I, _I, _L, _F, _P, _L, _P],
+    "halva_wgrad_accumulate_batch": [_I, _P, _P, _L, _P],
     "halva_clip_patch_embed": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "halva_vit_patch_embed": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "halva_layernorm_fwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
@@ -59,6 +60,14 @@ SIGNATURES = {
     "halva_clock_probe": [_P, _I, _I, _P],
     "halva_sdpa_block_pairs": [_I, _I, _I, _I, _P],
 }
+
+
+
+class WgradItem(ctypes.Structure):
+    """halva_wgrad_item (include/halva_hip.h)"""
+    _fields_ = [("A", c_void_p), ("lda", c_int64), ("B", c_void_p), ("ldb", c_int64), ("C", c_void_p), ("M", ctypes.c_int32), ("N", ctypes.c_int32),
+                ("rows", c_int64), ("alpha", c_float), ("reserved", ctypes.c_int32)]
+
 
 _lib = None
 

@@ -4,6 +4,7 @@ Each Function names the reference call it stands in for; numerics follow the ven
 (reference llava/model/language_model/modelling_llama.py) - see include/halva_hip.h for the per-kernel contract.
 """
 import math
+import ctypes
 import os
 
 import torch
@@ -108,6 +109,23 @@ def wgrad_accumulate(C, A, B, alpha=1.0):
         ws = _wgrad_ws[C.device] = torch.empty(48 * 2 ** 20, dtype=torch.float32, device=C.device)      # 192 MB: 30+ slabs at these sizes
     call("halva_wgrad_accumulate", ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), M, N, rows, float(alpha), ptr(ws), ws.numel(),
          stream_ptr())
+
+
+def wgrad_accumulate_batch(items):
+    """[(C, A, B, alpha), ...] -> every C [M, N] f32 += alpha * A^T B, as ONE launch pair for the two to four products of a LoRA group
+    (include/halva_hip.h:halva_wgrad_accumulate_batch); bitwise the results of wgrad_accumulate called once per item."""
+    dev = items[0][0].device
+    ws = _wgrad_ws.get(dev)
+    if ws is None:
+        ws = _wgrad_ws[dev] = torch.empty(48 * 2 ** 20, dtype=torch.float32, device=dev)      # 192 MB: 30+ slabs at these sizes
+    arr = (hip.WgradItem * len(items))()
+    for it, (C, A, B, alpha) in zip(arr, items):
+        rows, M = A.shape
+        N = B.shape[1]
+        assert B.shape[0] == rows and C.shape == (M, N) and C.dtype == torch.float32 and C.is_contiguous()
+        assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.stride(1) == 1 and B.stride(1) == 1
+        it.A, it.lda, it.B, it.ldb, it.C, it.M, it.N, it.rows, it.alpha = ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), M, N, rows, float(alpha)
+    call("halva_wgrad_accumulate_batch", len(items), ctypes.cast(arr, ctypes.c_void_p), ptr(ws), ws.numel(), stream_ptr())
 
 
 def wgrad_supported(A, B):

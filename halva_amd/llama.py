@@ -67,6 +67,7 @@ def _jsonable(v):
 # memory once more (13.5 GB at 7B, 26 GB at 13B - of 288 GB); HALVA_DGRAD_WT=0 turns it off.
 DGRAD_TRANSPOSED_COPY = os.environ.get("HALVA_DGRAD_WT", "1") != "0"
 WGRAD_KERNEL = os.environ.get("HALVA_WGRAD_KERNEL", "1") != "0"      # LoRA weight gradients through halva_wgrad_accumulate
+WGRAD_BATCH = os.environ.get("HALVA_WGRAD_BATCH", "1") != "0"        # ... the factors of a group as ONE launch pair (round 6; 0 = one pair per factor, bitwise the same)
 RES_INPLACE = os.environ.get("HALVA_RES_INPLACE", "1") != "0"        # residual adds accumulate onto the block's own buffer (A/B: 0)
 # dgrad through the MERGED weight: the transposed copy holds (W + scale * B A)^T, so dx = dy (W + scale B A) comes out of the one
 # dgrad GEMM complete and the separate dx += (scale * dy B) A pass over [rows, in] is gone (A/B: 0)
@@ -150,14 +151,19 @@ class _LoraGroupFn(torch.autograd.Function):
             fused = (sink and WGRAD_KERNEL and all(t.main_grad.is_contiguous() and t.main_grad.data_ptr() % 16 == 0 and
                                                    t.main_grad.dtype == torch.float32 for t in (A, *Bs))
                      and K_.wgrad_supported(da, xa2[:, :K]) and K_.wgrad_supported(dy2[:, :Bs[0].shape[0]], xa2[:, K:K + r]))
-            if fused:
+            batch = [] if (fused and WGRAD_BATCH and len(Bs) <= 3) else None      # (the A factor + up to three B factors: one launch pair)
+            if batch is not None:
+                batch.append((A.main_grad, da, xa2[:, :K], 1.0))
+            elif fused:
                 K_.wgrad_accumulate(A.main_grad, da, xa2[:, :K], 1.0)
             else:
                 gA = torch.mm(da.t(), xa2[:, :K])
             off = 0
             for g, B in enumerate(Bs):
                 n = B.shape[0]
-                if fused:
+                if batch is not None:
+                    batch.append((B.main_grad, dy2[:, off:off + n], xa2[:, K + g * r:K + (g + 1) * r], scale))
+                elif fused:
                     K_.wgrad_accumulate(B.main_grad, dy2[:, off:off + n], xa2[:, K + g * r:K + (g + 1) * r], scale)
                 else:
                     gB = torch.mm(dy2[:, off:off + n].t(), xa2[:, K + g * r:K + (g + 1) * r])
@@ -166,6 +172,8 @@ class _LoraGroupFn(torch.autograd.Function):
                     else:
                         dBs[g] = gB * scale
                 off += n
+            if batch is not None:
+                K_.wgrad_accumulate_batch(batch)
             if fused:
                 pass
             elif sink:

@@ -174,6 +174,23 @@ int halva_gemm_bf16(const void* A, const void* B, const void* bias, void* C, voi
  * round of workgroups (512). */
 int halva_wgrad_accumulate(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int M, int N, int64_t rows, float alpha,
                            float* ws, int64_t ws_floats, void* stream);
+/* The same for the two to four products of ONE LoRA group at once (its A factor and its B factors: they become available together in the group's
+ * backward - halva_amd/llama.py:_LoraGroupLinear, i.e. peft's LoRA linear backward as used by llava/train/train_halva.py:1085-1101): one launch of
+ * the tile kernel and one of the reduction instead of two per product.  Results are BITWISE those of halva_wgrad_accumulate called once per item
+ * with the same workspace (same k-slabs, same summation order); items that the batched kernel does not take (more than 4, shapes that are no
+ * multiples of 128, partials that do not fit the workspace side by side) simply run one by one.  items: HOST array of n descriptors. */
+typedef struct halva_wgrad_item {
+    const void* A;      /* [rows, M] bf16 window, row stride lda */
+    int64_t lda;
+    const void* B;      /* [rows, N] bf16 window, row stride ldb */
+    int64_t ldb;
+    float* C;           /* [M, N] f32, += alpha * A^T B */
+    int32_t M, N;
+    int64_t rows;
+    float alpha;
+    int32_t reserved;
+} halva_wgrad_item;
+int halva_wgrad_accumulate_batch(int n, const halva_wgrad_item* items, float* ws, int64_t ws_floats, void* stream);
 /* images [n, 3, hw, hw] bf16; weight_kp [d, Kp] bf16 = the conv weight flattened to [d, 3*p*p] and zero padded to
  * Kp (multiple of 8); col_ws: caller scratch [n * (hw/p)^2, Kp] bf16 -> out [n, (hw/p)^2, d] bf16 */
 int halva_clip_patch_embed(const void* images, const void* weight_kp, void* col_ws, void* out, int n, int hw, int p, int d,

@@ -754,6 +754,36 @@ def test_wgrad_lds_dma_kernel_gives_the_register_staged_kernels_bits(rows, M, N,
     assert torch.equal(out["1"], out["0"])
 
 
+@pytest.mark.parametrize("group", ["qkv_7b", "gate_up_7b", "o_7b", "down_7b", "odd_shapes"])
+def test_wgrad_batch_gives_the_bits_of_one_call_per_factor(group):
+    """halva_wgrad_accumulate_batch (round 6): the A factor and the B factors of ONE LoRA group as one launch of the tile
+    kernel + one of the reduction - with the slab counts of the single-problem call, so the partials, their order and the results are the bits of
+    halva_wgrad_accumulate called once per factor (peft's LoRA linear backward as used by llava/train/train_halva.py:1085-1101).  The shapes of the
+    7B step's four groups at the packed bench rows; "odd_shapes": items the batched kernel does not take run one by one inside the same call."""
+    rows, d, F, r = 27424, 4096, 11008, 128
+    shapes = {"qkv_7b": [(3 * r, d)] + [(d, r)] * 3, "gate_up_7b": [(2 * r, d)] + [(F, r)] * 2, "o_7b": [(r, d), (d, r)], "down_7b": [(r, F), (d, r)],
+              "odd_shapes": [(320, 1032), (8, 8)]}[group]
+    if group == "odd_shapes":
+        rows = 1500
+    g = torch.Generator().manual_seed(11)
+    items = []
+    for i, (M, N) in enumerate(shapes):
+        lda, ldb = M + 8 * (i + 1), N + 16 * (i + 2)
+        A = bf(torch.randn(rows, lda, generator=g)).to(DEV)[:, 8 * (i + 1):]
+        B = bf(torch.randn(rows, ldb, generator=g)).to(DEV)[:, :N]
+        items.append((torch.randn(M, N, generator=g).to(DEV), A, B, 0.25 * (i + 1)))
+    one_by_one = [C.clone() for C, _, _, _ in items]
+    for C, (_, A, B, alpha) in zip(one_by_one, items):
+        K().wgrad_accumulate(C, A, B, alpha)
+    batched = [C.clone() for C, _, _, _ in items]
+    K().wgrad_accumulate_batch([(C, A, B, alpha) for C, (_, A, B, alpha) in zip(batched, items)])
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(batched, one_by_one)):
+        assert torch.equal(a, b), (group, i, float((a - b).abs().max()))
+    ref = items[0][0].double() + items[0][3] * (items[0][1].double().t() @ items[0][2].double())
+    assert float((batched[0].double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())) * max(1, rows // 2000)
+
+
 def test_clip_tower_features_match_reference():
     """CLIPVisionTower.forward of the reference (clip_encoder.py:37-56 around HF CLIPVisionModel: patch conv, class token +
     position embeddings, pre-LN, pre-norm blocks with quick_gelu, hidden_states[-2], CLS row dropped) and encode_images
