@@ -14,6 +14,19 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr int kNW = 4;   // waves per workgroup
 
+// Round 6: the logits rows are streamed - a 0.5 GB chunk is read once per pass and overwritten in place by the gradient - so
+// the row kernels' policy applies: nontemporal loads and stores (-DHALVA_LOSS_NT=0: the plain accesses of rounds 1-5, A/B builds).
+#ifndef HALVA_LOSS_NT
+#define HALVA_LOSS_NT 1
+#endif
+#if HALVA_LOSS_NT
+#define LOSS_LOAD(p) __builtin_nontemporal_load(p)
+#define LOSS_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define LOSS_LOAD(p) (*(p))
+#define LOSS_STORE(p, v) (*(p) = (v))
+#endif
+
 template <typename T>
 struct RowIO;
 template <>
@@ -27,12 +40,12 @@ struct RowIO<bf16_t> {
             f[2 * i + 1] = bf16_hi(v[i]);
         }
     }
-    __device__ static void load(const bf16_t* p, float (&f)[8]) { cvt(*reinterpret_cast<const u32x4*>(p), f); }
+    __device__ static void load(const bf16_t* p, float (&f)[8]) { cvt(LOSS_LOAD(reinterpret_cast<const u32x4*>(p)), f); }
     __device__ static void store(bf16_t* p, const float (&f)[8]) {
         u32x4 v;
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
-        *reinterpret_cast<u32x4*>(p) = v;
+        LOSS_STORE(reinterpret_cast<u32x4*>(p), v);
     }
     __device__ static float get(const bf16_t* p) { return bf16_to_f32(*p); }
     __device__ static void put(bf16_t* p, float f) { *p = f32_to_bf16(f); }
@@ -45,12 +58,12 @@ struct RowIO<float> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) f[i] = v[i];
     }
-    __device__ static void load(const float* p, float (&f)[4]) { cvt(*reinterpret_cast<const f32x4*>(p), f); }
+    __device__ static void load(const float* p, float (&f)[4]) { cvt(LOSS_LOAD(reinterpret_cast<const f32x4*>(p)), f); }
     __device__ static void store(float* p, const float (&f)[4]) {
         f32x4 v;
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = f[i];
-        *reinterpret_cast<f32x4*>(p) = v;
+        LOSS_STORE(reinterpret_cast<f32x4*>(p), v);
     }
     __device__ static float get(const float* p) { return *p; }
     __device__ static void put(float* p, float f) { *p = f; }
@@ -82,19 +95,21 @@ __device__ __forceinline__ bool row_vec_ok(const T* p, int64_t ld) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <typename T>
+// KCH > 0 (round 6): every thread asks for ALL of its (<= KCH) 16-byte chunks of the row before it touches the first - sixteen loads in flight per
+// thread instead of one or two behind the dependent online-softmax update; same chunks in the same order per thread: the same bits.  The launcher
+// picks it when the row fits KCH * 256 chunks (V <= 32 768 in bf16).
+template <typename T, int KCH>
 __global__ __launch_bounds__(256) void token_logp_fwd_kernel(const T* __restrict__ logits, int64_t ld,
                                                              const int32_t* __restrict__ target, float* __restrict__ logp,
                                                              float* __restrict__ lse, int V) {
     constexpr int W = RowIO<T>::W;
+    typedef typename RowIO<T>::Raw Raw;
     __shared__ float red_m[kNW], red_s[kNW];
     const int64_t r = blockIdx.x;
     const T* row = logits + r * ld;
     const int nvec = row_vec_ok(logits, ld) ? V / W : 0;
     MS a{-INFINITY, 0.f};
-    for (int c = threadIdx.x; c < nvec; c += 256) {
-        float f[W];
-        RowIO<T>::load(row + (int64_t)c * W, f);
+    auto chunk = [&](const float (&f)[W]) {
         float cm = f[0];
 #pragma unroll
         for (int j = 1; j < W; ++j) cm = fmaxf(cm, f[j]);
@@ -105,6 +120,29 @@ __global__ __launch_bounds__(256) void token_logp_fwd_kernel(const T* __restrict
         for (int j = 0; j < W; ++j) s += exp2f(f[j] * kLog2e - M);
         a.s = a.s * ((a.m == -INFINITY) ? 0.f : exp2f(a.m - M)) + s;
         a.m = M;
+    };
+    if (KCH > 0) {
+        Raw keep[KCH > 0 ? KCH : 1];
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int c = threadIdx.x + i * 256;
+            if (c < nvec) keep[i] = LOSS_LOAD(reinterpret_cast<const Raw*>(row + (int64_t)c * W));
+        }
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int c = threadIdx.x + i * 256;
+            if (c < nvec) {
+                float f[W];
+                RowIO<T>::cvt(keep[i], f);
+                chunk(f);
+            }
+        }
+    } else {
+        for (int c = threadIdx.x; c < nvec; c += 256) {
+            float f[W];
+            RowIO<T>::load(row + (int64_t)c * W, f);
+            chunk(f);
+        }
     }
     for (int v = nvec * W + threadIdx.x; v < V; v += 256) ms_merge(a, RowIO<T>::get(row + v) * kLog2e, 1.f);
     a = ms_wave(a);
@@ -123,11 +161,12 @@ __global__ __launch_bounds__(256) void token_logp_fwd_kernel(const T* __restrict
     }
 }
 
-template <typename T>
+template <typename T, int KCH>
 __global__ __launch_bounds__(256) void token_logp_bwd_kernel(const T* logits, int64_t ld,
                                                              const int32_t* __restrict__ target, const float* __restrict__ lse,
                                                              const float* __restrict__ g, T* dlogits, int V) {
     constexpr int W = RowIO<T>::W;
+    typedef typename RowIO<T>::Raw Raw;
     const int64_t r = blockIdx.x;
     const T* row = logits + r * ld;
     T* drow = dlogits + r * ld;
@@ -135,17 +174,39 @@ __global__ __launch_bounds__(256) void token_logp_bwd_kernel(const T* logits, in
     const float l2 = lse[r] * kLog2e;
     const int tgt = target[r];
     const int nvec = (row_vec_ok(logits, ld) && row_vec_ok(dlogits, ld)) ? V / W : 0;
-    for (int c = threadIdx.x; c < nvec; c += 256) {
-        float f[W];
-        if (gr != 0.f) {
-            RowIO<T>::load(row + (int64_t)c * W, f);
+    auto grad = [&](int c, float (&f)[W]) {
 #pragma unroll
-            for (int j = 0; j < W; ++j) f[j] = gr * ((c * W + j == tgt ? 1.f : 0.f) - exp2f(f[j] * kLog2e - l2));
-        } else {
+        for (int j = 0; j < W; ++j) f[j] = gr * ((c * W + j == tgt ? 1.f : 0.f) - exp2f(f[j] * kLog2e - l2));
+    };
+    if (KCH > 0 && gr != 0.f) {      // (a row without a gradient is not read at all: below)
+        Raw keep[KCH > 0 ? KCH : 1];
 #pragma unroll
-            for (int j = 0; j < W; ++j) f[j] = 0.f;
+        for (int i = 0; i < KCH; ++i) {
+            const int c = threadIdx.x + i * 256;
+            if (c < nvec) keep[i] = LOSS_LOAD(reinterpret_cast<const Raw*>(row + (int64_t)c * W));
         }
-        RowIO<T>::store(drow + (int64_t)c * W, f);
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int c = threadIdx.x + i * 256;
+            if (c < nvec) {
+                float f[W];
+                RowIO<T>::cvt(keep[i], f);
+                grad(c, f);
+                RowIO<T>::store(drow + (int64_t)c * W, f);
+            }
+        }
+    } else {
+        for (int c = threadIdx.x; c < nvec; c += 256) {
+            float f[W];
+            if (gr != 0.f) {
+                RowIO<T>::load(row + (int64_t)c * W, f);
+                grad(c, f);
+            } else {
+#pragma unroll
+                for (int j = 0; j < W; ++j) f[j] = 0.f;
+            }
+            RowIO<T>::store(drow + (int64_t)c * W, f);
+        }
     }
     for (int v = nvec * W + threadIdx.x; v < V; v += 256) {
         const float x = RowIO<T>::get(row + v);
@@ -211,7 +272,7 @@ __global__ __launch_bounds__(NT) void kl_rows_kernel(const T* pol, const T* __re
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
             const int c = threadIdx.x + i * NT;
-            if (c < nvec) keep_r[i] = *reinterpret_cast<const Raw*>(rrow + (int64_t)c * W), keep_p[i] = *reinterpret_cast<const Raw*>(prow + (int64_t)c * W);
+            if (c < nvec) keep_r[i] = LOSS_LOAD(reinterpret_cast<const Raw*>(rrow + (int64_t)c * W)), keep_p[i] = LOSS_LOAD(reinterpret_cast<const Raw*>(prow + (int64_t)c * W));
         }
     }
 #pragma unroll
@@ -369,11 +430,14 @@ extern "C" int halva_token_logp_fwd(const void* logits, halva_dtype dt, int64_t 
     HALVA_CHECK_ARG(V > 0 && ld >= V, "token_logp_fwd: bad V=%d / ld=%lld", V, (long long)ld);
     HALVA_CHECK_ARG(R < (1ll << 31), "token_logp_fwd: too many rows");
     if (R <= 0) return HALVA_OK;
-    if (dt == HALVA_BF16)
-        hipLaunchKernelGGL(token_logp_fwd_kernel<bf16_t>, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream,
+    if (dt == HALVA_BF16 && V / 8 <= 16 * 256)
+        hipLaunchKernelGGL((token_logp_fwd_kernel<bf16_t, 16>), dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)logits, ld, target, logp, lse, V);
+    else if (dt == HALVA_BF16)
+        hipLaunchKernelGGL((token_logp_fwd_kernel<bf16_t, 0>), dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)logits, ld, target, logp, lse, V);
     else if (dt == HALVA_F32)
-        hipLaunchKernelGGL(token_logp_fwd_kernel<float>, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((token_logp_fwd_kernel<float, 0>), dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream,
                            (const float*)logits, ld, target, logp, lse, V);
     else
         HALVA_CHECK_ARG(false, "token_logp_fwd: unsupported dtype %d", (int)dt);
@@ -387,11 +451,14 @@ extern "C" int halva_token_logp_bwd(const void* logits, halva_dtype dt, int64_t 
     HALVA_CHECK_ARG(V > 0 && ld >= V, "token_logp_bwd: bad V=%d / ld=%lld", V, (long long)ld);
     HALVA_CHECK_ARG(R < (1ll << 31), "token_logp_bwd: too many rows");
     if (R <= 0) return HALVA_OK;
-    if (dt == HALVA_BF16)
-        hipLaunchKernelGGL(token_logp_bwd_kernel<bf16_t>, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream,
+    if (dt == HALVA_BF16 && V / 8 <= 16 * 256)
+        hipLaunchKernelGGL((token_logp_bwd_kernel<bf16_t, 16>), dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)logits, ld, target, lse, g, (bf16_t*)dlogits, V);
+    else if (dt == HALVA_BF16)
+        hipLaunchKernelGGL((token_logp_bwd_kernel<bf16_t, 0>), dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)logits, ld, target, lse, g, (bf16_t*)dlogits, V);
     else if (dt == HALVA_F32)
-        hipLaunchKernelGGL(token_logp_bwd_kernel<float>, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((token_logp_bwd_kernel<float, 0>), dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream,
                            (const float*)logits, ld, target, lse, g, (float*)dlogits, V);
     else
         HALVA_CHECK_ARG(false, "token_logp_bwd: unsupported dtype %d", (int)dt);
