@@ -14,22 +14,22 @@ over S and dZ = P dP' in place over dP'.  This script assigns every instruction 
     result in the next issue slot, a packed operand is written >= 4 instructions before the MFMA that reads it.
 The stream was developed and timed in experiments/dkv3 (2 419 cycles per step against 3 650 for hipcc's own schedule, bit-identical).
 
-Operands of the asm block (sdpa_dkv3.h), by NAME in the emitted text (%[name]; the %NN in this script are shorthand resolved in main()):
-accV0-3 / accK0-3 the dV^T / dK^T accumulators ("+a", fixed registers), kq0-7 / vq0-7 the K / V fragments ("a", fixed registers: possibly
-still in flight when the block is entered - its first call starts with s_waitcnt vmcnt(0)); rowrel, colrel, statrel the
-row-read, transposed-read and statistics lane offsets, voff_q / voff_do the lane offsets of the Q / dO tile pieces ("v"); sc = scale * log2 e,
-n02 / n1 the steps of the three phases (masked | plain | masked: the diagonal steps, the interior, the tail; n02 = first | last << 16),
-ndma the steps that request a tile (+ the next item's tiles << 8, see dma_groups), wave, q_piece / do_piece the bytes between a wave's pieces (16 rows) ("s");
+Operands of the asm block (sdpa_dkv3_call.h), by NAME in the emitted text (%[name]; the %NN in this script are shorthand resolved in main()):
+accV0-3 / accK0-3 the dV^T / dK^T accumulators ("+a" / "=a", fixed registers a0-a127); the K / V fragments are NO operands (round 6) but the literal
+registers a128-a191, named in the clobber list (possibly still in flight when the block is entered - its first call waits with s_waitcnt vmcnt(0));
+rowrel, colrel, statrel the row-read, transposed-read and statistics lane offsets, voff_q / voff_do / stat_voff the lane offsets of the Q / dO tile
+pieces and of the statistics request ("v"); sc = scale * log2 e, n02 / n1 the steps of the three phases (masked | plain | masked: the diagonal steps,
+the interior, the tail; n02 = first | last << 16), ndma the steps that request a tile (+ the next item's tiles << 8, see dma_groups), wave,
+q_piece / do_piece the bytes between a wave's pieces (16 rows) ("s");
 lo0 / range the masks' per-lane bounds ("v"): a score of key kl and row ql = qt0 + 4 h + c (c = the register's row inside the step) survives
 iff unsigned(c - lo) < range with lo = kl - qt0 - 4 h of the first step (the loop subtracts 64 per step) and range = len - kl (0 = lane off);
-alt_stat the lane offset of the statistics row of a PARTIAL last tile (rows clamped to the sequence) ("v");
-safe_l an always-valid address that the statistics requests of the steps without a tile left read into the dummy chunk ("s");
-ctl the control word (CTL_* below) ("s"); drawn ("=&v") what the home queue's counter at sched_ptr ("v", 64 bit) answered (first call, thread 0);  every other address arrives as the low / high word of a uniform value in VECTOR registers
-(x_lo, x_hi: scalar operands are scarce, and when they run out the compiler silently hands the asm a vector register): q / do the sequence's
-first Q / dO row of this head (the base of a buffer descriptor; q_rec / do_rec its bytes, q_soff / do_soff the first tile to request in bytes
-from that row), lse / nd the statistics rows of the first tile to request, ds the dS pointer of the first step (this wave's strip).  The rows of
-the workgroup's NEXT item (nq / ndo + nqrec / ndorec / nqsoff / ndosoff, nlse / nnd: in vector registers too) are requested by the block's
-last three steps (ndma bits 8-15: how many of its tiles).
+ctl the control word (CTL_* below; bit 11: the mail-box slot) ("s"); drawn ("=&v") what the home queue's counter at sched_ptr ("v", 64 bit) answered
+(first call, thread 0); rec_ptr ("v", 64 bit) where wave 0's lane l < 16 finds its 16 bytes of the record of the item after next;
+rec / nrec ("v") THE ITEM RECORDS of this item and the next (round 6; lane l = dword l, REC_FIELDS below): the bases / extents of the Q / dO /
+statistics buffer descriptors are picked out of them with v_readlane_b32 here; what changes from call to call arrives as uniform values in
+VECTOR registers (scalar operands are scarce, and when they run out the compiler silently hands the asm a vector register): q_soff / do_soff /
+st_soff the first tile / statistics record to request in bytes from the descriptor's base, ds_lo / ds_hi the dS pointer of the call's first step (this
+wave's strip).  The rows of the workgroup's NEXT item are requested by the block's last three steps (ndma bits 8-15: how many of its tiles).
 The masked phases cost three more vector instructions per score."""
 import os
 import sys
