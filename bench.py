@@ -492,6 +492,12 @@ def main():
     torch.cuda.set_device(ctx.local_rank)
     dev = torch.device("cuda", ctx.local_rank)
     dp.barrier(ctx)      # N > 1: RCCL builds its communicator (and allocates its buffers) now, while the HBM is still empty
+    if ctx.active:      # (RCCL's version banner goes to stdout through C stdio: push it out NOW, on every rank, so that none of it can land behind rank 0's JSON line)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
     if os.environ.get("HALVA_BENCH_MEM_FRACTION"):      # diagnostic: cap this process's share of the HBM (exercises the out-of-memory fall-back)
         # "0.3" = every rank, "1:0.3" = rank 1 only (the collective fall-back must cope with ONE rank running out of memory)
         spec = os.environ["HALVA_BENCH_MEM_FRACTION"]
@@ -783,6 +789,13 @@ def main():
                "peak_mem_reserved_gb": round(torch.cuda.max_memory_reserved() / 2 ** 30, 1),
                "clock_trace": clock,
                "roofline": roof, "cpu_baseline": cpu}
+        # RCCL prints its version banner to stdout through C stdio at communicator creation; into a pipe that buffer is only flushed at exit, i.e.
+        # BEHIND the line below (seen in profiles/r06_bench_dp1_rccl.json's raw output).  Flush it first: the JSON line is the LAST line on stdout.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(rec), flush=True)
     if ctx.active:
         torch.distributed.destroy_process_group()
