@@ -142,6 +142,23 @@ def test_one_rank_rccl_communicator_runs_the_exchange_and_changes_nothing(tmp_pa
     assert got["loss"] == loss
 
 
+def test_bench_json_line_is_the_last_line_of_stdout_with_an_rccl_communicator():
+    """The driver reads ONE JSON line from rank 0.  RCCL prints a version banner to stdout through C stdio when its communicator is created; into a
+    pipe that buffer used to be flushed at process exit - BEHIND the JSON line (round 6: profiles/r06_bench_dp1_rccl.json's raw output).  bench.py
+    flushes it right after the communicator exists: with a (forced one-rank) RCCL communicator the last line of stdout is the JSON record."""
+    import json
+    env = dict(os.environ, HALVA_DP_FORCE="1", HALVA_DIST_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HALVA_SHARE_GPU", "HALVA_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--layers", "2", "--pairs-per-gpu", "2",
+                        "--pairs-per-group", "2", "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    rec = json.loads(lines[-1])                      # (raises if anything trails the record)
+    assert rec["grad_allreduce"]["backend"] == "nccl" and rec["grad_allreduce"]["forced_one_rank_communicator"]
+    assert sum(1 for l in lines if l.startswith("{")) == 1
+
+
 def test_bench_spawns_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` (no launcher): the parent starts two fresh rank processes before touching the GPU and rank 0
     prints the JSON line.  Two layers of the 7B geometry; on a 1-GPU box the ranks share the device (HALVA_BENCH_SHARE_GPU)."""
