@@ -159,6 +159,28 @@ def test_bench_json_line_is_the_last_line_of_stdout_with_an_rccl_communicator():
     assert sum(1 for l in lines if l.startswith("{")) == 1
 
 
+def test_bench_under_the_drivers_launcher_form():
+    """The driver's N > 1 command, verbatim: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N --steps K --warmup W` - the ranks exist already (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher), nothing is
+    spawned, rank 0 prints the ONE JSON line.  Two ranks; on a 1-GPU box they share the device over gloo (HALVA_SHARE_GPU / HALVA_DIST_BACKEND -
+    what the spawner sets for HALVA_BENCH_SHARE_GPU); with 2 GPUs visible: RCCL.  Every other N > 1 test goes through bench.py's own spawner."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 2:
+        env.update(HALVA_SHARE_GPU="1", HALVA_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--layers", "2", "--pairs-per-gpu", "2", "--pairs-per-group", "2", "--no-cpu-baseline", "--no-roofline"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_pairs"] == 4 and rec["value"] > 0 and rec["grad_allreduce"]["world"] == 2
+
+
 def test_bench_spawns_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` (no launcher): the parent starts two fresh rank processes before touching the GPU and rank 0
     prints the JSON line.  Two layers of the 7B geometry; on a 1-GPU box the ranks share the device (HALVA_BENCH_SHARE_GPU)."""
