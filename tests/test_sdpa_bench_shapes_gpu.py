@@ -194,6 +194,85 @@ def test_dkv3_work_queues_are_a_permutation_of_the_static_launch(case):
     assert rel_err(ref.float().cpu(), old.float().cpu()) < 5e-3
 
 
+@pytest.mark.parametrize("case,order", [("ragged_5_heads", 2), ("packed", 2), ("packed", 0), ("one_pair", 1)])
+def test_dkv3_item_records_match_a_host_restatement(case, order, monkeypatch):
+    """Round 6: everything uniform about a (sequence, head, key block) item of sdpa_bwd_dkv3 is written ONCE by the delta pass as a 64-dword record
+    (csrc/sdpa_dkv3_items.h) instead of being re-derived by every workgroup.  The records of a launch - read back from the workspace behind the dS
+    region, the statistics and the counters - against an independent numpy restatement of the queue order and the block geometry (which rows see a
+    key block, where its masked / plain / masked runs begin, what its first call requests; reference semantics: causal varlen attention with the
+    branch mask of halva_sdpa_branch_fwd, llava/train/llama_flash_attn_monkey_patch.py:85-91)."""
+    import re, os
+    import numpy as np
+    from halva_amd import kernels as HK
+    D = 128
+    if case == "ragged_5_heads":
+        S, T, H, lens, starts, br = 3, 640, 5, [640, 333, 70], [0, 64, 500], None
+    elif case == "packed":
+        S, T, H, lens, starts, br = 2, 1216, 8, [1216, 1100], [0, 0], ([300, 290], [768, 704])
+    else:
+        S, T, H, lens, starts, br = 1, 384, 1, [384], [0], None
+    _bwd_bits(S, T, H, D, lens, starts, br, 3, {"HALVA_DKV3_ORDER": str(order)})
+    ws = HK._sdpa_ws[torch.device(DEV, torch.cuda.current_device())]
+    nkb, nt = (T + 127) // 128, (T + 63) // 64
+    ds_bytes = S * H * nkb * nt * 16384
+    lse2_bytes = ((S * H * nt * 512 + 256) + 127) // 128 * 128
+    G, total = S * H, S * H * nkb
+    rec = ws[ds_bytes + lse2_bytes + 1024: ds_bytes + lse2_bytes + 1024 + (total + 1) * 256].cpu().numpy().view(np.int32).reshape(total + 1, 64)
+    F = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"DKV3_REC_([A-Z0-9_]+) = (\d+)",
+             open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "halva_amd", "csrc", "sdpa_dkv3_loop_rec.inc")).read()))
+    assert not rec[total].any()                                   # the "queues are empty" record
+    INF = 0x7fffffff
+    seen, idx = set(), 0
+    for x in range(8):                                            # the queues lie one behind the other; queue x holds the pairs x, x + 8, ...
+        ng = (G - x + 7) // 8 if x < G else 0
+        for j in range(ng * nkb):
+            if order == 1:
+                kb, gi = divmod(j, ng)
+            elif order == 2:
+                hl = (nkb + 1) // 2
+                if j < ng * hl:
+                    gi, kb = divmod(j, hl)
+                else:
+                    q, gi = divmod(j - ng * hl, ng)
+                    kb = hl + q
+            else:
+                gi, kb = divmod(j, nkb)
+            g = x + 8 * gi
+            s_, hd = divmod(g, H)
+            r = rec[idx]
+            idx += 1
+            seen.add((s_, hd, kb))
+            start, ln = starts[s_], lens[s_]
+            a, b = (br[0][s_], br[1][s_]) if br else (INF, INF)
+            # which 64-row steps see keys [kb * 128, kb * 128 + 128): straight from the masks
+            keys = np.arange(kb * 128, kb * 128 + 128) - start
+            kvalid = (keys >= 0) & (keys < ln)
+            rows = np.arange(ln)
+            vis = (rows[:, None] >= keys[None, :]) & kvalid[None, :] & ~((rows[:, None] >= b) & (keys[None, :] >= a) & (keys[None, :] < b))
+            steps = np.nonzero([vis[t0:t0 + 64].any() for t0 in range(0, ln, 64)])[0]
+            want_n = 0 if len(steps) == 0 else int(steps[-1]) + 1 - max(0, kb * 128 - start) // 64
+            assert r[F["VALID"]] == 1 and (r[F["S"]], r[F["HD"]], r[F["KB"]]) == (s_, hd, kb), (idx, r[:4])
+            assert (r[F["START"]], r[F["LEN"]], r[F["BR_A"]], r[F["BR_B"]]) == (start, ln, a, b)
+            q_begin = max(0, kb * 128 - start) // 64 * 64
+            assert r[F["KBLK_MIN"]] == kb * 128 - start and r[F["Q_BEGIN"]] == q_begin
+            # the record's step count covers every step that sees a key of the block (and may run past them to the block's nominal end)
+            assert r[F["NTILES"]] >= want_n, (case, s_, hd, kb, r[F["NTILES"]], want_n)
+            if r[F["NTILES"]]:
+                t_all = range(r[F["NTILES"]])
+                full = [bool(vis[q_begin + 64 * t: q_begin + 64 * t + 64].all()) and q_begin + 64 * t + 64 <= ln for t in t_all]
+                n0, n2, n1, t_side = r[F["N02"]] & 0xffff, (r[F["N02"]] >> 16) & 0xffff, r[F["N1"]], r[F["T_SIDE"]]
+                assert n0 + n1 + n2 == t_side <= r[F["NTILES"]]
+                assert all(full[n0:n0 + n1]), (case, kb, n0, n1, full)          # a step run through the PLAIN body must need no mask at all
+                assert r[F["NDMA"]] == min(t_side, max(0, r[F["NTILES"]] - 3))
+                assert r[F["PREFETCHABLE"]] in (0, min(3, r[F["NTILES"]]))
+            for w in range(4):
+                assert r[F["ROWS_OK0"] + w] == min(32, max(0, T - (kb * 128 + 32 * w)))
+                t = min(kb * 128 + 32 * w, T - 1)
+                assert r[F["ROPE_POS0"] + w] == (a + (t - b) if t >= b else t)
+            assert r[F["Q_IN_B0"]] == int(q_begin >= b) and r[F["ALL_VALID"]] == int(kvalid.all())
+    assert idx == total and len(seen) == total                   # every item exactly once
+
+
 def test_dkv3_plain_hip_twin_matches_the_generated_loop():
     """HALVA_DKV3_ASM=0 runs sdpa_bwd_dkv3 with every step in plain HIP (sdpa_dkv3.h: dkv3_hip_step) - the readable statement of what the
     generated asm blocks compute, same ring protocol, same masks.  The two must agree to the last bit on a packed, ragged launch (the
