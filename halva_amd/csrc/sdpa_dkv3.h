@@ -107,7 +107,8 @@ __device__ __forceinline__ unsigned dkv3_piece_voff(int64_t ld, int wave, int la
 // 8-byte pieces of the pass to [row][128 bytes] with the 16-byte chunk index XORed by (row >> 1) & 7, reads back 16 bytes of row 8 j + (lane >> 3),
 // chunk lane & 7, and every store instruction writes eight whole 128-byte row pieces - instead of 16 bytes into each of 32 rows, which the CU's address
 // unit takes a lane at a time (rows converted and stored: 5 180 cycles per item, profiles/r04_dkv3_anatomy.log).  row0: the wave's first row; rows_ok:
-// how many of its 32 rows exist in the tensor.  mul: per KEY lane (0 for a key outside the sequence).
+// how many of its 32 rows exist in the tensor.  mul: the scale of the rows (MUL = false: none, the dV rows; a key outside the sequence needs no 0: every
+// step of such a key is a masked one, its P is exactly 0 and so are its accumulators).
 // ROPE (round 5, the dK rows of halva_sdpa_branch_bwd_rope): the inverse rotation applied on the way (store_rows_T_rope's arithmetic: row rounded to
 // bf16, rotated with the bf16 table entries of the KEY's position, rounded again); elements d and d + 64 are the same register of tiles dt and dt + 2.
 // rope_cos / rope_sin: the wave's 4-KiB blocks of table rows in LDS (dkv3_rope_request_lds below), landed.
